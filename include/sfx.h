@@ -1,0 +1,203 @@
+/*
+ * sfx.h -- C ABI of libsfx: the MI355X (gfx950) 2D XPBD physics tick.
+ *
+ * This is the drop-in boundary for starframe's per-frame physics tick
+ * (SURVEY.md section 8b).  The reference (m0lentum/starframe, Rust) has NO FFI
+ * or plugin interface for this path: physics is ordinary Rust called directly,
+ * and its source is not present in /root/reference (README.md:1-3 is a redirect
+ * stub).  Every entry point below therefore cites the *contract line* it
+ * implements (BASELINE.json:5 "north_star") instead of a reference file:line;
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all array arguments are caller-owned host
+ *    memory borrowed for the duration of the call;
+ *  - every function returns SFX_OK (0) or a negative sfx_status, never throws,
+ *    never aborts; sfx_last_error() gives a human readable reason;
+ *  - a world is not thread-safe (the reference tick takes `&mut self`);
+ *  - scalars are f32, rotations are unit complex numbers (cos, sin), units are
+ *    metres / seconds / radians.
+ */
+#ifndef SFX_H
+#define SFX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFX_ABI_VERSION 1u
+
+typedef enum sfx_status {
+    SFX_OK = 0,
+    SFX_ERR_INVALID = -1,     /* bad argument / call order                      */
+    SFX_ERR_UNSUPPORTED = -2, /* outside the documented limits                  */
+    SFX_ERR_DEVICE = -3,      /* HIP / RCCL failure (message in sfx_last_error) */
+    SFX_ERR_CAPACITY = -4,    /* a device buffer overflowed (pairs, colours)    */
+    SFX_ERR_NOMEM = -5
+} sfx_status;
+
+/* collider shapes: BASELINE.json:5 "circle, rectangle and rounded-polygon/capsule" */
+typedef enum sfx_shape_type {
+    SFX_SHAPE_NONE = 0,    /* body has no collider                                     */
+    SFX_SHAPE_CIRCLE = 1,  /* p[2] = radius                                            */
+    SFX_SHAPE_RECT = 2,    /* p[0],p[1] = half extents, p[2] = rounding radius (>= 0)  */
+    SFX_SHAPE_CAPSULE = 3, /* p[0] = half length along local x, p[2] = radius          */
+    SFX_SHAPE_POLY = 4     /* convex CCW polygon, 3..8 verts in the pool, p[2] = rounding */
+} sfx_shape_type;
+
+#define SFX_MAX_POLY_VERTS 8u
+#define SFX_WORLD_BODY 0xFFFFFFFFu /* constraint end attached to the world */
+#define SFX_MAX_COLORS 64u
+
+/* physics config struct (BASELINE.json:5 "physics config") */
+typedef struct sfx_config {
+    uint32_t struct_size;   /* = sizeof(sfx_config), for ABI growth                  */
+    int32_t device;         /* HIP device ordinal                                    */
+    uint32_t substeps;      /* substeps per tick (>= 1)                              */
+    float gravity[2];
+    float aabb_margin;      /* fixed AABB padding (m); velocity*dt is added per frame */
+    float cell_size;        /* broadphase cell edge (m); 0 = derive from shapes      */
+    uint32_t grid_log2[2];  /* wrapped grid is 2^gx by 2^gy cells; 0 = auto          */
+    uint32_t max_pairs;     /* candidate pair capacity; 0 = 12 * bodies              */
+    uint32_t color_rounds;  /* parallel colouring rounds before the serial finish; 0 = 12 */
+    uint32_t launch_colors; /* colours that get their own launch; the rest share a
+                               single-workgroup tail kernel; 0 = 16                  */
+    float restitution_threshold; /* restitution is dropped when |vn_pre| <= this * |g| * h; 0 = 2.0 */
+    uint32_t flags;         /* SFX_CFG_* */
+} sfx_config;
+
+#define SFX_CFG_USE_GRAPH 1u     /* replay the tick from a captured hipGraph        */
+#define SFX_CFG_NO_FRICTION 2u   /* skip static + dynamic friction (debug)          */
+
+/* collider component (BASELINE.json:5 "body/collider/material components").
+ * Collider k belongs to body k (one collider per body, no local offset). */
+typedef struct sfx_collider {
+    uint32_t type;      /* sfx_shape_type                                   */
+    uint32_t material;  /* index into the material table                    */
+    uint32_t category;  /* layer bits this collider is in                   */
+    uint32_t mask;      /* layer bits it collides with                      */
+    uint32_t group;     /* != 0: never collides with the same group         */
+    float p[3];         /* shape parameters, see sfx_shape_type             */
+    uint32_t poly_offset; /* first vertex in the pool (SFX_SHAPE_POLY)      */
+    uint32_t poly_count;  /* vertex count (SFX_SHAPE_POLY)                  */
+} sfx_collider;
+
+typedef struct sfx_material {
+    float restitution;
+    float static_friction;
+    float dynamic_friction;
+} sfx_material;
+
+/* distance constraint between two anchors (BASELINE.json:10 "distance-constrained links") */
+typedef struct sfx_distance_constraint {
+    uint32_t body_a;     /* body index or SFX_WORLD_BODY                         */
+    uint32_t body_b;
+    float anchor_a[2];   /* body-local anchor (world position for SFX_WORLD_BODY) */
+    float anchor_b[2];
+    float rest_length;
+    float compliance;    /* XPBD alpha (m/N); 0 = rigid                           */
+} sfx_distance_constraint;
+
+/* one narrowphase manifold, as returned by sfx_debug_contacts */
+typedef struct sfx_contact {
+    uint32_t body_a, body_b; /* a < b                                        */
+    uint32_t count;          /* 0, 1 or 2 points                             */
+    float normal[2];         /* unit, points from a to b                     */
+    float depth[2];          /* penetration depth per point (> 0)            */
+    float point_a[2][2];     /* world point on a's surface, per point        */
+    float point_b[2][2];     /* world point on b's surface, per point        */
+} sfx_contact;
+
+typedef struct sfx_frame_stats {
+    uint32_t n_bodies;
+    uint32_t n_small;        /* colliders sorted into the grid               */
+    uint32_t n_large;        /* colliders tested against everything          */
+    uint32_t n_pairs;        /* candidate pairs of the last tick             */
+    uint32_t n_colors;       /* colours used by the candidate-pair graph     */
+    uint32_t n_leftover;     /* pairs coloured by the serial finish          */
+    uint32_t n_contacts;     /* contact points of the last substep           */
+    uint32_t n_joint_colors;
+    uint32_t overflow;       /* != 0: a capacity was exceeded this tick      */
+    uint32_t launches;       /* kernel launches issued by the last tick      */
+    float max_depth;         /* deepest penetration seen in the last substep */
+    float kinetic_energy;    /* sum 1/2 m v^2 + 1/2 I w^2 over dynamic bodies */
+    uint32_t color_count[SFX_MAX_COLORS];
+} sfx_frame_stats;
+
+/* per kernel-class device time, filled while profiling is on */
+typedef enum sfx_kernel_class {
+    SFX_K_AABB_COUNT = 0, SFX_K_SCAN, SFX_K_SCATTER, SFX_K_PAIR_COUNT, SFX_K_PAIR_FILL,
+    SFX_K_COLOR, SFX_K_COLOR_SORT, SFX_K_INTEGRATE, SFX_K_SOLVE_JOINTS, SFX_K_SOLVE_POS,
+    SFX_K_SOLVE_POS_TAIL, SFX_K_DERIVE_VEL, SFX_K_SOLVE_VEL, SFX_K_SOLVE_VEL_TAIL,
+    SFX_K_STATS, SFX_K_HALO, SFX_K_CLASSES
+} sfx_kernel_class;
+
+typedef struct sfx_kernel_time {
+    double total_ms;   /* summed device time between the bracketing events */
+    uint64_t launches;
+    uint64_t items;    /* bodies / pairs / constraints processed            */
+} sfx_kernel_time;
+
+typedef struct sfx_world sfx_world;
+
+/* ---- lifetime ------------------------------------------------------------ */
+/* "physics config" -> world.  Fails with SFX_ERR_DEVICE when no HIP device is usable:
+ * there is no CPU fallback behind this ABI. */
+int sfx_create(const sfx_config* cfg, sfx_world** out);
+void sfx_destroy(sfx_world* w); /* NULL is a no-op */
+uint32_t sfx_abi_version(void);
+void sfx_default_config(sfx_config* cfg);
+
+/* ---- scene upload (BASELINE.json:5 "body/collider/material components") --- */
+/* SoA body state; pos/rot/vel are [n][2], the rest [n].  inv_mass == 0 and
+ * inv_inertia == 0 marks a static (or, with a velocity, kinematic) body. */
+int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* rot,
+                      const float* vel, const float* angvel, const float* inv_mass,
+                      const float* inv_inertia);
+/* n must equal the body count.  poly_verts is the [n_poly_verts][2] vertex pool. */
+int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* colliders,
+                         const float* poly_verts, uint32_t n_poly_verts);
+int sfx_upload_materials(sfx_world* w, uint32_t n, const sfx_material* materials);
+int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constraint* c);
+
+/* ---- the tick (BASELINE.json:5 "the per-frame tick entry point") ---------- */
+/* One frame: broadphase + colouring once, then `substeps` x (integrate, position solve
+ * with fused narrowphase, velocity derive, velocity pass).  Asynchronous on the world's
+ * stream; sfx_sync / any download waits for it. */
+int sfx_step(sfx_world* w, float frame_dt);
+int sfx_sync(sfx_world* w);
+
+int sfx_download_poses(sfx_world* w, float* pos, float* rot);
+int sfx_download_velocities(sfx_world* w, float* vel, float* angvel);
+
+/* ---- parity hooks (slow paths, used by tests) ----------------------------- */
+/* world AABBs [n][4] = (lo.x, lo.y, hi.x, hi.y) of the last tick's broadphase */
+int sfx_debug_aabbs(sfx_world* w, float* out);
+/* candidate pairs of the last tick as ascending keys (a << 32 | b), a < b */
+int sfx_debug_pairs(sfx_world* w, uint64_t* keys, size_t cap, size_t* n);
+/* the same pairs in device (colour-sorted) order with their colour */
+int sfx_debug_pair_colors(sfx_world* w, uint64_t* keys, uint8_t* colors, size_t cap, size_t* n);
+/* runs only the broadphase + colouring of a tick (no substeps), for dt = frame_dt */
+int sfx_debug_broadphase(sfx_world* w, float frame_dt);
+/* narrowphase of every candidate pair at the current poses, in sfx_debug_pairs order */
+int sfx_debug_contacts(sfx_world* w, sfx_contact* out, size_t cap, size_t* n);
+/* joint order after colouring: perm[k] = index into the uploaded constraint array */
+int sfx_debug_joint_order(sfx_world* w, uint32_t* perm, uint8_t* colors, size_t cap, size_t* n);
+
+/* ---- reporting ------------------------------------------------------------ */
+int sfx_stats(sfx_world* w, sfx_frame_stats* out); /* synchronises */
+int sfx_set_profiling(sfx_world* w, int on);       /* brackets every launch with events */
+int sfx_kernel_times(sfx_world* w, sfx_kernel_time* out /* [SFX_K_CLASSES] */, int reset);
+const char* sfx_kernel_class_name(int cls);
+/* device time of everything enqueued between begin and end, via events on the world's stream */
+int sfx_timer_begin(sfx_world* w);
+int sfx_timer_end(sfx_world* w, double* ms); /* synchronises */
+const char* sfx_last_error(sfx_world* w); /* w may be NULL: last create error */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SFX_H */

@@ -1,0 +1,157 @@
+"""Python handle over the CPU oracle (oracle/libsfx_oracle.so).  TEST INFRASTRUCTURE ONLY.
+
+PARITY UNPINNED (see oracle/sfx_oracle.h): this checks libsfx against this repository's own
+CPU restatement of the published XPBD algorithm, not against starframe's Rust code, which
+was unavailable.  Import this only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from starframe_amd import _abi
+from starframe_amd._abi import SfxConfig, contact_dtype, fptr, make_config, vptr
+from starframe_amd.world import WorldBase
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsfx_oracle.so")
+
+ORDER_SEQUENTIAL = 0
+ORDER_COLORED = 1
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    src_newer = (not os.path.exists(LIB_PATH)) or any(
+        os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB_PATH)
+        for f in ("sfx_oracle.c", "sfx_oracle.h")
+    )
+    if src_newer:
+        build()
+    lib = C.CDLL(LIB_PATH)
+    P, vp = C.POINTER, C.c_void_p
+    lib.sfo_create.argtypes = [P(SfxConfig)]
+    lib.sfo_create.restype = vp
+    lib.sfo_destroy.argtypes = [vp]
+    lib.sfo_destroy.restype = None
+    _abi.bind_world_api(lib, "sfo_")
+    lib.sfo_resolved_config.argtypes = [vp, P(SfxConfig)]
+    lib.sfo_resolved_config.restype = None
+    lib.sfo_step.argtypes = [vp, C.c_float, C.c_int]
+    lib.sfo_step.restype = C.c_int
+    lib.sfo_broadphase.argtypes = [vp, C.c_float]
+    lib.sfo_broadphase.restype = C.c_int
+    lib.sfo_aabbs.argtypes = [vp, P(C.c_float)]
+    for n in ("sfo_pairs_grid", "sfo_pairs_sweep", "sfo_pairs_brute"):
+        getattr(lib, n).argtypes = [vp, vp, C.c_size_t]
+        getattr(lib, n).restype = C.c_size_t
+    lib.sfo_pair_colors.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.sfo_pair_colors.restype = C.c_size_t
+    lib.sfo_contacts.argtypes = [vp, vp, C.c_size_t]
+    lib.sfo_contacts.restype = C.c_size_t
+    lib.sfo_contact_pair.argtypes = [vp, C.c_uint32, C.c_uint32, vp]
+    lib.sfo_contact_pair.restype = C.c_int
+    lib.sfo_joint_order.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.sfo_joint_order.restype = C.c_size_t
+    _lib = lib
+    return lib
+
+
+class OracleWorld(WorldBase):
+    prefix = "sfo_"
+
+    def __init__(self, cfg=None, **cfg_kw):
+        self.lib = load()
+        self.cfg = cfg or make_config(**cfg_kw)
+        self.handle = C.c_void_p(self.lib.sfo_create(C.byref(self.cfg)))
+        if not self.handle:
+            raise MemoryError("sfo_create")
+
+    @classmethod
+    def from_scene(cls, scene, **cfg_kw):
+        kw = dict(substeps=scene.substeps, gravity=scene.gravity, aabb_margin=scene.aabb_margin)
+        kw.update(cfg_kw)
+        return cls(**kw).upload(scene)
+
+    def close(self):
+        if self.handle:
+            self.lib.sfo_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def resolved_config(self):
+        out = SfxConfig()
+        self.lib.sfo_resolved_config(self.handle, C.byref(out))
+        return out
+
+    def step(self, dt, order=ORDER_COLORED):
+        self._check(self.lib.sfo_step(self.handle, dt, order))
+
+    def sync(self):
+        pass
+
+    def broadphase(self, dt):
+        self._check(self.lib.sfo_broadphase(self.handle, dt))
+
+    def aabbs(self):
+        out = np.empty((self.n, 4), np.float32)
+        self.lib.sfo_aabbs(self.handle, fptr(out))
+        return out
+
+    def _pairs(self, fn):
+        cap = max(int(self.stats().n_pairs), 1024)
+        while True:
+            keys = np.empty(cap, np.uint64)
+            n = getattr(self.lib, fn)(self.handle, vptr(keys), cap)
+            if n <= cap:
+                return keys[:n]
+            cap = n
+
+    def pairs(self):
+        return self._pairs("sfo_pairs_grid")
+
+    def pairs_sweep(self):
+        return self._pairs("sfo_pairs_sweep")
+
+    def pairs_brute(self):
+        return self._pairs("sfo_pairs_brute")
+
+    def pair_colors(self):
+        cap = max(int(self.stats().n_pairs), 1)
+        keys = np.empty(cap, np.uint64)
+        col = np.empty(cap, np.uint8)
+        n = self.lib.sfo_pair_colors(self.handle, vptr(keys), vptr(col), cap)
+        return keys[:n], col[:n]
+
+    def contacts(self):
+        cap = max(int(self.stats().n_pairs), 1)
+        out = np.zeros(cap, contact_dtype)
+        n = self.lib.sfo_contacts(self.handle, vptr(out), cap)
+        return out[:n]
+
+    def contact_pair(self, a, b):
+        out = np.zeros(1, contact_dtype)
+        self._check(self.lib.sfo_contact_pair(self.handle, a, b, vptr(out)))
+        return out[0]
+
+    def joint_order(self):
+        cap = max(self.m, 1)
+        perm = np.empty(cap, np.uint32)
+        col = np.empty(cap, np.uint8)
+        n = self.lib.sfo_joint_order(self.handle, vptr(perm), vptr(col), cap)
+        return perm[:n], col[:n]

@@ -1,0 +1,1261 @@
+/*
+ * sfx_oracle.c -- CPU oracle for the libsfx physics tick.  TEST INFRASTRUCTURE ONLY.
+ * PARITY UNPINNED -- see sfx_oracle.h for why and for what this restates.
+ *
+ * Sources restated (no reference file:line exists; the reference source is absent):
+ *   [XPBD-RB]  Mueller, Macklin, Chentanez, Jeschke, Kim: "Detailed Rigid Body Simulation
+ *              with Extended Position Based Dynamics", SCA 2020.  Alg. 2 (substep loop),
+ *              sec. 3.3 (positional constraint), 3.5 (contacts + static friction),
+ *              3.6 (velocity pass: dynamic friction, restitution).
+ *   [XPBD]     Macklin, Mueller, Chentanez: "XPBD", MIG 2016 (compliance term).
+ *   [SPEC]     /root/repo/BASELINE.json:5 (kernel list, tolerances), SURVEY.md 8a-8d.
+ *   [DESIGN]   DESIGN.md "Contract" (AABB formula, candidate set definition, grid
+ *              enumeration order, colouring algorithm, narrowphase conventions).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (oracle/Makefile).
+ */
+#include "sfx_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define EPS_LEN 1e-9f
+#define NO_COLOR 0xFFu
+
+typedef struct { float x, y; } v2;
+
+typedef struct {
+    int n;
+    float vx[SFX_MAX_POLY_VERTS], vy[SFX_MAX_POLY_VERTS];
+    float nx[SFX_MAX_POLY_VERTS], ny[SFX_MAX_POLY_VERTS];
+    float r;
+} core_t;
+
+/* per candidate pair solver record: what the position solve leaves for the velocity pass */
+typedef struct {
+    uint32_t count;
+    float nx, ny;
+    float ra[2][2], rb[2][2]; /* body-local anchors */
+    float lam[2];             /* normal lambda of this substep */
+    float vn_pre[2];          /* normal relative velocity before the position solve */
+    float mu_s, mu_d, rest;
+} pair_rec;
+
+struct sfo_world {
+    sfx_config cfg;
+    float cell, inv_cell;
+    uint32_t gxl, gyl;
+    uint32_t n;
+    float *pos, *rot, *vel, *angvel, *inv_mass, *inv_inertia, *prev_pos, *prev_rot;
+    sfx_collider* col;
+    float *poly, *poly_nrm;
+    uint32_t n_poly;
+    sfx_material* mats;
+    uint32_t n_mats;
+    /* joints */
+    uint32_t m;
+    sfx_distance_constraint* joints;
+    uint32_t* joint_perm; /* colour-major order */
+    uint8_t* joint_color;
+    uint32_t n_joint_colors;
+    /* per tick */
+    float* aabb;
+    uint32_t n_small, n_large;
+    uint32_t max_pairs, n_pairs;
+    uint32_t *pa, *pb; /* emission order */
+    uint8_t* color;
+    uint32_t n_colors, n_leftover, overflow;
+    uint32_t color_count[SFX_MAX_COLORS];
+    uint32_t* order;   /* processing order (indices into pa/pb) */
+    pair_rec* rec;
+    uint32_t n_contacts;
+    float max_depth;
+};
+
+/* ------------------------------------------------------------------ config */
+
+static void resolve_defaults(sfx_config* c) {
+    if (c->substeps == 0) c->substeps = 1;
+    if (c->color_rounds == 0) c->color_rounds = 12;
+    if (c->color_rounds > 60) c->color_rounds = 60;
+    if (c->launch_colors == 0) c->launch_colors = 16;
+    if (c->restitution_threshold == 0.0f) c->restitution_threshold = 2.0f;
+}
+
+sfo_world* sfo_create(const sfx_config* cfg) {
+    sfo_world* w = (sfo_world*)calloc(1, sizeof(sfo_world));
+    if (!w) return NULL;
+    w->cfg = *cfg;
+    resolve_defaults(&w->cfg);
+    return w;
+}
+
+void sfo_destroy(sfo_world* w) {
+    if (!w) return;
+    free(w->pos); free(w->rot); free(w->vel); free(w->angvel); free(w->inv_mass);
+    free(w->inv_inertia); free(w->prev_pos); free(w->prev_rot); free(w->col); free(w->poly);
+    free(w->poly_nrm); free(w->mats); free(w->joints); free(w->joint_perm); free(w->joint_color);
+    free(w->aabb); free(w->pa); free(w->pb); free(w->color); free(w->order); free(w->rec);
+    free(w);
+}
+
+static float* dupf(const float* src, size_t n) {
+    float* p = (float*)malloc((n ? n : 1) * sizeof(float));
+    if (p && src && n) memcpy(p, src, n * sizeof(float));
+    return p;
+}
+
+int sfo_upload_bodies(sfo_world* w, uint32_t n, const float* pos, const float* rot,
+                      const float* vel, const float* angvel, const float* inv_mass,
+                      const float* inv_inertia) {
+    free(w->pos); free(w->rot); free(w->vel); free(w->angvel); free(w->inv_mass);
+    free(w->inv_inertia); free(w->prev_pos); free(w->prev_rot);
+    w->n = n;
+    w->pos = dupf(pos, 2u * n); w->rot = dupf(rot, 2u * n); w->vel = dupf(vel, 2u * n);
+    w->angvel = dupf(angvel, n); w->inv_mass = dupf(inv_mass, n);
+    w->inv_inertia = dupf(inv_inertia, n);
+    w->prev_pos = dupf(pos, 2u * n); w->prev_rot = dupf(rot, 2u * n);
+    return SFX_OK;
+}
+
+static int is_dynamic(const sfo_world* w, uint32_t i) {
+    return w->inv_mass[i] > 0.0f || w->inv_inertia[i] > 0.0f;
+}
+
+/* [DESIGN] bounding diameter of a shape, used only for the automatic cell size */
+static float shape_diameter(const sfo_world* w, const sfx_collider* c) {
+    switch (c->type) {
+    case SFX_SHAPE_CIRCLE: return 2.0f * c->p[2];
+    case SFX_SHAPE_RECT: return 2.0f * (sqrtf(c->p[0] * c->p[0] + c->p[1] * c->p[1]) + c->p[2]);
+    case SFX_SHAPE_CAPSULE: return 2.0f * (c->p[0] + c->p[2]);
+    case SFX_SHAPE_POLY: {
+        float m = 0.0f;
+        for (uint32_t k = 0; k < c->poly_count; ++k) {
+            float x = w->poly[2 * (c->poly_offset + k)], y = w->poly[2 * (c->poly_offset + k) + 1];
+            float d = sqrtf(x * x + y * y);
+            if (d > m) m = d;
+        }
+        return 2.0f * (m + c->p[2]);
+    }
+    default: return 0.0f;
+    }
+}
+
+static uint32_t ceil_log2(uint32_t v) {
+    uint32_t l = 0;
+    while ((1u << l) < v && l < 31) ++l;
+    return l;
+}
+
+/* [DESIGN] DESIGN.md "Contract / grid": cell = 1.25 * (largest dynamic diameter + 2 margin);
+ * grid = smallest square power-of-two torus with >= 2 cells per body, 4..4096 per side. */
+static void resolve_grid(sfo_world* w) {
+    float cell = w->cfg.cell_size;
+    if (!(cell > 0.0f)) {
+        float dmax = 0.0f;
+        for (uint32_t i = 0; i < w->n; ++i) {
+            if (!is_dynamic(w, i) || w->col[i].type == SFX_SHAPE_NONE) continue;
+            float d = shape_diameter(w, &w->col[i]);
+            if (d > dmax) dmax = d;
+        }
+        cell = dmax > 0.0f ? 1.25f * (dmax + 2.0f * w->cfg.aabb_margin) : 1.0f;
+    }
+    w->cell = cell;
+    w->inv_cell = 1.0f / cell;
+    uint32_t gx = w->cfg.grid_log2[0], gy = w->cfg.grid_log2[1];
+    if (gx == 0 || gy == 0) {
+        uint32_t side = (uint32_t)ceil(sqrt(2.0 * (double)(w->n ? w->n : 1)));
+        uint32_t l = ceil_log2(side);
+        if (l < 2) l = 2;
+        if (l > 12) l = 12;
+        gx = gy = l;
+    }
+    if (gx < 2) gx = 2;
+    if (gy < 2) gy = 2;
+    if (gx > 12) gx = 12;
+    if (gy > 12) gy = 12;
+    w->gxl = gx; w->gyl = gy;
+}
+
+int sfo_upload_colliders(sfo_world* w, uint32_t n, const sfx_collider* colliders,
+                         const float* poly_verts, uint32_t n_poly_verts) {
+    if (n != w->n) return SFX_ERR_INVALID;
+    free(w->col); free(w->poly); free(w->poly_nrm);
+    w->col = (sfx_collider*)malloc((n ? n : 1) * sizeof(sfx_collider));
+    memcpy(w->col, colliders, n * sizeof(sfx_collider));
+    w->n_poly = n_poly_verts;
+    w->poly = dupf(poly_verts, 2u * n_poly_verts);
+    w->poly_nrm = (float*)calloc(2u * n_poly_verts + 1, sizeof(float));
+    for (uint32_t i = 0; i < n; ++i) {
+        const sfx_collider* c = &w->col[i];
+        if (c->type != SFX_SHAPE_POLY) continue;
+        if (c->poly_count < 3 || c->poly_count > SFX_MAX_POLY_VERTS ||
+            c->poly_offset + c->poly_count > n_poly_verts) return SFX_ERR_INVALID;
+        for (uint32_t k = 0; k < c->poly_count; ++k) {
+            uint32_t k0 = c->poly_offset + k, k1 = c->poly_offset + (k + 1) % c->poly_count;
+            float ex = w->poly[2 * k1] - w->poly[2 * k0], ey = w->poly[2 * k1 + 1] - w->poly[2 * k0 + 1];
+            float len = sqrtf(ex * ex + ey * ey);
+            w->poly_nrm[2 * k0] = ey / len;
+            w->poly_nrm[2 * k0 + 1] = -ex / len;
+        }
+    }
+    resolve_grid(w);
+    free(w->aabb); free(w->pa); free(w->pb); free(w->color); free(w->order); free(w->rec);
+    w->max_pairs = w->cfg.max_pairs ? w->cfg.max_pairs : 12u * n;
+    if (w->max_pairs < 1024u) w->max_pairs = 1024u;
+    w->aabb = (float*)calloc(4u * n + 4, sizeof(float));
+    w->pa = (uint32_t*)malloc(w->max_pairs * sizeof(uint32_t));
+    w->pb = (uint32_t*)malloc(w->max_pairs * sizeof(uint32_t));
+    w->color = (uint8_t*)malloc(w->max_pairs);
+    w->order = (uint32_t*)malloc(w->max_pairs * sizeof(uint32_t));
+    w->rec = (pair_rec*)calloc(w->max_pairs, sizeof(pair_rec));
+    w->n_pairs = 0;
+    return SFX_OK;
+}
+
+int sfo_upload_materials(sfo_world* w, uint32_t n, const sfx_material* materials) {
+    free(w->mats);
+    w->mats = (sfx_material*)malloc((n ? n : 1) * sizeof(sfx_material));
+    memcpy(w->mats, materials, n * sizeof(sfx_material));
+    w->n_mats = n;
+    return SFX_OK;
+}
+
+void sfo_resolved_config(const sfo_world* w, sfx_config* out) {
+    *out = w->cfg;
+    out->cell_size = w->cell;
+    out->grid_log2[0] = w->gxl;
+    out->grid_log2[1] = w->gyl;
+    out->max_pairs = w->max_pairs;
+}
+
+/* ------------------------------------------------------------------ colouring
+ * [DESIGN] DESIGN.md "Contract / colouring".  Edge colouring of the constraint graph:
+ * two constraints that share a dynamic body never get the same colour.  `rounds` parallel
+ * rounds (each uncoloured edge proposes a hashed colour out of a small window of colours
+ * free at both ends; per (body, colour mod 8) the lowest priority wins; an edge is coloured
+ * when it wins at both dynamic ends), then a serial first-fit finish.  Deterministic in the
+ * edge order. */
+
+static uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
+static int kth_set_bit(uint64_t m, uint32_t k) {
+    for (uint32_t i = 0; i < k; ++i) m &= m - 1;
+    return __builtin_ctzll(m);
+}
+
+/* dyn_a/dyn_b: whether the end is a dynamic body.  Returns number of colours, fills
+ * color[], *leftover, *overflow. */
+static uint32_t color_edges(uint32_t n_bodies, uint32_t ne, const uint32_t* ea, const uint32_t* eb,
+                            const uint8_t* dyn, uint32_t rounds, uint8_t* color,
+                            uint32_t* leftover, uint32_t* overflow) {
+    uint64_t* used = (uint64_t*)calloc(n_bodies ? n_bodies : 1, sizeof(uint64_t));
+    uint32_t* deg = (uint32_t*)calloc(n_bodies ? n_bodies : 1, sizeof(uint32_t));
+    uint64_t* claim = (uint64_t*)malloc((size_t)(n_bodies ? n_bodies : 1) * 8 * sizeof(uint64_t));
+    uint8_t* prop = (uint8_t*)malloc(ne ? ne : 1);
+    uint64_t* prio = (uint64_t*)malloc((ne ? ne : 1) * sizeof(uint64_t));
+    memset(claim, 0xFF, (size_t)(n_bodies ? n_bodies : 1) * 8 * sizeof(uint64_t));
+    *overflow = 0;
+    for (uint32_t e = 0; e < ne; ++e) {
+        color[e] = NO_COLOR;
+        if (ea[e] != SFX_WORLD_BODY && dyn[ea[e]]) deg[ea[e]]++;
+        if (eb[e] != SFX_WORLD_BODY && dyn[eb[e]]) deg[eb[e]]++;
+    }
+    for (uint32_t r = 0; r < rounds; ++r) {
+        /* propose */
+        for (uint32_t e = 0; e < ne; ++e) {
+            if (color[e] != NO_COLOR) continue;
+            uint32_t a = ea[e], b = eb[e];
+            int da = a != SFX_WORLD_BODY && dyn[a], db = b != SFX_WORLD_BODY && dyn[b];
+            uint64_t ma = da ? used[a] : 0, mb = db ? used[b] : 0;
+            uint64_t freem = ~(ma | mb);
+            if (freem == 0) { prop[e] = NO_COLOR; *overflow = 1; continue; }
+            uint32_t dg = 1;
+            if (da && deg[a] > dg) dg = deg[a];
+            if (db && deg[b] > dg) dg = deg[b];
+            if (dg > 8) dg = 8;
+            uint32_t nfree = (uint32_t)__builtin_popcountll(freem);
+            if (dg > nfree) dg = nfree;
+            uint32_t h = mix32(e * 0x9E3779B1u + r * 0x7F4A7C15u + 0x165667B1u);
+            uint32_t k = mix32(h ^ 0xA5A5A5A5u) % dg;
+            uint32_t c = (uint32_t)kth_set_bit(freem, k);
+            prop[e] = (uint8_t)c;
+            uint64_t p = ((uint64_t)(63u - r) << 58) | ((uint64_t)(h >> 6) << 32) | e;
+            prio[e] = p;
+            if (da && p < claim[(size_t)a * 8 + (c & 7)]) claim[(size_t)a * 8 + (c & 7)] = p;
+            if (db && p < claim[(size_t)b * 8 + (c & 7)]) claim[(size_t)b * 8 + (c & 7)] = p;
+        }
+        /* resolve */
+        for (uint32_t e = 0; e < ne; ++e) {
+            if (color[e] != NO_COLOR || prop[e] == NO_COLOR) continue;
+            uint32_t a = ea[e], b = eb[e], c = prop[e];
+            int da = a != SFX_WORLD_BODY && dyn[a], db = b != SFX_WORLD_BODY && dyn[b];
+            int win = (!da || claim[(size_t)a * 8 + (c & 7)] == prio[e]) &&
+                      (!db || claim[(size_t)b * 8 + (c & 7)] == prio[e]);
+            if (!win) continue;
+            color[e] = (uint8_t)c;
+            if (da) { used[a] |= 1ull << c; deg[a]--; }
+            if (db) { used[b] |= 1ull << c; deg[b]--; }
+        }
+    }
+    /* serial first-fit finish */
+    *leftover = 0;
+    for (uint32_t e = 0; e < ne; ++e) {
+        if (color[e] != NO_COLOR) continue;
+        uint32_t a = ea[e], b = eb[e];
+        int da = a != SFX_WORLD_BODY && dyn[a], db = b != SFX_WORLD_BODY && dyn[b];
+        uint64_t freem = ~((da ? used[a] : 0) | (db ? used[b] : 0));
+        (*leftover)++;
+        if (freem == 0) { *overflow = 1; color[e] = 63; continue; }
+        uint32_t c = (uint32_t)__builtin_ctzll(freem);
+        color[e] = (uint8_t)c;
+        if (da) used[a] |= 1ull << c;
+        if (db) used[b] |= 1ull << c;
+    }
+    uint32_t nc = 0;
+    for (uint32_t e = 0; e < ne; ++e) if (color[e] + 1u > nc) nc = color[e] + 1u;
+    free(used); free(deg); free(claim); free(prop); free(prio);
+    return nc;
+}
+
+int sfo_upload_constraints(sfo_world* w, uint32_t m, const sfx_distance_constraint* c) {
+    free(w->joints); free(w->joint_perm); free(w->joint_color);
+    w->m = m;
+    w->joints = (sfx_distance_constraint*)malloc((m ? m : 1) * sizeof(*c));
+    memcpy(w->joints, c, m * sizeof(*c));
+    w->joint_perm = (uint32_t*)malloc((m ? m : 1) * sizeof(uint32_t));
+    w->joint_color = (uint8_t*)malloc(m ? m : 1);
+    uint32_t* ea = (uint32_t*)malloc((m ? m : 1) * sizeof(uint32_t));
+    uint32_t* eb = (uint32_t*)malloc((m ? m : 1) * sizeof(uint32_t));
+    uint8_t* dyn = (uint8_t*)malloc(w->n ? w->n : 1);
+    for (uint32_t i = 0; i < w->n; ++i) dyn[i] = (uint8_t)is_dynamic(w, i);
+    for (uint32_t k = 0; k < m; ++k) {
+        ea[k] = c[k].body_a; eb[k] = c[k].body_b;
+        if ((ea[k] != SFX_WORLD_BODY && ea[k] >= w->n) || (eb[k] != SFX_WORLD_BODY && eb[k] >= w->n)) {
+            free(ea); free(eb); free(dyn);
+            return SFX_ERR_INVALID;
+        }
+    }
+    uint32_t left, ovf;
+    w->n_joint_colors = color_edges(w->n, m, ea, eb, dyn, w->cfg.color_rounds, w->joint_color, &left, &ovf);
+    /* colour-major, stable */
+    uint32_t pos = 0;
+    for (uint32_t col = 0; col < w->n_joint_colors; ++col)
+        for (uint32_t k = 0; k < m; ++k)
+            if (w->joint_color[k] == col) w->joint_perm[pos++] = k;
+    free(ea); free(eb); free(dyn);
+    return ovf ? SFX_ERR_CAPACITY : SFX_OK;
+}
+
+/* ------------------------------------------------------------------ AABB
+ * [DESIGN] DESIGN.md "Contract / AABB".  Operation order is part of the contract. */
+static void compute_aabb(const sfo_world* w, uint32_t i, float dt, float* out) {
+    const sfx_collider* c = &w->col[i];
+    float px = w->pos[2 * i], py = w->pos[2 * i + 1];
+    float rc = w->rot[2 * i], rs = w->rot[2 * i + 1];
+    float minx, maxx, miny, maxy;
+    switch (c->type) {
+    case SFX_SHAPE_CIRCLE:
+        minx = -c->p[2]; maxx = c->p[2]; miny = -c->p[2]; maxy = c->p[2];
+        break;
+    case SFX_SHAPE_RECT: {
+        float ex = (fabsf(rc * c->p[0]) + fabsf(rs * c->p[1])) + c->p[2];
+        float ey = (fabsf(rs * c->p[0]) + fabsf(rc * c->p[1])) + c->p[2];
+        minx = -ex; maxx = ex; miny = -ey; maxy = ey;
+        break;
+    }
+    case SFX_SHAPE_CAPSULE: {
+        float ex = fabsf(rc * c->p[0]) + c->p[2];
+        float ey = fabsf(rs * c->p[0]) + c->p[2];
+        minx = -ex; maxx = ex; miny = -ey; maxy = ey;
+        break;
+    }
+    case SFX_SHAPE_POLY: {
+        minx = miny = INFINITY; maxx = maxy = -INFINITY;
+        for (uint32_t k = 0; k < c->poly_count; ++k) {
+            float lx = w->poly[2 * (c->poly_offset + k)], ly = w->poly[2 * (c->poly_offset + k) + 1];
+            float wx = rc * lx - rs * ly, wy = rs * lx + rc * ly;
+            minx = fminf(minx, wx); maxx = fmaxf(maxx, wx);
+            miny = fminf(miny, wy); maxy = fmaxf(maxy, wy);
+        }
+        minx -= c->p[2]; maxx += c->p[2]; miny -= c->p[2]; maxy += c->p[2];
+        break;
+    }
+    default: /* no collider: empty box */
+        out[0] = out[1] = INFINITY; out[2] = out[3] = -INFINITY;
+        return;
+    }
+    float padx = w->cfg.aabb_margin + fabsf(w->vel[2 * i]) * dt;
+    float pady = w->cfg.aabb_margin + fabsf(w->vel[2 * i + 1]) * dt;
+    out[0] = (px + minx) - padx;
+    out[1] = (py + miny) - pady;
+    out[2] = (px + maxx) + padx;
+    out[3] = (py + maxy) + pady;
+}
+
+static int pair_filter(const sfo_world* w, uint32_t i, uint32_t j) {
+    if (!is_dynamic(w, i) && !is_dynamic(w, j)) return 0;
+    const sfx_collider *a = &w->col[i], *b = &w->col[j];
+    if (!(a->category & b->mask) || !(b->category & a->mask)) return 0;
+    if (a->group != 0 && a->group == b->group) return 0;
+    return 1;
+}
+
+static int aabb_overlap(const float* A, const float* B) {
+    return A[0] <= B[2] && B[0] <= A[2] && A[1] <= B[3] && B[1] <= A[3];
+}
+
+static int cmp_u64(const void* a, const void* b) {
+    uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return x < y ? -1 : x > y;
+}
+
+static uint64_t pair_key(uint32_t i, uint32_t j) {
+    uint32_t a = i < j ? i : j, b = i < j ? j : i;
+    return ((uint64_t)a << 32) | b;
+}
+
+size_t sfo_pairs_brute(const sfo_world* w, uint64_t* keys, size_t cap) {
+    size_t n = 0;
+    for (uint32_t i = 0; i < w->n; ++i) {
+        if (w->col[i].type == SFX_SHAPE_NONE) continue;
+        for (uint32_t j = i + 1; j < w->n; ++j) {
+            if (w->col[j].type == SFX_SHAPE_NONE) continue;
+            if (aabb_overlap(&w->aabb[4 * i], &w->aabb[4 * j]) && pair_filter(w, i, j)) {
+                if (n < cap) keys[n] = pair_key(i, j);
+                ++n;
+            }
+        }
+    }
+    return n; /* already ascending */
+}
+
+typedef struct { float lo; uint32_t id; } sweep_ent;
+static int cmp_sweep(const void* a, const void* b) {
+    const sweep_ent *x = (const sweep_ent*)a, *y = (const sweep_ent*)b;
+    if (x->lo < y->lo) return -1;
+    if (x->lo > y->lo) return 1;
+    return x->id < y->id ? -1 : x->id > y->id;
+}
+
+size_t sfo_pairs_sweep(const sfo_world* w, uint64_t* keys, size_t cap) {
+    sweep_ent* s = (sweep_ent*)malloc((w->n ? w->n : 1) * sizeof(sweep_ent));
+    uint32_t ns = 0;
+    for (uint32_t i = 0; i < w->n; ++i)
+        if (w->col[i].type != SFX_SHAPE_NONE) { s[ns].lo = w->aabb[4 * i]; s[ns].id = i; ++ns; }
+    qsort(s, ns, sizeof(sweep_ent), cmp_sweep);
+    size_t n = 0;
+    for (uint32_t p = 0; p < ns; ++p) {
+        uint32_t i = s[p].id;
+        float hix = w->aabb[4 * i + 2];
+        for (uint32_t q = p + 1; q < ns && s[q].lo <= hix; ++q) {
+            uint32_t j = s[q].id;
+            if (aabb_overlap(&w->aabb[4 * i], &w->aabb[4 * j]) && pair_filter(w, i, j)) {
+                if (n < cap) keys[n] = pair_key(i, j);
+                ++n;
+            }
+        }
+    }
+    free(s);
+    qsort(keys, n < cap ? n : cap, sizeof(uint64_t), cmp_u64);
+    return n;
+}
+
+/* [DESIGN] DESIGN.md "Contract / grid": home cell = cell of the AABB's low corner on a
+ * 2^gx x 2^gy torus; small colliders (extent <= 0.9 cell) are counting-sorted by bucket
+ * (ascending id inside a bucket), large ones are kept in an ascending-id list.  Emission:
+ * per small slot the own cell (later slots only), then the forward neighbours
+ * (1,0) (-1,1) (0,1) (1,1), then every large; per large slot every later large. */
+static int32_t cell_coord(float lo, float inv_cell) {
+    float f = floorf(lo * inv_cell);
+    if (!(f > -1073741824.0f)) f = -1073741824.0f;
+    if (f > 1073741824.0f) f = 1073741824.0f;
+    return (int32_t)f;
+}
+
+static void emit_pair(sfo_world* w, uint32_t i, uint32_t j) {
+    if (!aabb_overlap(&w->aabb[4 * i], &w->aabb[4 * j]) || !pair_filter(w, i, j)) return;
+    if (w->n_pairs < w->max_pairs) {
+        w->pa[w->n_pairs] = i < j ? i : j;
+        w->pb[w->n_pairs] = i < j ? j : i;
+    } else {
+        w->overflow = 1;
+    }
+    w->n_pairs++;
+}
+
+static void grid_pairs(sfo_world* w) {
+    uint32_t n = w->n, GX = 1u << w->gxl, GY = 1u << w->gyl, ncell = GX * GY;
+    uint32_t* start = (uint32_t*)calloc((size_t)ncell + 1, sizeof(uint32_t));
+    uint32_t* bucket = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    int32_t* ccx = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+    int32_t* ccy = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+    uint32_t* slot_id = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    uint32_t* large = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    uint32_t ns = 0, nl = 0;
+    float lim = 0.9f * w->cell;
+    for (uint32_t i = 0; i < n; ++i) {
+        bucket[i] = 0xFFFFFFFFu;
+        if (w->col[i].type == SFX_SHAPE_NONE) continue;
+        const float* A = &w->aabb[4 * i];
+        if ((A[2] - A[0]) <= lim && (A[3] - A[1]) <= lim) {
+            ccx[i] = cell_coord(A[0], w->inv_cell);
+            ccy[i] = cell_coord(A[1], w->inv_cell);
+            bucket[i] = (((uint32_t)ccy[i] & (GY - 1)) << w->gxl) | ((uint32_t)ccx[i] & (GX - 1));
+            start[bucket[i] + 1]++;
+            ++ns;
+        } else {
+            large[nl++] = i;
+        }
+    }
+    for (uint32_t c = 0; c < ncell; ++c) start[c + 1] += start[c];
+    uint32_t* fill = (uint32_t*)malloc((size_t)ncell * sizeof(uint32_t));
+    memcpy(fill, start, (size_t)ncell * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; ++i)
+        if (bucket[i] != 0xFFFFFFFFu) slot_id[fill[bucket[i]]++] = i;
+    w->n_small = ns; w->n_large = nl;
+    w->n_pairs = 0; w->overflow = 0;
+    static const int off[5][2] = {{0, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
+    for (uint32_t p = 0; p < ns; ++p) {
+        uint32_t i = slot_id[p];
+        for (int o = 0; o < 5; ++o) {
+            int32_t nx = ccx[i] + off[o][0], ny = ccy[i] + off[o][1];
+            uint32_t nb = (((uint32_t)ny & (GY - 1)) << w->gxl) | ((uint32_t)nx & (GX - 1));
+            for (uint32_t q = start[nb]; q < start[nb + 1]; ++q) {
+                uint32_t j = slot_id[q];
+                if (ccx[j] != nx || ccy[j] != ny) continue;
+                if (o == 0 && q <= p) continue;
+                emit_pair(w, i, j);
+            }
+        }
+        for (uint32_t l = 0; l < nl; ++l) emit_pair(w, i, large[l]);
+    }
+    for (uint32_t l = 0; l < nl; ++l)
+        for (uint32_t l2 = l + 1; l2 < nl; ++l2) emit_pair(w, large[l], large[l2]);
+    free(start); free(bucket); free(ccx); free(ccy); free(slot_id); free(large); free(fill);
+}
+
+int sfo_broadphase(sfo_world* w, float frame_dt) {
+    if (!w->col) return SFX_ERR_INVALID;
+    for (uint32_t i = 0; i < w->n; ++i) compute_aabb(w, i, frame_dt, &w->aabb[4 * i]);
+    grid_pairs(w);
+    uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
+    uint8_t* dyn = (uint8_t*)malloc(w->n ? w->n : 1);
+    for (uint32_t i = 0; i < w->n; ++i) dyn[i] = (uint8_t)is_dynamic(w, i);
+    uint32_t ovf = 0;
+    w->n_colors = color_edges(w->n, np, w->pa, w->pb, dyn, w->cfg.color_rounds, w->color, &w->n_leftover, &ovf);
+    if (ovf) w->overflow = 1;
+    memset(w->color_count, 0, sizeof(w->color_count));
+    for (uint32_t e = 0; e < np; ++e) w->color_count[w->color[e]]++;
+    free(dyn);
+    return w->overflow ? SFX_ERR_CAPACITY : SFX_OK;
+}
+
+int sfo_aabbs(const sfo_world* w, float* out) {
+    memcpy(out, w->aabb, 4u * w->n * sizeof(float));
+    return SFX_OK;
+}
+
+size_t sfo_pairs_grid(const sfo_world* w, uint64_t* keys, size_t cap) {
+    uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
+    size_t k = 0;
+    for (uint32_t e = 0; e < np && k < cap; ++e) keys[k++] = ((uint64_t)w->pa[e] << 32) | w->pb[e];
+    qsort(keys, k, sizeof(uint64_t), cmp_u64);
+    return w->n_pairs;
+}
+
+size_t sfo_pair_colors(const sfo_world* w, uint64_t* keys, uint8_t* colors, size_t cap) {
+    uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
+    for (uint32_t e = 0; e < np && e < cap; ++e) {
+        keys[e] = ((uint64_t)w->pa[e] << 32) | w->pb[e];
+        colors[e] = w->color[e];
+    }
+    return np;
+}
+
+size_t sfo_joint_order(const sfo_world* w, uint32_t* perm, uint8_t* colors, size_t cap) {
+    for (uint32_t k = 0; k < w->m && k < cap; ++k) {
+        perm[k] = w->joint_perm[k];
+        colors[k] = w->joint_color[w->joint_perm[k]];
+    }
+    return w->m;
+}
+
+/* ------------------------------------------------------------------ narrowphase
+ * [DESIGN] DESIGN.md "Contract / narrowphase".  Every shape is a convex core polygon of
+ * 1..8 vertices plus a radius; contacts come from SAT + reference-face clipping on the
+ * cores (closest features when the clip is empty), with the radii subtracted. */
+
+static void build_core(const sfo_world* w, uint32_t i, core_t* c) {
+    const sfx_collider* col = &w->col[i];
+    float px = w->pos[2 * i], py = w->pos[2 * i + 1];
+    float rc = w->rot[2 * i], rs = w->rot[2 * i + 1];
+    c->r = col->p[2];
+    switch (col->type) {
+    case SFX_SHAPE_CIRCLE:
+        c->n = 1; c->vx[0] = px; c->vy[0] = py; c->nx[0] = 0.0f; c->ny[0] = 0.0f;
+        break;
+    case SFX_SHAPE_RECT: {
+        float ax = rc * col->p[0], ay = rs * col->p[0];
+        float bx = -rs * col->p[1], by = rc * col->p[1];
+        c->n = 4;
+        c->vx[0] = (px - ax) - bx; c->vy[0] = (py - ay) - by;
+        c->vx[1] = (px + ax) - bx; c->vy[1] = (py + ay) - by;
+        c->vx[2] = (px + ax) + bx; c->vy[2] = (py + ay) + by;
+        c->vx[3] = (px - ax) + bx; c->vy[3] = (py - ay) + by;
+        c->nx[0] = rs;  c->ny[0] = -rc;
+        c->nx[1] = rc;  c->ny[1] = rs;
+        c->nx[2] = -rs; c->ny[2] = rc;
+        c->nx[3] = -rc; c->ny[3] = -rs;
+        break;
+    }
+    case SFX_SHAPE_CAPSULE: {
+        float ax = rc * col->p[0], ay = rs * col->p[0];
+        c->n = 2;
+        c->vx[0] = px - ax; c->vy[0] = py - ay;
+        c->vx[1] = px + ax; c->vy[1] = py + ay;
+        c->nx[0] = rs;  c->ny[0] = -rc;
+        c->nx[1] = -rs; c->ny[1] = rc;
+        break;
+    }
+    case SFX_SHAPE_POLY:
+        c->n = (int)col->poly_count;
+        for (int k = 0; k < c->n; ++k) {
+            float lx = w->poly[2 * (col->poly_offset + k)], ly = w->poly[2 * (col->poly_offset + k) + 1];
+            float mx = w->poly_nrm[2 * (col->poly_offset + k)], my = w->poly_nrm[2 * (col->poly_offset + k) + 1];
+            c->vx[k] = px + (rc * lx - rs * ly); c->vy[k] = py + (rs * lx + rc * ly);
+            c->nx[k] = rc * mx - rs * my;        c->ny[k] = rs * mx + rc * my;
+        }
+        break;
+    default:
+        c->n = 0;
+    }
+}
+
+typedef struct {
+    int count;
+    float nx, ny;         /* from first core to second core */
+    float p1x[2], p1y[2]; /* surface points on the first shape */
+    float p2x[2], p2y[2]; /* surface points on the second shape */
+    float depth[2];
+} manifold_t;
+
+static void cc_manifold(const core_t* A, const core_t* B, manifold_t* m) {
+    float dx = B->vx[0] - A->vx[0], dy = B->vy[0] - A->vy[0];
+    float d2 = dx * dx + dy * dy;
+    float rsum = A->r + B->r;
+    m->count = 0;
+    if (d2 > rsum * rsum) return;
+    float dist = sqrtf(d2);
+    float nx = 0.0f, ny = 1.0f;
+    if (dist > EPS_LEN) { nx = dx / dist; ny = dy / dist; }
+    float depth = rsum - dist;
+    if (!(depth > 0.0f)) return;
+    m->count = 1; m->nx = nx; m->ny = ny; m->depth[0] = depth;
+    m->p1x[0] = A->vx[0] + nx * A->r; m->p1y[0] = A->vy[0] + ny * A->r;
+    m->p2x[0] = B->vx[0] - nx * B->r; m->p2y[0] = B->vy[0] - ny * B->r;
+}
+
+/* closest point on polygon boundary P (n >= 2) to point (cx, cy); first minimum wins */
+static void closest_on_poly(const core_t* P, float cx, float cy, float* qx, float* qy, float* d2out) {
+    float best = INFINITY, bx = 0.0f, by = 0.0f;
+    for (int k = 0; k < P->n; ++k) {
+        int k1 = (k + 1 == P->n) ? 0 : k + 1;
+        float ex = P->vx[k1] - P->vx[k], ey = P->vy[k1] - P->vy[k];
+        float wx = cx - P->vx[k], wy = cy - P->vy[k];
+        float ee = ex * ex + ey * ey;
+        float t = 0.0f;
+        if (ee > 0.0f) t = (wx * ex + wy * ey) / ee;
+        t = fminf(fmaxf(t, 0.0f), 1.0f);
+        float x = P->vx[k] + t * ex, y = P->vy[k] + t * ey;
+        float ddx = cx - x, ddy = cy - y;
+        float d2 = ddx * ddx + ddy * ddy;
+        if (d2 < best) { best = d2; bx = x; by = y; }
+    }
+    *qx = bx; *qy = by; *d2out = best;
+}
+
+/* polygon P (n >= 2) against circle C: normal points from P to C */
+static void pc_manifold(const core_t* P, const core_t* C, manifold_t* m) {
+    float cx = C->vx[0], cy = C->vy[0];
+    float rsum = P->r + C->r;
+    float sep = -INFINITY; int ks = 0;
+    m->count = 0;
+    for (int k = 0; k < P->n; ++k) {
+        float s = P->nx[k] * (cx - P->vx[k]) + P->ny[k] * (cy - P->vy[k]);
+        if (s > sep) { sep = s; ks = k; }
+    }
+    if (sep > rsum) return;
+    float nx, ny, qx, qy, depth;
+    if (P->n == 2 || sep > 0.0f) {
+        float d2;
+        closest_on_poly(P, cx, cy, &qx, &qy, &d2);
+        if (d2 > rsum * rsum) return;
+        float dist = sqrtf(d2);
+        if (dist > EPS_LEN) { nx = (cx - qx) / dist; ny = (cy - qy) / dist; }
+        else { nx = P->nx[ks]; ny = P->ny[ks]; }
+        depth = rsum - dist;
+    } else {
+        nx = P->nx[ks]; ny = P->ny[ks];
+        qx = cx - nx * sep; qy = cy - ny * sep;
+        depth = rsum - sep;
+    }
+    if (!(depth > 0.0f)) return;
+    m->count = 1; m->nx = nx; m->ny = ny; m->depth[0] = depth;
+    m->p1x[0] = qx + nx * P->r; m->p1y[0] = qy + ny * P->r;
+    m->p2x[0] = cx - nx * C->r; m->p2y[0] = cy - ny * C->r;
+}
+
+static float sat_sep(const core_t* P, const core_t* Q, int* kbest) {
+    float best = -INFINITY; int bk = 0;
+    for (int k = 0; k < P->n; ++k) {
+        float s = INFINITY;
+        for (int j = 0; j < Q->n; ++j) {
+            float d = P->nx[k] * (Q->vx[j] - P->vx[k]) + P->ny[k] * (Q->vy[j] - P->vy[k]);
+            if (d < s) s = d;
+        }
+        if (s > best) { best = s; bk = k; }
+    }
+    *kbest = bk;
+    return best;
+}
+
+/* polygon (n >= 2) against polygon (n >= 2); normal from A to B */
+static void pp_manifold(const core_t* A, const core_t* B, manifold_t* m) {
+    int ka, kb;
+    float rsum = A->r + B->r;
+    m->count = 0;
+    float sa = sat_sep(A, B, &ka);
+    if (sa > rsum) return;
+    float sb = sat_sep(B, A, &kb);
+    if (sb > rsum) return;
+    int flip = sb > sa;
+    const core_t* R = flip ? B : A; /* reference */
+    const core_t* I = flip ? A : B; /* incident  */
+    int kr = flip ? kb : ka;
+    int kr1 = (kr + 1 == R->n) ? 0 : kr + 1;
+    float nrx = R->nx[kr], nry = R->ny[kr];
+    float r1x = R->vx[kr], r1y = R->vy[kr], r2x = R->vx[kr1], r2y = R->vy[kr1];
+    /* incident edge: most anti-parallel normal, first minimum */
+    float bestd = INFINITY; int ki = 0;
+    for (int j = 0; j < I->n; ++j) {
+        float d = I->nx[j] * nrx + I->ny[j] * nry;
+        if (d < bestd) { bestd = d; ki = j; }
+    }
+    int ki1 = (ki + 1 == I->n) ? 0 : ki + 1;
+    float i1x = I->vx[ki], i1y = I->vy[ki], i2x = I->vx[ki1], i2y = I->vy[ki1];
+    float tx = -nry, ty = nrx;
+    float L = (r2x - r1x) * tx + (r2y - r1y) * ty;
+    float u1 = (i1x - r1x) * tx + (i1y - r1y) * ty;
+    float u2 = (i2x - r1x) * tx + (i2y - r1y) * ty;
+    float du = u2 - u1;
+    float ta = 0.0f, tb = 1.0f;
+    int empty = 0;
+    if (du > 0.0f) {
+        ta = fmaxf(ta, (0.0f - u1) / du);
+        tb = fminf(tb, (L - u1) / du);
+    } else if (du < 0.0f) {
+        tb = fminf(tb, (0.0f - u1) / du);
+        ta = fmaxf(ta, (L - u1) / du);
+    } else if (u1 < 0.0f || u1 > L) {
+        empty = 1;
+    }
+    if (ta > tb) empty = 1;
+    float rr = R->r, ri = I->r;
+    float nx, ny;           /* from reference to incident */
+    float prx[2], pry[2], pix[2], piy[2], dep[2];
+    int cnt = 0;
+    if (!empty) {
+        float ex = i2x - i1x, ey = i2y - i1y;
+        float tt[2]; tt[0] = ta; tt[1] = tb;
+        int np = (tb > ta) ? 2 : 1;
+        nx = nrx; ny = nry;
+        for (int k = 0; k < np; ++k) {
+            float cx = i1x + tt[k] * ex, cy = i1y + tt[k] * ey;
+            float s = (cx - r1x) * nrx + (cy - r1y) * nry;
+            float d = rsum - s;
+            if (!(d > 0.0f)) continue;
+            /* foot on the reference edge pushed out by its radius / incident point pulled in */
+            prx[cnt] = (cx - nrx * s) + nrx * rr; pry[cnt] = (cy - nry * s) + nry * rr;
+            pix[cnt] = cx - nrx * ri;             piy[cnt] = cy - nry * ri;
+            dep[cnt] = d;
+            ++cnt;
+        }
+    } else {
+        /* incident edge lies past one end of the reference edge: vertex against polygon */
+        float vx = (u1 + u2 < 0.0f) ? r1x : r2x, vy = (u1 + u2 < 0.0f) ? r1y : r2y;
+        float qx, qy, d2;
+        closest_on_poly(I, vx, vy, &qx, &qy, &d2);
+        if (d2 > rsum * rsum) return;
+        float dist = sqrtf(d2);
+        if (dist > EPS_LEN) { nx = (qx - vx) / dist; ny = (qy - vy) / dist; }
+        else { nx = nrx; ny = nry; }
+        float d = rsum - dist;
+        if (d > 0.0f) {
+            prx[0] = vx + nx * rr; pry[0] = vy + ny * rr;
+            pix[0] = qx - nx * ri; piy[0] = qy - ny * ri;
+            dep[0] = d;
+            cnt = 1;
+        }
+    }
+    if (cnt == 0) return;
+    m->count = cnt;
+    for (int k = 0; k < cnt; ++k) {
+        m->depth[k] = dep[k];
+        if (!flip) { m->p1x[k] = prx[k]; m->p1y[k] = pry[k]; m->p2x[k] = pix[k]; m->p2y[k] = piy[k]; }
+        else       { m->p1x[k] = pix[k]; m->p1y[k] = piy[k]; m->p2x[k] = prx[k]; m->p2y[k] = pry[k]; }
+    }
+    if (!flip) { m->nx = nx; m->ny = ny; } else { m->nx = -nx; m->ny = -ny; }
+}
+
+/* manifold of bodies a, b (normal from a to b) */
+static void manifold(const sfo_world* w, uint32_t a, uint32_t b, manifold_t* m) {
+    core_t A, B;
+    build_core(w, a, &A);
+    build_core(w, b, &B);
+    m->count = 0;
+    if (A.n == 0 || B.n == 0) return;
+    if (A.n == 1 && B.n == 1) { cc_manifold(&A, &B, m); return; }
+    if (B.n == 1) { pc_manifold(&A, &B, m); return; }
+    if (A.n == 1) {
+        manifold_t t;
+        pc_manifold(&B, &A, &t);
+        m->count = t.count;
+        if (t.count) {
+            m->nx = -t.nx; m->ny = -t.ny; m->depth[0] = t.depth[0];
+            m->p1x[0] = t.p2x[0]; m->p1y[0] = t.p2y[0];
+            m->p2x[0] = t.p1x[0]; m->p2y[0] = t.p1y[0];
+        }
+        return;
+    }
+    pp_manifold(&A, &B, m);
+}
+
+static void fill_contact(uint32_t a, uint32_t b, const manifold_t* m, sfx_contact* c) {
+    memset(c, 0, sizeof(*c));
+    c->body_a = a; c->body_b = b; c->count = (uint32_t)m->count;
+    if (!m->count) return;
+    c->normal[0] = m->nx; c->normal[1] = m->ny;
+    for (int k = 0; k < m->count; ++k) {
+        c->depth[k] = m->depth[k];
+        c->point_a[k][0] = m->p1x[k]; c->point_a[k][1] = m->p1y[k];
+        c->point_b[k][0] = m->p2x[k]; c->point_b[k][1] = m->p2y[k];
+    }
+}
+
+int sfo_contact_pair(const sfo_world* w, uint32_t a, uint32_t b, sfx_contact* out) {
+    manifold_t m;
+    if (a >= w->n || b >= w->n) return SFX_ERR_INVALID;
+    manifold(w, a, b, &m);
+    fill_contact(a, b, &m, out);
+    return SFX_OK;
+}
+
+size_t sfo_contacts(const sfo_world* w, sfx_contact* out, size_t cap) {
+    uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
+    uint64_t* keys = (uint64_t*)malloc((np ? np : 1) * sizeof(uint64_t));
+    for (uint32_t e = 0; e < np; ++e) keys[e] = ((uint64_t)w->pa[e] << 32) | w->pb[e];
+    qsort(keys, np, sizeof(uint64_t), cmp_u64);
+    for (uint32_t e = 0; e < np && e < cap; ++e) {
+        manifold_t m;
+        uint32_t a = (uint32_t)(keys[e] >> 32), b = (uint32_t)keys[e];
+        manifold(w, a, b, &m);
+        fill_contact(a, b, &m, &out[e]);
+    }
+    free(keys);
+    return np;
+}
+
+/* ------------------------------------------------------------------ solver */
+
+static void rotate_by(float* c, float* s, float dth) {
+    float nc = *c - dth * *s;
+    float ns = *s + dth * *c;
+    float inv = 1.0f / sqrtf(nc * nc + ns * ns);
+    *c = nc * inv; *s = ns * inv;
+}
+
+/* [XPBD-RB] Alg. 2 lines 3-9 */
+static void integrate(sfo_world* w, float h) {
+    float gx = w->cfg.gravity[0], gy = w->cfg.gravity[1];
+    for (uint32_t i = 0; i < w->n; ++i) {
+        w->prev_pos[2 * i] = w->pos[2 * i]; w->prev_pos[2 * i + 1] = w->pos[2 * i + 1];
+        w->prev_rot[2 * i] = w->rot[2 * i]; w->prev_rot[2 * i + 1] = w->rot[2 * i + 1];
+        if (w->inv_mass[i] > 0.0f) {
+            w->vel[2 * i] = w->vel[2 * i] + gx * h;
+            w->vel[2 * i + 1] = w->vel[2 * i + 1] + gy * h;
+        }
+        w->pos[2 * i] = w->pos[2 * i] + w->vel[2 * i] * h;
+        w->pos[2 * i + 1] = w->pos[2 * i + 1] + w->vel[2 * i + 1] * h;
+        rotate_by(&w->rot[2 * i], &w->rot[2 * i + 1], w->angvel[i] * h);
+    }
+}
+
+/* [XPBD-RB] Alg. 2 lines 12-16; omega is the exact inverse of rotate_by: tan(dtheta)/h */
+static void derive_velocities(sfo_world* w, float inv_h) {
+    for (uint32_t i = 0; i < w->n; ++i) {
+        if (!is_dynamic(w, i)) continue;
+        w->vel[2 * i] = (w->pos[2 * i] - w->prev_pos[2 * i]) * inv_h;
+        w->vel[2 * i + 1] = (w->pos[2 * i + 1] - w->prev_pos[2 * i + 1]) * inv_h;
+        float c = w->rot[2 * i], s = w->rot[2 * i + 1];
+        float pc = w->prev_rot[2 * i], ps = w->prev_rot[2 * i + 1];
+        float dc = c * pc + s * ps;
+        float ds = s * pc - c * ps;
+        if (dc > 1e-6f) w->angvel[i] = (ds / dc) * inv_h;
+    }
+}
+
+/* apply a positional impulse p (world) at world offset r from the centre of body i, scaled by sign */
+static void apply_pos(sfo_world* w, uint32_t i, float rx, float ry, float px, float py, float sign) {
+    float im = w->inv_mass[i], ii = w->inv_inertia[i];
+    if (im > 0.0f) {
+        w->pos[2 * i] = w->pos[2 * i] + sign * (px * im);
+        w->pos[2 * i + 1] = w->pos[2 * i + 1] + sign * (py * im);
+    }
+    if (ii > 0.0f) {
+        float dth = sign * (ii * (rx * py - ry * px));
+        rotate_by(&w->rot[2 * i], &w->rot[2 * i + 1], dth);
+    }
+}
+
+static float gen_inv_mass(const sfo_world* w, uint32_t i, float rx, float ry, float nx, float ny) {
+    float rn = rx * ny - ry * nx;
+    return w->inv_mass[i] + w->inv_inertia[i] * (rn * rn);
+}
+
+/* world-space anchor of a body-local point */
+static void anchor_world(const sfo_world* w, uint32_t i, const float* loc, float* rx, float* ry) {
+    float c = w->rot[2 * i], s = w->rot[2 * i + 1];
+    *rx = c * loc[0] - s * loc[1];
+    *ry = s * loc[0] + c * loc[1];
+}
+
+/* [DESIGN] DESIGN.md "Contract / manifold block solve": the two normal constraints of a
+ * manifold are solved together as a 2x2 LCP (lambda >= 0, no residual penetration), which
+ * removes the point-order bias of a sequential solve that makes box stacks creep.
+ * K is the effective inverse mass matrix along the shared normal, d the penetrations. */
+static void solve_lcp2(float K00, float K01, float K11, float d0, float d1, float* l0, float* l1) {
+    float det = K00 * K11 - K01 * K01;
+    if (det > 1e-6f * (K00 * K11)) {
+        float inv = 1.0f / det;
+        float a = (K11 * d0 - K01 * d1) * inv;
+        float b = (K00 * d1 - K01 * d0) * inv;
+        if (a >= 0.0f && b >= 0.0f) { *l0 = a; *l1 = b; return; }
+    }
+    float a = d0 / K00;
+    if (a >= 0.0f && d1 - K01 * a <= 0.0f) { *l0 = a; *l1 = 0.0f; return; }
+    float b = d1 / K11;
+    if (b >= 0.0f && d0 - K01 * b <= 0.0f) { *l0 = 0.0f; *l1 = b; return; }
+    if (d0 >= d1) { *l0 = fmaxf(d0, 0.0f) / K00; *l1 = 0.0f; }
+    else { *l0 = 0.0f; *l1 = fmaxf(d1, 0.0f) / K11; }
+}
+
+/* [XPBD-RB] sec. 3.5: contact handled with the manifold recomputed from the current poses;
+ * normal constraints of the manifold solved as a block.  Friction is not applied here but
+ * in the velocity pass (see solve_vel_pair) so that it sees the net motion of the substep. */
+static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec) {
+    manifold_t m;
+    manifold(w, a, b, &m);
+    rec->count = (uint32_t)m.count;
+    if (!m.count) return;
+    const sfx_material* ma = &w->mats[w->col[a].material];
+    const sfx_material* mb = &w->mats[w->col[b].material];
+    rec->mu_s = 0.5f * (ma->static_friction + mb->static_friction);
+    rec->mu_d = 0.5f * (ma->dynamic_friction + mb->dynamic_friction);
+    rec->rest = fmaxf(ma->restitution, mb->restitution);
+    rec->nx = m.nx; rec->ny = m.ny;
+    float nx = m.nx, ny = m.ny;
+    float ima = w->inv_mass[a], iia = w->inv_inertia[a], imb = w->inv_mass[b], iib = w->inv_inertia[b];
+    float rax[2], ray[2], rbx[2], rby[2], d[2], cna[2] = {0.0f, 0.0f}, cnb[2] = {0.0f, 0.0f};
+    /* body-local anchors from the poses the manifold was built on */
+    for (int k = 0; k < m.count; ++k) {
+        float ax = m.p1x[k] - w->pos[2 * a], ay = m.p1y[k] - w->pos[2 * a + 1];
+        float bx = m.p2x[k] - w->pos[2 * b], by = m.p2y[k] - w->pos[2 * b + 1];
+        float ca = w->rot[2 * a], sa = w->rot[2 * a + 1], cb = w->rot[2 * b], sb = w->rot[2 * b + 1];
+        rec->ra[k][0] = ca * ax + sa * ay; rec->ra[k][1] = ca * ay - sa * ax;
+        rec->rb[k][0] = cb * bx + sb * by; rec->rb[k][1] = cb * by - sb * bx;
+    }
+    for (int k = 0; k < m.count; ++k) {
+        anchor_world(w, a, rec->ra[k], &rax[k], &ray[k]);
+        anchor_world(w, b, rec->rb[k], &rbx[k], &rby[k]);
+        /* pre-solve normal velocity of b relative to a (velocities are still the integrated ones) */
+        float vax = w->vel[2 * a] - w->angvel[a] * ray[k], vay = w->vel[2 * a + 1] + w->angvel[a] * rax[k];
+        float vbx = w->vel[2 * b] - w->angvel[b] * rby[k], vby = w->vel[2 * b + 1] + w->angvel[b] * rbx[k];
+        rec->vn_pre[k] = (vbx - vax) * nx + (vby - vay) * ny;
+        d[k] = ((w->pos[2 * a] + rax[k]) - (w->pos[2 * b] + rbx[k])) * nx +
+               ((w->pos[2 * a + 1] + ray[k]) - (w->pos[2 * b + 1] + rby[k])) * ny;
+        cna[k] = rax[k] * ny - ray[k] * nx;
+        cnb[k] = rbx[k] * ny - rby[k] * nx;
+    }
+    float l0 = 0.0f, l1 = 0.0f;
+    float ims = ima + imb;
+    float K00 = (ims + iia * (cna[0] * cna[0])) + iib * (cnb[0] * cnb[0]);
+    rec->lam[0] = 0.0f; rec->lam[1] = 0.0f;
+    if (!(K00 > 0.0f)) return;
+    if (m.count == 2) {
+        float K11 = (ims + iia * (cna[1] * cna[1])) + iib * (cnb[1] * cnb[1]);
+        float K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
+        solve_lcp2(K00, K01, K11, d[0], d[1], &l0, &l1);
+    } else {
+        l0 = fmaxf(d[0], 0.0f) / K00;
+    }
+    rec->lam[0] = l0; rec->lam[1] = l1;
+    float lt = l0 + l1;
+    if (!(lt > 0.0f)) return;
+    /* apply both normal impulses at once: a moves against n, b along n */
+    if (ima > 0.0f) {
+        w->pos[2 * a] = w->pos[2 * a] - (nx * lt) * ima;
+        w->pos[2 * a + 1] = w->pos[2 * a + 1] - (ny * lt) * ima;
+    }
+    if (iia > 0.0f) rotate_by(&w->rot[2 * a], &w->rot[2 * a + 1], -(iia * (cna[0] * l0 + cna[1] * l1)));
+    if (imb > 0.0f) {
+        w->pos[2 * b] = w->pos[2 * b] + (nx * lt) * imb;
+        w->pos[2 * b + 1] = w->pos[2 * b + 1] + (ny * lt) * imb;
+    }
+    if (iib > 0.0f) rotate_by(&w->rot[2 * b], &w->rot[2 * b + 1], iib * (cnb[0] * l0 + cnb[1] * l1));
+}
+
+static float rel_vel_n(const sfo_world* w, uint32_t a, uint32_t b, float rax, float ray, float rbx,
+                       float rby, float nx, float ny, float* vx, float* vy) {
+    float vax = w->vel[2 * a] - w->angvel[a] * ray, vay = w->vel[2 * a + 1] + w->angvel[a] * rax;
+    float vbx = w->vel[2 * b] - w->angvel[b] * rby, vby = w->vel[2 * b + 1] + w->angvel[b] * rbx;
+    *vx = vbx - vax; *vy = vby - vay;
+    return *vx * nx + *vy * ny;
+}
+
+/* y = K^-1 r restricted to the active normal constraints of a manifold */
+static void kinv_apply(const float* K, float K01, const int* act, int count, float r0, float r1,
+                       float* y0, float* y1) {
+    *y0 = 0.0f; *y1 = 0.0f;
+    if (count == 2 && act[0] && act[1]) {
+        float det = K[0] * K[1] - K01 * K01;
+        if (det > 1e-6f * (K[0] * K[1])) {
+            float inv = 1.0f / det;
+            *y0 = (K[1] * r0 - K01 * r1) * inv;
+            *y1 = (K[0] * r1 - K01 * r0) * inv;
+        } else {
+            *y0 = 0.5f * (r0 / K[0]); *y1 = 0.5f * (r1 / K[1]);
+        }
+    } else if (act[0]) {
+        *y0 = r0 / K[0];
+    } else if (count == 2 && act[1]) {
+        *y1 = r1 / K[1];
+    }
+}
+
+/* [XPBD-RB] sec. 3.6, as a per-manifold block ([DESIGN] DESIGN.md "Contract / velocity pass"):
+ *  1. restitution (eq. 34): the normal velocities of the active points are replaced by
+ *     max(-e vn_pre, 0), both points solved together;
+ *  2. friction once per manifold at the mean anchor, with compensating normal impulses so
+ *     that step 1 stays satisfied: static (eq. 27-28, applied to velocity AND pose, i.e. the
+ *     tangential displacement of this substep is undone) when the stopping impulse fits the
+ *     static cone, else dynamic (eq. 30). */
+static void solve_vel_pair(sfo_world* w, uint32_t a, uint32_t b, const pair_rec* rec, float h, float inv_h) {
+    float nx = rec->nx, ny = rec->ny;
+    int count = (int)rec->count;
+    float l0 = rec->lam[0], l1 = count == 2 ? rec->lam[1] : 0.0f;
+    float lt = l0 + l1;
+    if (!(lt > 0.0f)) return;
+    float gl = sqrtf(w->cfg.gravity[0] * w->cfg.gravity[0] + w->cfg.gravity[1] * w->cfg.gravity[1]);
+    float vthr = w->cfg.restitution_threshold * gl * h;
+    float ima = w->inv_mass[a], iia = w->inv_inertia[a], imb = w->inv_mass[b], iib = w->inv_inertia[b];
+    float ims = ima + imb;
+    float rax[2], ray[2], rbx[2], rby[2], dv[2], cna[2], cnb[2], K[2];
+    int act[2];
+    act[1] = 0; dv[1] = 0.0f; cna[1] = 0.0f; cnb[1] = 0.0f; K[1] = 1.0f;
+    for (int k = 0; k < count; ++k) {
+        anchor_world(w, a, rec->ra[k], &rax[k], &ray[k]);
+        anchor_world(w, b, rec->rb[k], &rbx[k], &rby[k]);
+        float vx, vy;
+        float vn = rel_vel_n(w, a, b, rax[k], ray[k], rbx[k], rby[k], nx, ny, &vx, &vy);
+        float e = fabsf(rec->vn_pre[k]) <= vthr ? 0.0f : rec->rest;
+        dv[k] = fmaxf(-e * rec->vn_pre[k], 0.0f) - vn;
+        cna[k] = rax[k] * ny - ray[k] * nx;
+        cnb[k] = rbx[k] * ny - rby[k] * nx;
+        K[k] = (ims + iia * (cna[k] * cna[k])) + iib * (cnb[k] * cnb[k]);
+        act[k] = rec->lam[k] > 0.0f && K[k] > 0.0f;
+    }
+    float K01 = 0.0f;
+    if (count == 2) K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
+    float p0, p1;
+    kinv_apply(K, K01, act, count, dv[0], dv[1], &p0, &p1);
+    {
+        float pt = p0 + p1;
+        float cra = cna[0] * p0 + cna[1] * p1, crb = cnb[0] * p0 + cnb[1] * p1;
+        w->vel[2 * a] = w->vel[2 * a] - (nx * pt) * ima;
+        w->vel[2 * a + 1] = w->vel[2 * a + 1] - (ny * pt) * ima;
+        w->angvel[a] = w->angvel[a] - iia * cra;
+        w->vel[2 * b] = w->vel[2 * b] + (nx * pt) * imb;
+        w->vel[2 * b + 1] = w->vel[2 * b + 1] + (ny * pt) * imb;
+        w->angvel[b] = w->angvel[b] + iib * crb;
+    }
+    if (w->cfg.flags & SFX_CFG_NO_FRICTION) return;
+    float max_, may_, mbx_, mby_;
+    if (count == 2) {
+        max_ = 0.5f * (rax[0] + rax[1]); may_ = 0.5f * (ray[0] + ray[1]);
+        mbx_ = 0.5f * (rbx[0] + rbx[1]); mby_ = 0.5f * (rby[0] + rby[1]);
+    } else { max_ = rax[0]; may_ = ray[0]; mbx_ = rbx[0]; mby_ = rby[0]; }
+    float vx, vy;
+    float vn = rel_vel_n(w, a, b, max_, may_, mbx_, mby_, nx, ny, &vx, &vy);
+    float vtx = vx - nx * vn, vty = vy - ny * vn;
+    float vt = sqrtf(vtx * vtx + vty * vty);
+    if (!(vt > EPS_LEN)) return;
+    float tx = vtx / vt, ty = vty / vt;
+    float cta = max_ * ty - may_ * tx, ctb = mbx_ * ty - mby_ * tx;
+    float Att = (ims + iia * (cta * cta)) + iib * (ctb * ctb);
+    float At0 = iia * (cta * cna[0]) + iib * (ctb * cnb[0]);
+    float At1 = iia * (cta * cna[1]) + iib * (ctb * cnb[1]);
+    float y0, y1;
+    kinv_apply(K, K01, act, count, At0, At1, &y0, &y1);
+    float S = Att - (At0 * y0 + At1 * y1);
+    if (!(S > 0.0f)) return;
+    float need = vt / S;
+    int is_static = need * h < rec->mu_s * lt;
+    float pt = is_static ? -need : -fminf(rec->mu_d * lt * inv_h, need);
+    float q0 = -(y0 * pt), q1 = -(y1 * pt);
+    /* total impulse on b (a gets the opposite): pt t + (q0 + q1) n, with torques */
+    float jx = tx * pt + nx * (q0 + q1), jy = ty * pt + ny * (q0 + q1);
+    float ja = (cta * pt + cna[0] * q0) + cna[1] * q1;
+    float jb = (ctb * pt + cnb[0] * q0) + cnb[1] * q1;
+    w->vel[2 * a] = w->vel[2 * a] - jx * ima;
+    w->vel[2 * a + 1] = w->vel[2 * a + 1] - jy * ima;
+    w->angvel[a] = w->angvel[a] - iia * ja;
+    w->vel[2 * b] = w->vel[2 * b] + jx * imb;
+    w->vel[2 * b + 1] = w->vel[2 * b + 1] + jy * imb;
+    w->angvel[b] = w->angvel[b] + iib * jb;
+    if (is_static) {
+        if (ima > 0.0f) {
+            w->pos[2 * a] = w->pos[2 * a] - (jx * h) * ima;
+            w->pos[2 * a + 1] = w->pos[2 * a + 1] - (jy * h) * ima;
+        }
+        if (iia > 0.0f) rotate_by(&w->rot[2 * a], &w->rot[2 * a + 1], -(iia * (ja * h)));
+        if (imb > 0.0f) {
+            w->pos[2 * b] = w->pos[2 * b] + (jx * h) * imb;
+            w->pos[2 * b + 1] = w->pos[2 * b + 1] + (jy * h) * imb;
+        }
+        if (iib > 0.0f) rotate_by(&w->rot[2 * b], &w->rot[2 * b + 1], iib * (jb * h));
+    }
+}
+
+/* [XPBD-RB] sec. 3.3 / [XPBD] eq. 18: distance constraint with compliance, lambda restarts
+ * at 0 every substep (one iteration per substep) */
+static void solve_joint(sfo_world* w, const sfx_distance_constraint* j, float inv_h2) {
+    uint32_t a = j->body_a, b = j->body_b;
+    float rax = 0, ray = 0, rbx = 0, rby = 0, pax, pay, pbx, pby;
+    if (a != SFX_WORLD_BODY) {
+        float c = w->rot[2 * a], s = w->rot[2 * a + 1];
+        rax = c * j->anchor_a[0] - s * j->anchor_a[1]; ray = s * j->anchor_a[0] + c * j->anchor_a[1];
+        pax = w->pos[2 * a] + rax; pay = w->pos[2 * a + 1] + ray;
+    } else { pax = j->anchor_a[0]; pay = j->anchor_a[1]; }
+    if (b != SFX_WORLD_BODY) {
+        float c = w->rot[2 * b], s = w->rot[2 * b + 1];
+        rbx = c * j->anchor_b[0] - s * j->anchor_b[1]; rby = s * j->anchor_b[0] + c * j->anchor_b[1];
+        pbx = w->pos[2 * b] + rbx; pby = w->pos[2 * b + 1] + rby;
+    } else { pbx = j->anchor_b[0]; pby = j->anchor_b[1]; }
+    float dx = pbx - pax, dy = pby - pay;
+    float len = sqrtf(dx * dx + dy * dy);
+    if (!(len > EPS_LEN)) return;
+    float nx = dx / len, ny = dy / len;
+    float C = len - j->rest_length;
+    float wsum = j->compliance * inv_h2;
+    if (a != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(w, a, rax, ray, nx, ny);
+    if (b != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(w, b, rbx, rby, nx, ny);
+    if (!(wsum > 0.0f)) return;
+    float corr = C / wsum;
+    if (a != SFX_WORLD_BODY) apply_pos(w, a, rax, ray, nx * corr, ny * corr, 1.0f);
+    if (b != SFX_WORLD_BODY) apply_pos(w, b, rbx, rby, nx * corr, ny * corr, -1.0f);
+}
+
+typedef struct { uint64_t key; uint32_t idx; } key_idx;
+static int cmp_key_idx(const void* a, const void* b) {
+    const key_idx *x = (const key_idx*)a, *y = (const key_idx*)b;
+    return x->key < y->key ? -1 : x->key > y->key;
+}
+
+int sfo_step(sfo_world* w, float frame_dt, int order) {
+    if (!w->col || !w->mats) return SFX_ERR_INVALID;
+    int rc = sfo_broadphase(w, frame_dt);
+    if (rc != SFX_OK) return rc;
+    uint32_t np = w->n_pairs;
+    if (order == SFO_ORDER_SEQUENTIAL) {
+        key_idx* ki = (key_idx*)malloc((np ? np : 1) * sizeof(key_idx));
+        for (uint32_t e = 0; e < np; ++e) { ki[e].key = ((uint64_t)w->pa[e] << 32) | w->pb[e]; ki[e].idx = e; }
+        qsort(ki, np, sizeof(key_idx), cmp_key_idx);
+        for (uint32_t e = 0; e < np; ++e) w->order[e] = ki[e].idx;
+        free(ki);
+    } else {
+        uint32_t start[SFX_MAX_COLORS + 1];
+        start[0] = 0;
+        for (uint32_t c = 0; c < SFX_MAX_COLORS; ++c) start[c + 1] = start[c] + w->color_count[c];
+        for (uint32_t e = 0; e < np; ++e) w->order[start[w->color[e]]++] = e;
+    }
+    float h = frame_dt / (float)w->cfg.substeps;
+    float inv_h = 1.0f / h;
+    float inv_h2 = inv_h * inv_h;
+    for (uint32_t s = 0; s < w->cfg.substeps; ++s) {
+        integrate(w, h);
+        for (uint32_t k = 0; k < w->m; ++k) {
+            uint32_t jk = order == SFO_ORDER_SEQUENTIAL ? k : w->joint_perm[k];
+            solve_joint(w, &w->joints[jk], inv_h2);
+        }
+        for (uint32_t k = 0; k < np; ++k) {
+            uint32_t e = w->order[k];
+            solve_pos_pair(w, w->pa[e], w->pb[e], &w->rec[e]);
+        }
+        derive_velocities(w, inv_h);
+        for (uint32_t k = 0; k < np; ++k) {
+            uint32_t e = w->order[k];
+            if (w->rec[e].count) solve_vel_pair(w, w->pa[e], w->pb[e], &w->rec[e], h, inv_h);
+        }
+    }
+    /* stats of the last substep, measured on the records */
+    w->n_contacts = 0; w->max_depth = 0.0f;
+    for (uint32_t e = 0; e < np; ++e) {
+        for (uint32_t k = 0; k < w->rec[e].count; ++k)
+            if (w->rec[e].lam[k] > 0.0f) w->n_contacts++;
+    }
+    return SFX_OK;
+}
+
+int sfo_download_poses(const sfo_world* w, float* pos, float* rot) {
+    if (pos) memcpy(pos, w->pos, 2u * w->n * sizeof(float));
+    if (rot) memcpy(rot, w->rot, 2u * w->n * sizeof(float));
+    return SFX_OK;
+}
+
+int sfo_download_velocities(const sfo_world* w, float* vel, float* angvel) {
+    if (vel) memcpy(vel, w->vel, 2u * w->n * sizeof(float));
+    if (angvel) memcpy(angvel, w->angvel, w->n * sizeof(float));
+    return SFX_OK;
+}
+
+int sfo_stats(const sfo_world* w, sfx_frame_stats* out) {
+    memset(out, 0, sizeof(*out));
+    out->n_bodies = w->n; out->n_small = w->n_small; out->n_large = w->n_large;
+    out->n_pairs = w->n_pairs; out->n_colors = w->n_colors; out->n_leftover = w->n_leftover;
+    out->n_contacts = w->n_contacts; out->n_joint_colors = w->n_joint_colors;
+    out->overflow = w->overflow;
+    memcpy(out->color_count, w->color_count, sizeof(w->color_count));
+    /* deepest penetration at the current poses */
+    float md = 0.0f;
+    uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
+    for (uint32_t e = 0; e < np; ++e) {
+        manifold_t m;
+        manifold(w, w->pa[e], w->pb[e], &m);
+        for (int k = 0; k < m.count; ++k) if (m.depth[k] > md) md = m.depth[k];
+    }
+    out->max_depth = md;
+    double ke = 0.0;
+    for (uint32_t i = 0; i < w->n; ++i) {
+        if (w->inv_mass[i] > 0.0f)
+            ke += 0.5 * (1.0 / w->inv_mass[i]) * ((double)w->vel[2 * i] * w->vel[2 * i] + (double)w->vel[2 * i + 1] * w->vel[2 * i + 1]);
+        if (w->inv_inertia[i] > 0.0f)
+            ke += 0.5 * (1.0 / w->inv_inertia[i]) * (double)w->angvel[i] * w->angvel[i];
+    }
+    out->kinetic_energy = (float)ke;
+    return SFX_OK;
+}

@@ -1,0 +1,226 @@
+"""ctypes view of include/sfx.h: struct layouts, numpy dtypes and the libsfx loader.
+
+The product path has no CPU fallback: `load_libsfx()` raises if the HIP shared library has
+not been built (run `python -c "import __graft_entry__ as g; g.build()"`), and
+`sfx_create` itself fails with SFX_ERR_DEVICE when no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBSFX_PATH = os.path.join(HERE, "csrc", "libsfx.so")
+
+SFX_OK = 0
+SFX_ERR_INVALID = -1
+SFX_ERR_UNSUPPORTED = -2
+SFX_ERR_DEVICE = -3
+SFX_ERR_CAPACITY = -4
+SFX_ERR_NOMEM = -5
+
+SHAPE_NONE, SHAPE_CIRCLE, SHAPE_RECT, SHAPE_CAPSULE, SHAPE_POLY = 0, 1, 2, 3, 4
+MAX_POLY_VERTS = 8
+WORLD_BODY = 0xFFFFFFFF
+MAX_COLORS = 64
+
+CFG_USE_GRAPH = 1
+CFG_NO_FRICTION = 2
+
+
+class SfxConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32),
+        ("device", C.c_int32),
+        ("substeps", C.c_uint32),
+        ("gravity", C.c_float * 2),
+        ("aabb_margin", C.c_float),
+        ("cell_size", C.c_float),
+        ("grid_log2", C.c_uint32 * 2),
+        ("max_pairs", C.c_uint32),
+        ("color_rounds", C.c_uint32),
+        ("launch_colors", C.c_uint32),
+        ("restitution_threshold", C.c_float),
+        ("flags", C.c_uint32),
+    ]
+
+
+class SfxFrameStats(C.Structure):
+    _fields_ = [
+        ("n_bodies", C.c_uint32),
+        ("n_small", C.c_uint32),
+        ("n_large", C.c_uint32),
+        ("n_pairs", C.c_uint32),
+        ("n_colors", C.c_uint32),
+        ("n_leftover", C.c_uint32),
+        ("n_contacts", C.c_uint32),
+        ("n_joint_colors", C.c_uint32),
+        ("overflow", C.c_uint32),
+        ("launches", C.c_uint32),
+        ("max_depth", C.c_float),
+        ("kinetic_energy", C.c_float),
+        ("color_count", C.c_uint32 * MAX_COLORS),
+    ]
+
+
+class SfxKernelTime(C.Structure):
+    _fields_ = [("total_ms", C.c_double), ("launches", C.c_uint64), ("items", C.c_uint64)]
+
+
+K_CLASSES = 16
+
+collider_dtype = np.dtype(
+    [
+        ("type", "<u4"),
+        ("material", "<u4"),
+        ("category", "<u4"),
+        ("mask", "<u4"),
+        ("group", "<u4"),
+        ("p", "<f4", (3,)),
+        ("poly_offset", "<u4"),
+        ("poly_count", "<u4"),
+    ]
+)
+material_dtype = np.dtype([("restitution", "<f4"), ("static_friction", "<f4"), ("dynamic_friction", "<f4")])
+constraint_dtype = np.dtype(
+    [
+        ("body_a", "<u4"),
+        ("body_b", "<u4"),
+        ("anchor_a", "<f4", (2,)),
+        ("anchor_b", "<f4", (2,)),
+        ("rest_length", "<f4"),
+        ("compliance", "<f4"),
+    ]
+)
+contact_dtype = np.dtype(
+    [
+        ("body_a", "<u4"),
+        ("body_b", "<u4"),
+        ("count", "<u4"),
+        ("normal", "<f4", (2,)),
+        ("depth", "<f4", (2,)),
+        ("point_a", "<f4", (2, 2)),
+        ("point_b", "<f4", (2, 2)),
+    ]
+)
+assert collider_dtype.itemsize == 40
+assert material_dtype.itemsize == 12
+assert constraint_dtype.itemsize == 32
+assert contact_dtype.itemsize == 60
+
+
+def make_config(
+    substeps=4,
+    gravity=(0.0, -9.81),
+    aabb_margin=0.01,
+    cell_size=0.0,
+    grid_log2=(0, 0),
+    max_pairs=0,
+    color_rounds=0,
+    launch_colors=0,
+    restitution_threshold=0.0,
+    flags=0,
+    device=0,
+):
+    cfg = SfxConfig()
+    cfg.struct_size = C.sizeof(SfxConfig)
+    cfg.device = device
+    cfg.substeps = substeps
+    cfg.gravity[0], cfg.gravity[1] = gravity
+    cfg.aabb_margin = aabb_margin
+    cfg.cell_size = cell_size
+    cfg.grid_log2[0], cfg.grid_log2[1] = grid_log2
+    cfg.max_pairs = max_pairs
+    cfg.color_rounds = color_rounds
+    cfg.launch_colors = launch_colors
+    cfg.restitution_threshold = restitution_threshold
+    cfg.flags = flags
+    return cfg
+
+
+def fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def vptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+# every symbol include/sfx.h declares; tests check the built library exports all of them
+SFX_SYMBOLS = [
+    "sfx_create", "sfx_destroy", "sfx_abi_version", "sfx_default_config",
+    "sfx_upload_bodies", "sfx_upload_colliders", "sfx_upload_materials", "sfx_upload_constraints",
+    "sfx_step", "sfx_sync", "sfx_download_poses", "sfx_download_velocities",
+    "sfx_debug_aabbs", "sfx_debug_pairs", "sfx_debug_pair_colors", "sfx_debug_broadphase",
+    "sfx_debug_contacts", "sfx_debug_joint_order",
+    "sfx_stats", "sfx_set_profiling", "sfx_kernel_times", "sfx_kernel_class_name",
+    "sfx_timer_begin", "sfx_timer_end", "sfx_last_error",
+]
+
+_lib = None
+
+
+def bind_world_api(lib, prefix):
+    """Declare argument types of the world API shared by libsfx (`sfx_`) and the oracle (`sfo_`)."""
+    P = C.POINTER
+    vp, u32, f32p = C.c_void_p, C.c_uint32, P(C.c_float)
+    g = lambda name: getattr(lib, prefix + name)
+    g("upload_bodies").argtypes = [vp, u32, f32p, f32p, f32p, f32p, f32p, f32p]
+    g("upload_colliders").argtypes = [vp, u32, vp, f32p, u32]
+    g("upload_materials").argtypes = [vp, u32, vp]
+    g("upload_constraints").argtypes = [vp, u32, vp]
+    g("download_poses").argtypes = [vp, f32p, f32p]
+    g("download_velocities").argtypes = [vp, f32p, f32p]
+    g("stats").argtypes = [vp, P(SfxFrameStats)]
+    for n in ("upload_bodies", "upload_colliders", "upload_materials", "upload_constraints",
+              "download_poses", "download_velocities", "stats"):
+        g(n).restype = C.c_int
+
+
+def load_libsfx(path=None):
+    """Load the HIP library.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIBSFX_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"libsfx.so not found at {p}: build it with __graft_entry__.build() "
+            "(hipcc --offload-arch=gfx950); there is no CPU fallback"
+        )
+    lib = C.CDLL(p)
+    P = C.POINTER
+    vp = C.c_void_p
+    lib.sfx_create.argtypes = [P(SfxConfig), P(vp)]
+    lib.sfx_create.restype = C.c_int
+    lib.sfx_destroy.argtypes = [vp]
+    lib.sfx_destroy.restype = None
+    lib.sfx_abi_version.restype = C.c_uint32
+    lib.sfx_default_config.argtypes = [P(SfxConfig)]
+    lib.sfx_default_config.restype = None
+    bind_world_api(lib, "sfx_")
+    lib.sfx_step.argtypes = [vp, C.c_float]
+    lib.sfx_step.restype = C.c_int
+    lib.sfx_sync.argtypes = [vp]
+    lib.sfx_sync.restype = C.c_int
+    lib.sfx_debug_aabbs.argtypes = [vp, P(C.c_float)]
+    lib.sfx_debug_pairs.argtypes = [vp, vp, C.c_size_t, P(C.c_size_t)]
+    lib.sfx_debug_pair_colors.argtypes = [vp, vp, vp, C.c_size_t, P(C.c_size_t)]
+    lib.sfx_debug_broadphase.argtypes = [vp, C.c_float]
+    lib.sfx_debug_contacts.argtypes = [vp, vp, C.c_size_t, P(C.c_size_t)]
+    lib.sfx_debug_joint_order.argtypes = [vp, vp, vp, C.c_size_t, P(C.c_size_t)]
+    lib.sfx_set_profiling.argtypes = [vp, C.c_int]
+    lib.sfx_kernel_times.argtypes = [vp, P(SfxKernelTime), C.c_int]
+    lib.sfx_kernel_class_name.argtypes = [C.c_int]
+    lib.sfx_kernel_class_name.restype = C.c_char_p
+    lib.sfx_timer_begin.argtypes = [vp]
+    lib.sfx_timer_end.argtypes = [vp, P(C.c_double)]
+    lib.sfx_last_error.argtypes = [vp]
+    lib.sfx_last_error.restype = C.c_char_p
+    for n in ("sfx_debug_aabbs", "sfx_debug_pairs", "sfx_debug_pair_colors", "sfx_debug_broadphase",
+              "sfx_debug_contacts", "sfx_debug_joint_order", "sfx_set_profiling", "sfx_kernel_times",
+              "sfx_timer_begin", "sfx_timer_end"):
+        getattr(lib, n).restype = C.c_int
+    if path is None:
+        _lib = lib
+    return lib

@@ -1,0 +1,322 @@
+"""Synthetic scenes for the five BASELINE.json configs plus small
+test scenes.  Pure numpy: a Scene is the set of flat arrays the C ABI takes, so the same
+Scene feeds libsfx and the CPU oracle.
+
+PRNG (SURVEY.md 8d "Common"): splitmix64(seed) -> uniform f32 from the top 24 bits.
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ._abi import (
+    SHAPE_CAPSULE, SHAPE_CIRCLE, SHAPE_NONE, SHAPE_POLY, SHAPE_RECT, WORLD_BODY,
+    collider_dtype, constraint_dtype, material_dtype,
+)
+
+_M64 = (1 << 64) - 1
+
+
+def splitmix64_uniform(seed, count):
+    """count uniform f32 in [0, 1) from the splitmix64 stream started at `seed`."""
+    with np.errstate(over="ignore"):
+        i = np.arange(1, count + 1, dtype=np.uint64)
+        z = np.uint64(seed & _M64) + i * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
+
+
+@dataclass
+class Scene:
+    name: str
+    pos: np.ndarray
+    rot: np.ndarray
+    vel: np.ndarray
+    angvel: np.ndarray
+    inv_mass: np.ndarray
+    inv_inertia: np.ndarray
+    colliders: np.ndarray
+    materials: np.ndarray
+    poly_verts: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))
+    constraints: np.ndarray = field(default_factory=lambda: np.zeros(0, constraint_dtype))
+    substeps: int = 4
+    dt: float = 1.0 / 60.0
+    gravity: tuple = (0.0, -9.81)
+    aabb_margin: float = 0.01
+
+    @property
+    def n(self):
+        return self.pos.shape[0]
+
+    def n_dynamic(self):
+        return int(np.count_nonzero((self.inv_mass > 0) | (self.inv_inertia > 0)))
+
+    def subset(self, idx, name=None):
+        """Scene restricted to bodies idx (constraints are dropped)."""
+        idx = np.asarray(idx)
+        return Scene(
+            name or self.name, self.pos[idx].copy(), self.rot[idx].copy(), self.vel[idx].copy(),
+            self.angvel[idx].copy(), self.inv_mass[idx].copy(), self.inv_inertia[idx].copy(),
+            self.colliders[idx].copy(), self.materials.copy(), self.poly_verts.copy(),
+            np.zeros(0, constraint_dtype), self.substeps, self.dt, self.gravity, self.aabb_margin,
+        )
+
+
+class SceneBuilder:
+    """Accumulates bodies; mass properties follow from shape and density."""
+
+    def __init__(self, name, substeps=4, materials=None):
+        self.name = name
+        self.substeps = substeps
+        self.pos, self.rot, self.vel, self.angvel = [], [], [], []
+        self.inv_mass, self.inv_inertia, self.col = [], [], []
+        self.poly_pool = []
+        self.constraints = []
+        self.materials = materials or [(0.1, 0.5, 0.4)]
+
+    def _add(self, pos, angle, vel, angvel, mass, inertia, col):
+        self.pos.append(pos)
+        self.rot.append((np.cos(angle), np.sin(angle)))
+        self.vel.append(vel)
+        self.angvel.append(angvel)
+        self.inv_mass.append(0.0 if mass <= 0 else 1.0 / mass)
+        self.inv_inertia.append(0.0 if inertia <= 0 else 1.0 / inertia)
+        self.col.append(col)
+        return len(self.pos) - 1
+
+    @staticmethod
+    def _col(type_, p, material=0, category=1, mask=0xFFFFFFFF, group=0, poly_offset=0, poly_count=0):
+        return (type_, material, category, mask, group, tuple(p), poly_offset, poly_count)
+
+    def circle(self, pos, r, density=1.0, angle=0.0, vel=(0, 0), angvel=0.0, **kw):
+        m = density * np.pi * r * r
+        return self._add(pos, angle, vel, angvel, m, 0.5 * m * r * r, self._col(SHAPE_CIRCLE, (0, 0, r), **kw))
+
+    def rect(self, pos, hw, hh, density=1.0, angle=0.0, vel=(0, 0), angvel=0.0, rounding=0.0, **kw):
+        w, h = 2 * (hw + rounding), 2 * (hh + rounding)
+        m = density * w * h
+        return self._add(pos, angle, vel, angvel, m, m * (w * w + h * h) / 12.0,
+                         self._col(SHAPE_RECT, (hw, hh, rounding), **kw))
+
+    def capsule(self, pos, hl, r, density=1.0, angle=0.0, vel=(0, 0), angvel=0.0, **kw):
+        mr = density * (2 * hl) * (2 * r)
+        mc = density * np.pi * r * r
+        ir = mr * ((2 * hl) ** 2 + (2 * r) ** 2) / 12.0
+        ic = mc * (0.5 * r * r + hl * hl)
+        return self._add(pos, angle, vel, angvel, mr + mc, ir + ic, self._col(SHAPE_CAPSULE, (hl, 0, r), **kw))
+
+    def poly(self, pos, verts, density=1.0, angle=0.0, vel=(0, 0), angvel=0.0, rounding=0.0, **kw):
+        v = np.asarray(verts, np.float64)
+        x, y = v[:, 0], v[:, 1]
+        x1, y1 = np.roll(x, -1), np.roll(y, -1)
+        cr = x * y1 - x1 * y
+        area = 0.5 * cr.sum()
+        cx = ((x + x1) * cr).sum() / (6 * area)
+        cy = ((y + y1) * cr).sum() / (6 * area)
+        v = v - (cx, cy)  # centre of mass at the body origin
+        x, y = v[:, 0], v[:, 1]
+        x1, y1 = np.roll(x, -1), np.roll(y, -1)
+        cr = x * y1 - x1 * y
+        inertia = density * ((x * x + x * x1 + x1 * x1 + y * y + y * y1 + y1 * y1) * cr).sum() / 12.0
+        off = len(self.poly_pool)
+        self.poly_pool.extend(v.tolist())
+        return self._add(pos, angle, vel, angvel, density * area, inertia,
+                          self._col(SHAPE_POLY, (0, 0, rounding), poly_offset=off, poly_count=len(v), **kw))
+
+    def particle(self, pos, mass=1.0, vel=(0, 0)):
+        """Body without collider."""
+        return self._add(pos, 0.0, vel, 0.0, mass, 0.0, self._col(SHAPE_NONE, (0, 0, 0)))
+
+    def static_rect(self, pos, hw, hh, angle=0.0, **kw):
+        return self._add(pos, angle, (0, 0), 0.0, 0.0, 0.0, self._col(SHAPE_RECT, (hw, hh, 0.0), **kw))
+
+    def distance(self, a, b, anchor_a=(0, 0), anchor_b=(0, 0), rest=None, compliance=0.0):
+        if rest is None:
+            pa = np.asarray(anchor_a, float) if a == WORLD_BODY else np.asarray(self.pos[a], float)
+            pb = np.asarray(anchor_b, float) if b == WORLD_BODY else np.asarray(self.pos[b], float)
+            rest = float(np.linalg.norm(pb - pa))
+        self.constraints.append((a, b, tuple(anchor_a), tuple(anchor_b), rest, compliance))
+
+    def build(self):
+        n = len(self.pos)
+        f = lambda a, shape: np.ascontiguousarray(np.asarray(a, np.float32).reshape(shape))
+        return Scene(
+            self.name, f(self.pos, (n, 2)), f(self.rot, (n, 2)), f(self.vel, (n, 2)), f(self.angvel, (n,)),
+            f(self.inv_mass, (n,)), f(self.inv_inertia, (n,)),
+            np.array(self.col, dtype=collider_dtype), np.array(self.materials, dtype=material_dtype),
+            f(self.poly_pool, (len(self.poly_pool), 2)), np.array(self.constraints, dtype=constraint_dtype),
+            substeps=self.substeps,
+        )
+
+
+def from_arrays(name, pos, angle, types, params, density=1.0, substeps=4, materials=None, statics=()):
+    """Vectorised builder for big scenes: dynamic bodies from arrays, plus static rects
+    given as (x, y, hw, hh) tuples appended at the end."""
+    pos = np.asarray(pos, np.float32)
+    n = pos.shape[0]
+    ns = len(statics)
+    params = np.asarray(params, np.float64)
+    a, b, r = params[:, 0], params[:, 1], params[:, 2]
+    mass = np.zeros(n)
+    inertia = np.zeros(n)
+    c = types == SHAPE_CIRCLE
+    mass[c] = density * np.pi * r[c] ** 2
+    inertia[c] = 0.5 * mass[c] * r[c] ** 2
+    q = types == SHAPE_RECT
+    w, h = 2 * (a[q] + r[q]), 2 * (b[q] + r[q])
+    mass[q] = density * w * h
+    inertia[q] = mass[q] * (w * w + h * h) / 12.0
+    k = types == SHAPE_CAPSULE
+    mr = density * (2 * a[k]) * (2 * r[k])
+    mc = density * np.pi * r[k] ** 2
+    mass[k] = mr + mc
+    inertia[k] = mr * ((2 * a[k]) ** 2 + (2 * r[k]) ** 2) / 12.0 + mc * (0.5 * r[k] ** 2 + a[k] ** 2)
+    col = np.zeros(n + ns, collider_dtype)
+    col["type"][:n] = types
+    col["p"][:n] = params.astype(np.float32)
+    col["category"] = 1
+    col["mask"] = 0xFFFFFFFF
+    P = np.zeros((n + ns, 2), np.float32)
+    P[:n] = pos
+    R = np.zeros((n + ns, 2), np.float32)
+    R[:n, 0] = np.cos(angle)
+    R[:n, 1] = np.sin(angle)
+    R[n:, 0] = 1.0
+    im = np.zeros(n + ns, np.float32)
+    ii = np.zeros(n + ns, np.float32)
+    im[:n] = 1.0 / mass
+    ii[:n] = 1.0 / inertia
+    for s, (x, y, hw, hh) in enumerate(statics):
+        P[n + s] = (x, y)
+        col["type"][n + s] = SHAPE_RECT
+        col["p"][n + s] = (hw, hh, 0.0)
+    mats = np.array(materials or [(0.1, 0.5, 0.4)], dtype=material_dtype)
+    return Scene(name, P, R, np.zeros((n + ns, 2), np.float32), np.zeros(n + ns, np.float32), im, ii,
+                 col, mats, substeps=substeps)
+
+
+# ------------------------------------------------------------------ the five configs
+
+def pyramid(base=31, substeps=10):
+    """Config 1 (BASELINE.json:7): box pyramid, rows base..1 of unit boxes on a static ground."""
+    b = SceneBuilder("pyramid", substeps=substeps)
+    for row in range(base):
+        cnt = base - row
+        for j in range(cnt):
+            b.rect(((j - (cnt - 1) / 2.0) * 1.05, 0.5 + row * 1.0), 0.5, 0.5)
+    b.static_rect((0.0, -0.5), 40.0, 0.5)
+    return b.build()
+
+
+def _container(floor_hw, wall_hh):
+    return [(0.0, -0.5, floor_hw, 0.5), (-floor_hw + 0.5, wall_hh, 0.5, wall_hh), (floor_hw - 0.5, wall_hh, 0.5, wall_hh)]
+
+
+def _lattice(n, width, pitch, jitter, u, y0=0.3):
+    k = np.arange(n)
+    x = ((k % width) - (width - 1) / 2.0) * pitch + (u[0::2][:n] * 2 - 1) * jitter
+    y = y0 + (k // width) * pitch + (u[1::2][:n] * 2 - 1) * jitter
+    return np.stack([x, y], 1)
+
+
+def circles_container(n=10_000, seed=0x5EED0002, width=100, pitch=0.22, floor_hw=24.0, wall_hh=30.0, substeps=4):
+    """Config 2 (BASELINE.json:8): n circles r~U[0.05,0.10] on a jittered lattice above a
+    static container of three rects."""
+    u = splitmix64_uniform(seed, 3 * n)
+    r = 0.05 + 0.05 * u[:n].astype(np.float64)
+    pos = _lattice(n, width, pitch, 0.01, u[n:])
+    types = np.full(n, SHAPE_CIRCLE, np.uint32)
+    params = np.stack([np.zeros(n), np.zeros(n), r], 1)
+    s = from_arrays("circles_container", pos, np.zeros(n), types, params, substeps=substeps,
+                    statics=_container(floor_hw, wall_hh))
+    return s
+
+
+def mixed_pile(n=100_000, seed=0x5EED0003, width=400, pitch=0.30, floor_hw=62.0, wall_hh=60.0, substeps=4):
+    """Config 3, the headline (BASELINE.json:9): 40 % circles, 30 % rects, 30 % capsules,
+    random initial rotation, on a lattice above the container."""
+    u = splitmix64_uniform(seed, 7 * n)
+    kind, u1, u2, u3, ang = u[:n], u[n:2 * n], u[2 * n:3 * n], u[3 * n:4 * n], u[4 * n:5 * n]
+    types = np.where(kind < 0.4, SHAPE_CIRCLE, np.where(kind < 0.7, SHAPE_RECT, SHAPE_CAPSULE)).astype(np.uint32)
+    params = np.zeros((n, 3))
+    c, q, k = types == SHAPE_CIRCLE, types == SHAPE_RECT, types == SHAPE_CAPSULE
+    params[c, 2] = 0.05 + 0.05 * u1[c]
+    params[q, 0] = 0.05 + 0.05 * u1[q]
+    params[q, 1] = 0.05 + 0.05 * u2[q]
+    params[k, 0] = 0.05 + 0.05 * u1[k]
+    params[k, 2] = 0.03 + 0.03 * u3[k]
+    pos = _lattice(n, width, pitch, 0.01, u[5 * n:])
+    return from_arrays("mixed_pile", pos, ang.astype(np.float64) * 2 * np.pi, types, params,
+                       substeps=substeps, statics=_container(floor_hw, wall_hh))
+
+
+def chains(n_chains=1000, links=100, r=0.05, rest=0.12, substeps=4):
+    """Config 4 (BASELINE.json:10): chains of circle links joined by rigid distance
+    constraints, link 0 tied to a world anchor; chain k starts horizontal at (0.5 k, 0.3 k).
+    Links of one chain share a collision group (no self collision)."""
+    n = n_chains * links
+    ch = np.repeat(np.arange(n_chains), links)
+    li = np.tile(np.arange(links), n_chains)
+    pos = np.stack([0.5 * ch + rest * (li + 1), 0.3 * ch], 1)
+    types = np.full(n, SHAPE_CIRCLE, np.uint32)
+    params = np.stack([np.zeros(n), np.zeros(n), np.full(n, r)], 1)
+    s = from_arrays("chains", pos, np.zeros(n), types, params, substeps=substeps)
+    s.colliders["group"] = ch + 1
+    con = np.zeros(n, constraint_dtype)
+    idx = np.arange(n)
+    con["body_b"] = idx
+    con["body_a"] = np.where(li == 0, WORLD_BODY, idx - 1)
+    con["anchor_a"][li == 0] = np.stack([0.5 * np.arange(n_chains), 0.3 * np.arange(n_chains)], 1)
+    con["rest_length"] = rest
+    s.constraints = con
+    return s
+
+
+def granular_slab(n=4_000_000, seed=0x5EED0005, width=8000, pitch=0.22, wall_hh=80.0, substeps=4, x_range=None):
+    """Config 5 (BASELINE.json:11): n circles on a `width`-wide lattice over a long floor."""
+    u = splitmix64_uniform(seed, 3 * n)
+    r = 0.05 + 0.05 * u[:n].astype(np.float64)
+    pos = _lattice(n, width, pitch, 0.01, u[n:])
+    floor_hw = width * pitch / 2.0 + 2.0
+    types = np.full(n, SHAPE_CIRCLE, np.uint32)
+    params = np.stack([np.zeros(n), np.zeros(n), r], 1)
+    return from_arrays("granular_slab", pos, np.zeros(n), types, params, substeps=substeps,
+                       statics=_container(floor_hw, wall_hh))
+
+
+# ------------------------------------------------------------------ small test scenes
+
+def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, speed=1.0):
+    """Overlapping random shapes of every type with random velocities: a broadphase and
+    narrowphase stress scene for parity tests."""
+    rng = np.random.default_rng(seed)
+    b = SceneBuilder(f"soup{n}_{seed}", materials=[(0.1, 0.5, 0.4), (0.6, 0.8, 0.6), (0.0, 0.2, 0.1)])
+    for i in range(n):
+        p = rng.uniform(-extent, extent, 2)
+        ang = rng.uniform(0, 2 * np.pi)
+        v = rng.normal(0, speed, 2)
+        w = rng.normal(0, 2.0)
+        t = rng.integers(0, 4 if with_poly else 3)
+        kw = dict(angle=ang, vel=v, angvel=w, material=int(rng.integers(0, 3)))
+        if rng.random() < 0.1:
+            kw["group"] = int(rng.integers(1, 4))
+        if rng.random() < 0.1:
+            kw["category"], kw["mask"] = 2, 0xFFFFFFFD
+        if t == 0:
+            b.circle(p, rng.uniform(0.05, 0.2), **kw)
+        elif t == 1:
+            b.rect(p, rng.uniform(0.05, 0.2), rng.uniform(0.05, 0.2), rounding=rng.choice([0.0, 0.02]), **kw)
+        elif t == 2:
+            b.capsule(p, rng.uniform(0.05, 0.2), rng.uniform(0.03, 0.08), **kw)
+        else:
+            k = int(rng.integers(3, 9))
+            a = np.sort(rng.uniform(0, 2 * np.pi, k))
+            a = a + np.linspace(0, 1e-3, k)
+            rad = rng.uniform(0.08, 0.2)
+            b.poly(p, np.stack([rad * np.cos(a), rad * np.sin(a)], 1), rounding=rng.choice([0.0, 0.015]), **kw)
+    if with_statics:
+        b.static_rect((0.0, -extent - 0.5), extent + 2.0, 0.5)
+        b.static_rect((-extent - 1.0, 0.0), 0.5, extent + 1.0)
+        b.static_rect((extent + 1.0, 0.0), 0.5, extent + 1.0, angle=0.1)
+    return b.build()

@@ -1,0 +1,184 @@
+"""Thin Python handle over the libsfx C ABI (include/sfx.h).
+
+`World` owns one `sfx_world*`.  `WorldBase` holds the marshalling shared with the CPU
+oracle's handle (oracle/oracle.py), so parity tests drive both through identical calls.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import (
+    K_CLASSES, SFX_OK, SfxFrameStats, SfxKernelTime, contact_dtype, fptr, make_config, vptr,
+)
+
+
+class SfxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"sfx error {code}: {msg}")
+        self.code = code
+
+
+class WorldBase:
+    """Marshalling over a `<prefix>_*` world API; subclasses provide lib, prefix, handle."""
+
+    lib = None
+    prefix = ""
+    handle = None
+    n = 0
+    m = 0
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def _check(self, rc):
+        if rc != SFX_OK:
+            raise SfxError(rc, self.last_error())
+        return rc
+
+    def last_error(self):
+        return ""
+
+    def upload(self, scene):
+        """Upload a scenes.Scene: bodies, colliders, materials, constraints."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        self.n = scene.n
+        pos, rot, vel = f32(scene.pos), f32(scene.rot), f32(scene.vel)
+        angvel, im, ii = f32(scene.angvel), f32(scene.inv_mass), f32(scene.inv_inertia)
+        self._check(self._f("upload_bodies")(self.handle, self.n, fptr(pos), fptr(rot), fptr(vel),
+                                              fptr(angvel), fptr(im), fptr(ii)))
+        col = np.ascontiguousarray(scene.colliders)
+        pv = f32(scene.poly_verts).reshape(-1, 2)
+        self._check(self._f("upload_materials")(self.handle, len(scene.materials),
+                                                 vptr(np.ascontiguousarray(scene.materials))))
+        self._check(self._f("upload_colliders")(self.handle, len(col), vptr(col), fptr(pv), pv.shape[0]))
+        con = np.ascontiguousarray(scene.constraints)
+        self.m = len(con)
+        self._check(self._f("upload_constraints")(self.handle, len(con), vptr(con)))
+        return self
+
+    def set_state(self, pos, rot, vel, angvel, inv_mass, inv_inertia):
+        """Replace the body state (same body count; colliders and constraints are kept)."""
+        f32 = lambda a: np.ascontiguousarray(a, np.float32)
+        a = [f32(x) for x in (pos, rot, vel, angvel, inv_mass, inv_inertia)]
+        assert a[0].shape[0] == self.n
+        self._check(self._f("upload_bodies")(self.handle, self.n, *[fptr(x) for x in a]))
+
+    def poses(self):
+        pos = np.empty((self.n, 2), np.float32)
+        rot = np.empty((self.n, 2), np.float32)
+        self._check(self._f("download_poses")(self.handle, fptr(pos), fptr(rot)))
+        return pos, rot
+
+    def velocities(self):
+        vel = np.empty((self.n, 2), np.float32)
+        angvel = np.empty(self.n, np.float32)
+        self._check(self._f("download_velocities")(self.handle, fptr(vel), fptr(angvel)))
+        return vel, angvel
+
+    def stats(self):
+        st = SfxFrameStats()
+        self._check(self._f("stats")(self.handle, C.byref(st)))
+        return st
+
+
+class World(WorldBase):
+    """A libsfx world on one MI355X.  Raises if the HIP library or the device is missing."""
+
+    prefix = "sfx_"
+
+    def __init__(self, cfg=None, **cfg_kw):
+        self.lib = _abi.load_libsfx()
+        self.cfg = cfg or make_config(**cfg_kw)
+        h = C.c_void_p()
+        rc = self.lib.sfx_create(C.byref(self.cfg), C.byref(h))
+        if rc != SFX_OK:
+            raise SfxError(rc, (self.lib.sfx_last_error(None) or b"").decode())
+        self.handle = h
+
+    @classmethod
+    def from_scene(cls, scene, **cfg_kw):
+        kw = dict(substeps=scene.substeps, gravity=scene.gravity, aabb_margin=scene.aabb_margin)
+        kw.update(cfg_kw)
+        return cls(**kw).upload(scene)
+
+    def last_error(self):
+        return (self.lib.sfx_last_error(self.handle) or b"").decode()
+
+    def close(self):
+        if self.handle:
+            self.lib.sfx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def step(self, dt):
+        self._check(self.lib.sfx_step(self.handle, dt))
+
+    def sync(self):
+        self._check(self.lib.sfx_sync(self.handle))
+
+    # ---- parity hooks
+    def broadphase(self, dt):
+        self._check(self.lib.sfx_debug_broadphase(self.handle, dt))
+
+    def aabbs(self):
+        out = np.empty((self.n, 4), np.float32)
+        self._check(self.lib.sfx_debug_aabbs(self.handle, fptr(out)))
+        return out
+
+    def pairs(self):
+        cap = max(int(self.stats().n_pairs), 1)
+        keys = np.empty(cap, np.uint64)
+        n = C.c_size_t()
+        self._check(self.lib.sfx_debug_pairs(self.handle, vptr(keys), cap, C.byref(n)))
+        return keys[: min(n.value, cap)]
+
+    def pair_colors(self):
+        cap = max(int(self.stats().n_pairs), 1)
+        keys = np.empty(cap, np.uint64)
+        col = np.empty(cap, np.uint8)
+        n = C.c_size_t()
+        self._check(self.lib.sfx_debug_pair_colors(self.handle, vptr(keys), vptr(col), cap, C.byref(n)))
+        k = min(n.value, cap)
+        return keys[:k], col[:k]
+
+    def contacts(self):
+        cap = max(int(self.stats().n_pairs), 1)
+        out = np.zeros(cap, contact_dtype)
+        n = C.c_size_t()
+        self._check(self.lib.sfx_debug_contacts(self.handle, vptr(out), cap, C.byref(n)))
+        return out[: min(n.value, cap)]
+
+    def joint_order(self):
+        cap = max(self.m, 1)
+        perm = np.empty(cap, np.uint32)
+        col = np.empty(cap, np.uint8)
+        n = C.c_size_t()
+        self._check(self.lib.sfx_debug_joint_order(self.handle, vptr(perm), vptr(col), cap, C.byref(n)))
+        return perm[: n.value], col[: n.value]
+
+    # ---- reporting
+    def set_profiling(self, on):
+        self._check(self.lib.sfx_set_profiling(self.handle, int(on)))
+
+    def kernel_times(self, reset=False):
+        arr = (SfxKernelTime * K_CLASSES)()
+        self._check(self.lib.sfx_kernel_times(self.handle, arr, int(reset)))
+        out = {}
+        for k in range(K_CLASSES):
+            name = self.lib.sfx_kernel_class_name(k).decode()
+            out[name] = dict(total_ms=arr[k].total_ms, launches=arr[k].launches, items=arr[k].items)
+        return out
+
+    def timer_begin(self):
+        self._check(self.lib.sfx_timer_begin(self.handle))
+
+    def timer_end(self):
+        ms = C.c_double()
+        self._check(self.lib.sfx_timer_end(self.handle, C.byref(ms)))
+        return ms.value
