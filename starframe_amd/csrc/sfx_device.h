@@ -1,0 +1,754 @@
+// sfx_device.h -- device-side math, narrowphase and per-manifold XPBD solvers (gfx950).
+//
+// Written for the wave64 / HBM-bound regime of MI355X: every routine here works on
+// registers only; the kernels in sfx_kernels.h do the (16-byte, lane-contiguous where the
+// data layout allows) loads and stores around them.  Arithmetic follows DESIGN.md
+// "Contract" operation by operation and the library is built with -ffp-contract=off, so
+// the CPU oracle (oracle/sfx_oracle.c, an independent restatement) can be compared
+// bit-for-bit where the contract demands exactness.
+//
+// Paths restated from: Mueller et al. 2020 (XPBD rigid bodies) Alg. 2, sec. 3.3-3.6; the
+// reference implementation (starframe, Rust) is not available -- see DESIGN.md.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sfx.h"
+
+#define SFX_EPS_LEN 1e-9f
+#define SFX_NO_COLOR 0xFFu
+#define SFX_NO_BUCKET 0xFFFFFFFFu
+
+namespace sfx {
+
+// ---- body state records (all 16-byte aligned, one record per body, SoA of records) ----
+// pose  : float4 (x, y, cos, sin)        prev : the pose at the start of the substep
+// vel   : float4 (vx, vy, omega, 0)      mass : float2 (inv_mass, inv_inertia)
+// shape : float4 (bits: type | material << 8, a, b, r); POLY keeps offset/count in a/b bits
+// filt  : uint4  (category, mask, group, dynamic)
+
+struct BodyArrays {
+    float4* pose;
+    float4* prev;
+    float4* vel;
+    const float2* mass;
+    const float4* shape;
+    const uint4* filt;
+    const float4* poly;  // (vx, vy, nx, ny) per pool vertex
+    const float4* mats;  // (restitution, mu_s, mu_d, 0)
+};
+
+__device__ __forceinline__ uint32_t shape_type(const float4& s) { return __float_as_uint(s.x) & 0xFFu; }
+__device__ __forceinline__ uint32_t shape_material(const float4& s) { return __float_as_uint(s.x) >> 8; }
+
+__device__ __forceinline__ void rotate_by(float& c, float& s, float dth) {
+    float nc = c - dth * s;
+    float ns = s + dth * c;
+    float inv = 1.0f / sqrtf(nc * nc + ns * ns);
+    c = nc * inv;
+    s = ns * inv;
+}
+
+// ---- AABB (DESIGN.md "Contract / AABB") --------------------------------------------
+__device__ __forceinline__ float4 compute_aabb(const float4& pose, const float4& vel, const float4& shape,
+                                               const float4* __restrict__ poly, float margin, float dt) {
+    const float px = pose.x, py = pose.y, rc = pose.z, rs = pose.w;
+    float minx, maxx, miny, maxy;
+    const uint32_t type = shape_type(shape);
+    if (type == SFX_SHAPE_CIRCLE) {
+        minx = -shape.w; maxx = shape.w; miny = -shape.w; maxy = shape.w;
+    } else if (type == SFX_SHAPE_RECT) {
+        float ex = (fabsf(rc * shape.y) + fabsf(rs * shape.z)) + shape.w;
+        float ey = (fabsf(rs * shape.y) + fabsf(rc * shape.z)) + shape.w;
+        minx = -ex; maxx = ex; miny = -ey; maxy = ey;
+    } else if (type == SFX_SHAPE_CAPSULE) {
+        float ex = fabsf(rc * shape.y) + shape.w;
+        float ey = fabsf(rs * shape.y) + shape.w;
+        minx = -ex; maxx = ex; miny = -ey; maxy = ey;
+    } else if (type == SFX_SHAPE_POLY) {
+        const uint32_t off = __float_as_uint(shape.y), cnt = __float_as_uint(shape.z);
+        minx = miny = INFINITY; maxx = maxy = -INFINITY;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            float4 v = poly[off + k];
+            float wx = rc * v.x - rs * v.y, wy = rs * v.x + rc * v.y;
+            minx = fminf(minx, wx); maxx = fmaxf(maxx, wx);
+            miny = fminf(miny, wy); maxy = fmaxf(maxy, wy);
+        }
+        minx -= shape.w; maxx += shape.w; miny -= shape.w; maxy += shape.w;
+    } else {
+        return make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
+    }
+    float padx = margin + fabsf(vel.x) * dt;
+    float pady = margin + fabsf(vel.y) * dt;
+    return make_float4((px + minx) - padx, (py + miny) - pady, (px + maxx) + padx, (py + maxy) + pady);
+}
+
+__device__ __forceinline__ bool aabb_overlap(const float4& A, const float4& B) {
+    return A.x <= B.z && B.x <= A.z && A.y <= B.w && B.y <= A.w;
+}
+
+__device__ __forceinline__ bool pair_filter(const uint4& a, const uint4& b) {
+    if (!(a.w | b.w)) return false;
+    if (!(a.x & b.y) || !(b.x & a.y)) return false;
+    if (a.z != 0 && a.z == b.z) return false;
+    return true;
+}
+
+__device__ __forceinline__ int32_t cell_coord(float lo, float inv_cell) {
+    float f = floorf(lo * inv_cell);
+    if (!(f > -1073741824.0f)) f = -1073741824.0f;
+    if (f > 1073741824.0f) f = 1073741824.0f;
+    return (int32_t)f;
+}
+
+// ---- colouring hash (DESIGN.md "Contract / colouring") ------------------------------
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+
+__device__ __forceinline__ uint32_t kth_set_bit(uint64_t m, uint32_t k) {
+    for (uint32_t i = 0; i < k; ++i) m &= m - 1;
+    return (uint32_t)__builtin_ctzll(m);
+}
+
+// ---- narrowphase ---------------------------------------------------------------------
+// Every shape is a convex core polygon of 1..MAXV vertices plus a radius.  Arrays are only
+// ever indexed by unrolled loop counters so they live in VGPRs (runtime-indexed arrays
+// would go to scratch memory).
+
+template <int MAXV>
+struct Core {
+    int n;
+    float vx[MAXV], vy[MAXV], nx[MAXV], ny[MAXV];
+    float r;
+};
+
+struct Manifold {
+    int count;
+    float nx, ny;
+    float p1x[2], p1y[2], p2x[2], p2y[2], depth[2];
+};
+
+template <int N>
+__device__ __forceinline__ float pick(const float (&a)[N], int k) {
+    float v = a[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) v = (i == k) ? a[i] : v;
+    return v;
+}
+
+template <int MAXV>
+__device__ __forceinline__ void build_core(const float4& pose, const float4& shape,
+                                           const float4* __restrict__ poly, Core<MAXV>& c) {
+    const float px = pose.x, py = pose.y, rc = pose.z, rs = pose.w;
+    const uint32_t type = shape_type(shape);
+    c.r = shape.w;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) { c.vx[k] = 0.0f; c.vy[k] = 0.0f; c.nx[k] = 0.0f; c.ny[k] = 0.0f; }
+    if (type == SFX_SHAPE_CIRCLE) {
+        c.n = 1; c.vx[0] = px; c.vy[0] = py;
+    } else if (type == SFX_SHAPE_RECT) {
+        float ax = rc * shape.y, ay = rs * shape.y;
+        float bx = -rs * shape.z, by = rc * shape.z;
+        c.n = 4;
+        c.vx[0] = (px - ax) - bx; c.vy[0] = (py - ay) - by;
+        c.vx[1] = (px + ax) - bx; c.vy[1] = (py + ay) - by;
+        c.vx[2] = (px + ax) + bx; c.vy[2] = (py + ay) + by;
+        c.vx[3] = (px - ax) + bx; c.vy[3] = (py - ay) + by;
+        c.nx[0] = rs;  c.ny[0] = -rc;
+        c.nx[1] = rc;  c.ny[1] = rs;
+        c.nx[2] = -rs; c.ny[2] = rc;
+        c.nx[3] = -rc; c.ny[3] = -rs;
+    } else if (type == SFX_SHAPE_CAPSULE) {
+        float ax = rc * shape.y, ay = rs * shape.y;
+        c.n = 2;
+        c.vx[0] = px - ax; c.vy[0] = py - ay;
+        c.vx[1] = px + ax; c.vy[1] = py + ay;
+        c.nx[0] = rs;  c.ny[0] = -rc;
+        c.nx[1] = -rs; c.ny[1] = rc;
+    } else if (type == SFX_SHAPE_POLY) {
+        if constexpr (MAXV >= 8) {
+            const uint32_t off = __float_as_uint(shape.y);
+            c.n = (int)__float_as_uint(shape.z);
+#pragma unroll
+            for (int k = 0; k < MAXV; ++k) {
+                if (k < c.n) {
+                    float4 v = poly[off + k];
+                    c.vx[k] = px + (rc * v.x - rs * v.y); c.vy[k] = py + (rs * v.x + rc * v.y);
+                    c.nx[k] = rc * v.z - rs * v.w;        c.ny[k] = rs * v.z + rc * v.w;
+                }
+            }
+        } else {
+            c.n = 0;
+        }
+    } else {
+        c.n = 0;
+    }
+}
+
+__device__ __forceinline__ void cc_manifold(float ax, float ay, float ar, float bx, float by, float br, Manifold& m) {
+    float dx = bx - ax, dy = by - ay;
+    float d2 = dx * dx + dy * dy;
+    float rsum = ar + br;
+    m.count = 0;
+    if (d2 > rsum * rsum) return;
+    float dist = sqrtf(d2);
+    float nx = 0.0f, ny = 1.0f;
+    if (dist > SFX_EPS_LEN) { nx = dx / dist; ny = dy / dist; }
+    float depth = rsum - dist;
+    if (!(depth > 0.0f)) return;
+    m.count = 1; m.nx = nx; m.ny = ny; m.depth[0] = depth;
+    m.p1x[0] = ax + nx * ar; m.p1y[0] = ay + ny * ar;
+    m.p2x[0] = bx - nx * br; m.p2y[0] = by - ny * br;
+}
+
+// closest point on the boundary of P (n >= 2) to (cx, cy); first minimum wins
+template <int MAXV>
+__device__ __forceinline__ void closest_on_poly(const Core<MAXV>& P, float cx, float cy, float& qx, float& qy, float& d2out) {
+    float best = INFINITY, bx = 0.0f, by = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        if (k < P.n) {
+            const bool wrap = (k + 1 == P.n) || (k + 1 == MAXV);
+            float x1 = wrap ? P.vx[0] : P.vx[(k + 1) % MAXV];
+            float y1 = wrap ? P.vy[0] : P.vy[(k + 1) % MAXV];
+            float ex = x1 - P.vx[k], ey = y1 - P.vy[k];
+            float wx = cx - P.vx[k], wy = cy - P.vy[k];
+            float ee = ex * ex + ey * ey;
+            float t = 0.0f;
+            if (ee > 0.0f) t = (wx * ex + wy * ey) / ee;
+            t = fminf(fmaxf(t, 0.0f), 1.0f);
+            float x = P.vx[k] + t * ex, y = P.vy[k] + t * ey;
+            float ddx = cx - x, ddy = cy - y;
+            float d2 = ddx * ddx + ddy * ddy;
+            if (d2 < best) { best = d2; bx = x; by = y; }
+        }
+    }
+    qx = bx; qy = by; d2out = best;
+}
+
+// polygon P (n >= 2) against a circle: normal from P to the circle
+template <int MAXV>
+__device__ __forceinline__ void pc_manifold(const Core<MAXV>& P, float cx, float cy, float cr, Manifold& m) {
+    float rsum = P.r + cr;
+    float sep = -INFINITY, snx = 0.0f, sny = 0.0f;
+    m.count = 0;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        if (k < P.n) {
+            float s = P.nx[k] * (cx - P.vx[k]) + P.ny[k] * (cy - P.vy[k]);
+            if (s > sep) { sep = s; snx = P.nx[k]; sny = P.ny[k]; }
+        }
+    }
+    if (sep > rsum) return;
+    float nx, ny, qx, qy, depth;
+    if (P.n == 2 || sep > 0.0f) {
+        float d2;
+        closest_on_poly<MAXV>(P, cx, cy, qx, qy, d2);
+        if (d2 > rsum * rsum) return;
+        float dist = sqrtf(d2);
+        if (dist > SFX_EPS_LEN) { nx = (cx - qx) / dist; ny = (cy - qy) / dist; }
+        else { nx = snx; ny = sny; }
+        depth = rsum - dist;
+    } else {
+        nx = snx; ny = sny;
+        qx = cx - nx * sep; qy = cy - ny * sep;
+        depth = rsum - sep;
+    }
+    if (!(depth > 0.0f)) return;
+    m.count = 1; m.nx = nx; m.ny = ny; m.depth[0] = depth;
+    m.p1x[0] = qx + nx * P.r; m.p1y[0] = qy + ny * P.r;
+    m.p2x[0] = cx - nx * cr;  m.p2y[0] = cy - ny * cr;
+}
+
+template <int MAXV>
+__device__ __forceinline__ float sat_sep(const Core<MAXV>& P, const Core<MAXV>& Q, int& kbest) {
+    float best = -INFINITY;
+    int bk = 0;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        if (k < P.n) {
+            float s = INFINITY;
+#pragma unroll
+            for (int j = 0; j < MAXV; ++j) {
+                if (j < Q.n) {
+                    float d = P.nx[k] * (Q.vx[j] - P.vx[k]) + P.ny[k] * (Q.vy[j] - P.vy[k]);
+                    if (d < s) s = d;
+                }
+            }
+            if (s > best) { best = s; bk = k; }
+        }
+    }
+    kbest = bk;
+    return best;
+}
+
+// polygon against polygon (both n >= 2); normal from A to B
+template <int MAXV>
+__device__ __forceinline__ void pp_manifold(const Core<MAXV>& A, const Core<MAXV>& B, Manifold& m) {
+    int ka, kb;
+    const float rsum = A.r + B.r;
+    m.count = 0;
+    float sa = sat_sep<MAXV>(A, B, ka);
+    if (sa > rsum) return;
+    float sb = sat_sep<MAXV>(B, A, kb);
+    if (sb > rsum) return;
+    const bool flip = sb > sa;
+    // reference R / incident I, selected element-wise (keeps everything in registers)
+    Core<MAXV> R, I;
+    R.n = flip ? B.n : A.n; I.n = flip ? A.n : B.n;
+    R.r = flip ? B.r : A.r; I.r = flip ? A.r : B.r;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        R.vx[k] = flip ? B.vx[k] : A.vx[k]; R.vy[k] = flip ? B.vy[k] : A.vy[k];
+        R.nx[k] = flip ? B.nx[k] : A.nx[k]; R.ny[k] = flip ? B.ny[k] : A.ny[k];
+        I.vx[k] = flip ? A.vx[k] : B.vx[k]; I.vy[k] = flip ? A.vy[k] : B.vy[k];
+        I.nx[k] = flip ? A.nx[k] : B.nx[k]; I.ny[k] = flip ? A.ny[k] : B.ny[k];
+    }
+    const int kr = flip ? kb : ka;
+    const int kr1 = (kr + 1 == R.n) ? 0 : kr + 1;
+    const float nrx = pick(R.nx, kr), nry = pick(R.ny, kr);
+    const float r1x = pick(R.vx, kr), r1y = pick(R.vy, kr), r2x = pick(R.vx, kr1), r2y = pick(R.vy, kr1);
+    float bestd = INFINITY;
+    int ki = 0;
+#pragma unroll
+    for (int j = 0; j < MAXV; ++j) {
+        if (j < I.n) {
+            float d = I.nx[j] * nrx + I.ny[j] * nry;
+            if (d < bestd) { bestd = d; ki = j; }
+        }
+    }
+    const int ki1 = (ki + 1 == I.n) ? 0 : ki + 1;
+    const float i1x = pick(I.vx, ki), i1y = pick(I.vy, ki), i2x = pick(I.vx, ki1), i2y = pick(I.vy, ki1);
+    const float tx = -nry, ty = nrx;
+    const float L = (r2x - r1x) * tx + (r2y - r1y) * ty;
+    const float u1 = (i1x - r1x) * tx + (i1y - r1y) * ty;
+    const float u2 = (i2x - r1x) * tx + (i2y - r1y) * ty;
+    const float du = u2 - u1;
+    float ta = 0.0f, tb = 1.0f;
+    bool empty = false;
+    if (du > 0.0f) {
+        ta = fmaxf(ta, (0.0f - u1) / du);
+        tb = fminf(tb, (L - u1) / du);
+    } else if (du < 0.0f) {
+        tb = fminf(tb, (0.0f - u1) / du);
+        ta = fmaxf(ta, (L - u1) / du);
+    } else if (u1 < 0.0f || u1 > L) {
+        empty = true;
+    }
+    if (ta > tb) empty = true;
+    const float rr = R.r, ri = I.r;
+    float nx, ny;
+    float prx[2], pry[2], pix[2], piy[2], dep[2];
+    int cnt = 0;
+    if (!empty) {
+        const float ex = i2x - i1x, ey = i2y - i1y;
+        const int np = (tb > ta) ? 2 : 1;
+        nx = nrx; ny = nry;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k < np) {
+                const float tk = k == 0 ? ta : tb;
+                float cx = i1x + tk * ex, cy = i1y + tk * ey;
+                float s = (cx - r1x) * nrx + (cy - r1y) * nry;
+                float d = rsum - s;
+                if (d > 0.0f) {
+                    float fx = (cx - nrx * s) + nrx * rr, fy = (cy - nry * s) + nry * rr;
+                    float gx = cx - nrx * ri, gy = cy - nry * ri;
+                    if (cnt == 0) { prx[0] = fx; pry[0] = fy; pix[0] = gx; piy[0] = gy; dep[0] = d; }
+                    else { prx[1] = fx; pry[1] = fy; pix[1] = gx; piy[1] = gy; dep[1] = d; }
+                    ++cnt;
+                }
+            }
+        }
+    } else {
+        const bool lowend = (u1 + u2 < 0.0f);
+        float vx = lowend ? r1x : r2x, vy = lowend ? r1y : r2y;
+        float qx, qy, d2;
+        closest_on_poly<MAXV>(I, vx, vy, qx, qy, d2);
+        if (d2 > rsum * rsum) return;
+        float dist = sqrtf(d2);
+        if (dist > SFX_EPS_LEN) { nx = (qx - vx) / dist; ny = (qy - vy) / dist; }
+        else { nx = nrx; ny = nry; }
+        float d = rsum - dist;
+        if (d > 0.0f) {
+            prx[0] = vx + nx * rr; pry[0] = vy + ny * rr;
+            pix[0] = qx - nx * ri; piy[0] = qy - ny * ri;
+            dep[0] = d;
+            cnt = 1;
+        }
+    }
+    if (cnt == 0) return;
+    m.count = cnt;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k < cnt) {
+            m.depth[k] = dep[k];
+            m.p1x[k] = flip ? pix[k] : prx[k]; m.p1y[k] = flip ? piy[k] : pry[k];
+            m.p2x[k] = flip ? prx[k] : pix[k]; m.p2y[k] = flip ? pry[k] : piy[k];
+        }
+    }
+    m.nx = flip ? -nx : nx;
+    m.ny = flip ? -ny : ny;
+}
+
+template <int MAXV>
+__device__ __forceinline__ void manifold_poly(const float4& pa, const float4& sa, const float4& pb, const float4& sb,
+                                              const float4* __restrict__ poly, Manifold& m) {
+    const uint32_t ta = shape_type(sa), tb = shape_type(sb);
+    if (tb == SFX_SHAPE_CIRCLE) {
+        Core<MAXV> A;
+        build_core<MAXV>(pa, sa, poly, A);
+        if (A.n >= 2) pc_manifold<MAXV>(A, pb.x, pb.y, sb.w, m);
+    } else if (ta == SFX_SHAPE_CIRCLE) {
+        Core<MAXV> B;
+        build_core<MAXV>(pb, sb, poly, B);
+        if (B.n >= 2) {
+            Manifold t;
+            pc_manifold<MAXV>(B, pa.x, pa.y, sa.w, t);
+            m.count = t.count;
+            if (t.count) {
+                m.nx = -t.nx; m.ny = -t.ny; m.depth[0] = t.depth[0];
+                m.p1x[0] = t.p2x[0]; m.p1y[0] = t.p2y[0];
+                m.p2x[0] = t.p1x[0]; m.p2y[0] = t.p1y[0];
+            }
+        }
+    } else {
+        Core<MAXV> A, B;
+        build_core<MAXV>(pa, sa, poly, A);
+        build_core<MAXV>(pb, sb, poly, B);
+        if (A.n >= 2 && B.n >= 2) pp_manifold<MAXV>(A, B, m);
+    }
+}
+
+// manifold of two posed shapes, normal from a to b
+__device__ __forceinline__ void manifold(const float4& pa, const float4& sa, const float4& pb, const float4& sb,
+                                         const float4* __restrict__ poly, Manifold& m) {
+    const uint32_t ta = shape_type(sa), tb = shape_type(sb);
+    m.count = 0;
+    if (ta == SFX_SHAPE_NONE || tb == SFX_SHAPE_NONE) return;
+    if (ta == SFX_SHAPE_CIRCLE && tb == SFX_SHAPE_CIRCLE) {
+        cc_manifold(pa.x, pa.y, sa.w, pb.x, pb.y, sb.w, m);
+    } else if (ta == SFX_SHAPE_POLY || tb == SFX_SHAPE_POLY) {
+        manifold_poly<8>(pa, sa, pb, sb, poly, m);
+    } else {
+        manifold_poly<4>(pa, sa, pb, sb, poly, m);
+    }
+}
+
+// ---- per-manifold solver records -----------------------------------------------------
+// What the position solve leaves for the velocity pass, one record per candidate pair slot
+// (colour-sorted order), split into 16/8-byte arrays so a wave's accesses are contiguous.
+struct ContactArrays {
+    float4* hdr;     // (nx, ny, mu_s, mu_d)
+    float2* misc;    // (restitution, count as bits)
+    float4* anc0;    // point 0: (ra.x, ra.y, rb.x, rb.y) body-local
+    float4* anc1;    // point 1
+    float4* lamv;    // (lambda0, lambda1, vn_pre0, vn_pre1)
+};
+
+__device__ __forceinline__ void anchor_world(const float4& pose, float lx, float ly, float& rx, float& ry) {
+    rx = pose.z * lx - pose.w * ly;
+    ry = pose.w * lx + pose.z * ly;
+}
+
+__device__ __forceinline__ void solve_lcp2(float K00, float K01, float K11, float d0, float d1, float& l0, float& l1) {
+    float det = K00 * K11 - K01 * K01;
+    if (det > 1e-6f * (K00 * K11)) {
+        float inv = 1.0f / det;
+        float a = (K11 * d0 - K01 * d1) * inv;
+        float b = (K00 * d1 - K01 * d0) * inv;
+        if (a >= 0.0f && b >= 0.0f) { l0 = a; l1 = b; return; }
+    }
+    float a = d0 / K00;
+    if (a >= 0.0f && d1 - K01 * a <= 0.0f) { l0 = a; l1 = 0.0f; return; }
+    float b = d1 / K11;
+    if (b >= 0.0f && d0 - K01 * b <= 0.0f) { l0 = 0.0f; l1 = b; return; }
+    if (d0 >= d1) { l0 = fmaxf(d0, 0.0f) / K00; l1 = 0.0f; }
+    else { l0 = 0.0f; l1 = fmaxf(d1, 0.0f) / K11; }
+}
+
+// Position solve of one candidate pair: narrowphase at the current poses, block solve of
+// the manifold's normal constraints, poses written back.  Mueller et al. 2020 sec. 3.5.
+__device__ __forceinline__ void solve_pos_pair(const BodyArrays& B, const ContactArrays& C, uint32_t slot,
+                                               uint32_t a, uint32_t b) {
+    float4 pa = B.pose[a], pb = B.pose[b];
+    const float4 sa = B.shape[a], sb = B.shape[b];
+    Manifold m;
+    manifold(pa, sa, pb, sb, B.poly, m);
+    if (m.count == 0) {
+        C.misc[slot] = make_float2(0.0f, __uint_as_float(0u));
+        return;
+    }
+    const float4 ma = B.mats[shape_material(sa)], mb = B.mats[shape_material(sb)];
+    const float2 wa = B.mass[a], wb = B.mass[b];
+    const float4 va = B.vel[a], vb = B.vel[b];
+    const float mu_s = 0.5f * (ma.y + mb.y);
+    const float mu_d = 0.5f * (ma.z + mb.z);
+    const float rest = fmaxf(ma.x, mb.x);
+    const float nx = m.nx, ny = m.ny;
+    const float ima = wa.x, iia = wa.y, imb = wb.x, iib = wb.y;
+    float la[2][2], lb[2][2], d[2], cna[2], cnb[2], vpre[2];
+    la[1][0] = la[1][1] = lb[1][0] = lb[1][1] = 0.0f;
+    d[1] = 0.0f; cna[1] = 0.0f; cnb[1] = 0.0f; vpre[1] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k < m.count) {
+            float ax = m.p1x[k] - pa.x, ay = m.p1y[k] - pa.y;
+            float bx = m.p2x[k] - pb.x, by = m.p2y[k] - pb.y;
+            la[k][0] = pa.z * ax + pa.w * ay; la[k][1] = pa.z * ay - pa.w * ax;
+            lb[k][0] = pb.z * bx + pb.w * by; lb[k][1] = pb.z * by - pb.w * bx;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k < m.count) {
+            float rax, ray, rbx, rby;
+            anchor_world(pa, la[k][0], la[k][1], rax, ray);
+            anchor_world(pb, lb[k][0], lb[k][1], rbx, rby);
+            float vax = va.x - va.z * ray, vay = va.y + va.z * rax;
+            float vbx = vb.x - vb.z * rby, vby = vb.y + vb.z * rbx;
+            vpre[k] = (vbx - vax) * nx + (vby - vay) * ny;
+            d[k] = ((pa.x + rax) - (pb.x + rbx)) * nx + ((pa.y + ray) - (pb.y + rby)) * ny;
+            cna[k] = rax * ny - ray * nx;
+            cnb[k] = rbx * ny - rby * nx;
+        }
+    }
+    float l0 = 0.0f, l1 = 0.0f;
+    const float ims = ima + imb;
+    const float K00 = (ims + iia * (cna[0] * cna[0])) + iib * (cnb[0] * cnb[0]);
+    if (K00 > 0.0f) {
+        if (m.count == 2) {
+            float K11 = (ims + iia * (cna[1] * cna[1])) + iib * (cnb[1] * cnb[1]);
+            float K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
+            solve_lcp2(K00, K01, K11, d[0], d[1], l0, l1);
+        } else {
+            l0 = fmaxf(d[0], 0.0f) / K00;
+        }
+    }
+    C.hdr[slot] = make_float4(nx, ny, mu_s, mu_d);
+    C.misc[slot] = make_float2(rest, __uint_as_float((uint32_t)m.count));
+    C.anc0[slot] = make_float4(la[0][0], la[0][1], lb[0][0], lb[0][1]);
+    if (m.count == 2) C.anc1[slot] = make_float4(la[1][0], la[1][1], lb[1][0], lb[1][1]);
+    C.lamv[slot] = make_float4(l0, l1, vpre[0], vpre[1]);
+    const float lt = l0 + l1;
+    if (!(lt > 0.0f)) return;
+    if (ima > 0.0f) {
+        pa.x = pa.x - (nx * lt) * ima;
+        pa.y = pa.y - (ny * lt) * ima;
+    }
+    if (iia > 0.0f) rotate_by(pa.z, pa.w, -(iia * (cna[0] * l0 + cna[1] * l1)));
+    if (imb > 0.0f) {
+        pb.x = pb.x + (nx * lt) * imb;
+        pb.y = pb.y + (ny * lt) * imb;
+    }
+    if (iib > 0.0f) rotate_by(pb.z, pb.w, iib * (cnb[0] * l0 + cnb[1] * l1));
+    if (ima > 0.0f || iia > 0.0f) B.pose[a] = pa;
+    if (imb > 0.0f || iib > 0.0f) B.pose[b] = pb;
+}
+
+__device__ __forceinline__ void kinv_apply(float K0, float K1, float K01, bool act0, bool act1, int count,
+                                           float r0, float r1, float& y0, float& y1) {
+    y0 = 0.0f; y1 = 0.0f;
+    if (count == 2 && act0 && act1) {
+        float det = K0 * K1 - K01 * K01;
+        if (det > 1e-6f * (K0 * K1)) {
+            float inv = 1.0f / det;
+            y0 = (K1 * r0 - K01 * r1) * inv;
+            y1 = (K0 * r1 - K01 * r0) * inv;
+        } else {
+            y0 = 0.5f * (r0 / K0); y1 = 0.5f * (r1 / K1);
+        }
+    } else if (act0) {
+        y0 = r0 / K0;
+    } else if (count == 2 && act1) {
+        y1 = r1 / K1;
+    }
+}
+
+struct StepParams {
+    float h, inv_h, inv_h2;
+    float gx, gy;
+    float vthr;      // restitution threshold velocity: cfg.restitution_threshold * |g| * h
+    uint32_t flags;
+};
+
+// Velocity pass of one candidate pair: restitution block, then friction with compensating
+// normal impulses (static friction also shifts the poses).  Mueller et al. 2020 sec. 3.6.
+__device__ __forceinline__ void solve_vel_pair(const BodyArrays& B, const ContactArrays& C, uint32_t slot,
+                                               uint32_t a, uint32_t b, const StepParams& sp) {
+    const float2 misc = C.misc[slot];
+    const int count = (int)__float_as_uint(misc.y);
+    if (count == 0) return;
+    const float4 lamv = C.lamv[slot];
+    const float l0 = lamv.x, l1 = count == 2 ? lamv.y : 0.0f;
+    const float lt = l0 + l1;
+    if (!(lt > 0.0f)) return;
+    const float4 hdr = C.hdr[slot];
+    const float nx = hdr.x, ny = hdr.y, mu_s = hdr.z, mu_d = hdr.w, rest = misc.x;
+    const float4 a0 = C.anc0[slot];
+    float4 a1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (count == 2) a1 = C.anc1[slot];
+    float4 pa = B.pose[a], pb = B.pose[b];
+    float4 va = B.vel[a], vb = B.vel[b];
+    const float2 wa = B.mass[a], wb = B.mass[b];
+    const float ima = wa.x, iia = wa.y, imb = wb.x, iib = wb.y;
+    const float ims = ima + imb;
+    float rax[2], ray[2], rbx[2], rby[2], dv[2], cna[2], cnb[2], K[2];
+    bool act[2];
+    act[1] = false; dv[1] = 0.0f; cna[1] = 0.0f; cnb[1] = 0.0f; K[1] = 1.0f;
+    rax[1] = ray[1] = rbx[1] = rby[1] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k < count) {
+            const float4 an = k == 0 ? a0 : a1;
+            const float lam = k == 0 ? lamv.x : lamv.y;
+            const float vpre = k == 0 ? lamv.z : lamv.w;
+            anchor_world(pa, an.x, an.y, rax[k], ray[k]);
+            anchor_world(pb, an.z, an.w, rbx[k], rby[k]);
+            float vax = va.x - va.z * ray[k], vay = va.y + va.z * rax[k];
+            float vbx = vb.x - vb.z * rby[k], vby = vb.y + vb.z * rbx[k];
+            float vn = (vbx - vax) * nx + (vby - vay) * ny;
+            float e = fabsf(vpre) <= sp.vthr ? 0.0f : rest;
+            dv[k] = fmaxf(-e * vpre, 0.0f) - vn;
+            cna[k] = rax[k] * ny - ray[k] * nx;
+            cnb[k] = rbx[k] * ny - rby[k] * nx;
+            K[k] = (ims + iia * (cna[k] * cna[k])) + iib * (cnb[k] * cnb[k]);
+            act[k] = lam > 0.0f && K[k] > 0.0f;
+        }
+    }
+    float K01 = 0.0f;
+    if (count == 2) K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
+    float p0, p1;
+    kinv_apply(K[0], K[1], K01, act[0], act[1], count, dv[0], dv[1], p0, p1);
+    {
+        float pt = p0 + p1;
+        float cra = cna[0] * p0 + cna[1] * p1, crb = cnb[0] * p0 + cnb[1] * p1;
+        va.x = va.x - (nx * pt) * ima;
+        va.y = va.y - (ny * pt) * ima;
+        va.z = va.z - iia * cra;
+        vb.x = vb.x + (nx * pt) * imb;
+        vb.y = vb.y + (ny * pt) * imb;
+        vb.z = vb.z + iib * crb;
+    }
+    bool shift = false;
+    if (!(sp.flags & SFX_CFG_NO_FRICTION)) {
+        float max_, may_, mbx_, mby_;
+        if (count == 2) {
+            max_ = 0.5f * (rax[0] + rax[1]); may_ = 0.5f * (ray[0] + ray[1]);
+            mbx_ = 0.5f * (rbx[0] + rbx[1]); mby_ = 0.5f * (rby[0] + rby[1]);
+        } else { max_ = rax[0]; may_ = ray[0]; mbx_ = rbx[0]; mby_ = rby[0]; }
+        float vax = va.x - va.z * may_, vay = va.y + va.z * max_;
+        float vbx = vb.x - vb.z * mby_, vby = vb.y + vb.z * mbx_;
+        float vx = vbx - vax, vy = vby - vay;
+        float vn = vx * nx + vy * ny;
+        float vtx = vx - nx * vn, vty = vy - ny * vn;
+        float vt = sqrtf(vtx * vtx + vty * vty);
+        if (vt > SFX_EPS_LEN) {
+            float tx = vtx / vt, ty = vty / vt;
+            float cta = max_ * ty - may_ * tx, ctb = mbx_ * ty - mby_ * tx;
+            float Att = (ims + iia * (cta * cta)) + iib * (ctb * ctb);
+            float At0 = iia * (cta * cna[0]) + iib * (ctb * cnb[0]);
+            float At1 = iia * (cta * cna[1]) + iib * (ctb * cnb[1]);
+            float y0, y1;
+            kinv_apply(K[0], K[1], K01, act[0], act[1], count, At0, At1, y0, y1);
+            float S = Att - (At0 * y0 + At1 * y1);
+            if (S > 0.0f) {
+                float need = vt / S;
+                bool is_static = need * sp.h < mu_s * lt;
+                float pt = is_static ? -need : -fminf(mu_d * lt * sp.inv_h, need);
+                float q0 = -(y0 * pt), q1 = -(y1 * pt);
+                float jx = tx * pt + nx * (q0 + q1), jy = ty * pt + ny * (q0 + q1);
+                float ja = (cta * pt + cna[0] * q0) + cna[1] * q1;
+                float jb = (ctb * pt + cnb[0] * q0) + cnb[1] * q1;
+                va.x = va.x - jx * ima;
+                va.y = va.y - jy * ima;
+                va.z = va.z - iia * ja;
+                vb.x = vb.x + jx * imb;
+                vb.y = vb.y + jy * imb;
+                vb.z = vb.z + iib * jb;
+                if (is_static) {
+                    shift = true;
+                    if (ima > 0.0f) {
+                        pa.x = pa.x - (jx * sp.h) * ima;
+                        pa.y = pa.y - (jy * sp.h) * ima;
+                    }
+                    if (iia > 0.0f) rotate_by(pa.z, pa.w, -(iia * (ja * sp.h)));
+                    if (imb > 0.0f) {
+                        pb.x = pb.x + (jx * sp.h) * imb;
+                        pb.y = pb.y + (jy * sp.h) * imb;
+                    }
+                    if (iib > 0.0f) rotate_by(pb.z, pb.w, iib * (jb * sp.h));
+                }
+            }
+        }
+    }
+    const bool dyn_a = ima > 0.0f || iia > 0.0f, dyn_b = imb > 0.0f || iib > 0.0f;
+    if (dyn_a) { B.vel[a] = va; if (shift) B.pose[a] = pa; }
+    if (dyn_b) { B.vel[b] = vb; if (shift) B.pose[b] = pb; }
+}
+
+// distance constraint (Mueller et al. 2020 sec. 3.3, XPBD compliance), lambda restarts at 0
+struct JointArrays {
+    const uint2* bodies;    // (a, b), SFX_WORLD_BODY for the world
+    const float4* anchors;  // (a.x, a.y, b.x, b.y)
+    const float2* params;   // (rest_length, compliance)
+};
+
+__device__ __forceinline__ void apply_pos(float4& pose, const float2& w, float rx, float ry, float px, float py, float sign) {
+    if (w.x > 0.0f) {
+        pose.x = pose.x + sign * (px * w.x);
+        pose.y = pose.y + sign * (py * w.x);
+    }
+    if (w.y > 0.0f) {
+        float dth = sign * (w.y * (rx * py - ry * px));
+        rotate_by(pose.z, pose.w, dth);
+    }
+}
+
+__device__ __forceinline__ float gen_inv_mass(const float2& w, float rx, float ry, float nx, float ny) {
+    float rn = rx * ny - ry * nx;
+    return w.x + w.y * (rn * rn);
+}
+
+__device__ __forceinline__ void solve_joint(const BodyArrays& B, const JointArrays& J, uint32_t k, float inv_h2) {
+    const uint2 ab = J.bodies[k];
+    const float4 an = J.anchors[k];
+    const float2 pr = J.params[k];
+    const uint32_t a = ab.x, b = ab.y;
+    float rax = 0.0f, ray = 0.0f, rbx = 0.0f, rby = 0.0f, pax, pay, pbx, pby;
+    float4 pa = make_float4(0, 0, 1, 0), pb = make_float4(0, 0, 1, 0);
+    float2 wa = make_float2(0, 0), wb = make_float2(0, 0);
+    if (a != SFX_WORLD_BODY) {
+        pa = B.pose[a]; wa = B.mass[a];
+        anchor_world(pa, an.x, an.y, rax, ray);
+        pax = pa.x + rax; pay = pa.y + ray;
+    } else { pax = an.x; pay = an.y; }
+    if (b != SFX_WORLD_BODY) {
+        pb = B.pose[b]; wb = B.mass[b];
+        anchor_world(pb, an.z, an.w, rbx, rby);
+        pbx = pb.x + rbx; pby = pb.y + rby;
+    } else { pbx = an.z; pby = an.w; }
+    float dx = pbx - pax, dy = pby - pay;
+    float len = sqrtf(dx * dx + dy * dy);
+    if (!(len > SFX_EPS_LEN)) return;
+    float nx = dx / len, ny = dy / len;
+    float Cc = len - pr.x;
+    float wsum = pr.y * inv_h2;
+    if (a != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(wa, rax, ray, nx, ny);
+    if (b != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(wb, rbx, rby, nx, ny);
+    if (!(wsum > 0.0f)) return;
+    float corr = Cc / wsum;
+    if (a != SFX_WORLD_BODY && (wa.x > 0.0f || wa.y > 0.0f)) {
+        apply_pos(pa, wa, rax, ray, nx * corr, ny * corr, 1.0f);
+        B.pose[a] = pa;
+    }
+    if (b != SFX_WORLD_BODY && (wb.x > 0.0f || wb.y > 0.0f)) {
+        apply_pos(pb, wb, rbx, rby, nx * corr, ny * corr, -1.0f);
+        B.pose[b] = pb;
+    }
+}
+
+}  // namespace sfx

@@ -1,0 +1,910 @@
+// sfx_host.hip -- host runtime of libsfx: the C ABI of include/sfx.h over the gfx950 kernels.
+//
+// One world = one HIP device, one stream.  Every buffer is allocated at upload time; the
+// tick itself (sfx_step) only enqueues kernels and memsets on the world's stream and never
+// allocates, synchronises or copies to the host.  There is no CPU path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "sfx_kernels.h"
+
+using namespace sfx;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Event2 { hipEvent_t a, b; int cls; uint64_t items; };
+
+template <class T>
+struct DevBuf {
+    T* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) count = 1;
+        return hipMalloc(reinterpret_cast<void**>(&p), count * sizeof(T)) == hipSuccess ? 0 : -1;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; n = 0;
+    }
+};
+
+}  // namespace
+
+struct sfx_world {
+    sfx_config cfg{};
+    std::string err;
+    hipStream_t stream = nullptr;
+    int device = 0;
+    // resolved
+    float cell = 1.0f, inv_cell = 1.0f;
+    uint32_t gxl = 2, gyl = 2, ncell = 16, max_pairs = 0;
+    // scene
+    uint32_t n = 0, m = 0, n_mats = 0, n_poly = 0;
+    bool have_bodies = false, have_colliders = false, have_mats = false;
+    std::vector<float> h_inv_mass, h_inv_inertia;
+    std::vector<sfx_collider> h_col;
+    std::vector<float> h_poly;
+    DevBuf<float4> pose, prev, vel, shape, poly, mats, aabb, sorted_aabb;
+    DevBuf<float2> mass;
+    DevBuf<uint4> filt;
+    // broadphase
+    DevBuf<uint32_t> bucket, cell_start, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, scan_sums;
+    DevBuf<int2> cellxy, sorted_cell;
+    DevBuf<uint2> pairs, cpairs;
+    uint32_t large_cap = 0;
+    // colouring
+    DevBuf<unsigned long long> used, claim;
+    DevBuf<uint32_t> deg, left_list;
+    DevBuf<uint8_t> pcolor, prop;
+    DevBuf<Counters> ctr, jctr;
+    // contact records
+    DevBuf<float4> c_hdr, c_anc0, c_anc1, c_lamv;
+    DevBuf<float2> c_misc;
+    // joints (colour-sorted)
+    DevBuf<uint2> j_bodies;
+    DevBuf<float4> j_anchors;
+    DevBuf<float2> j_params;
+    DevBuf<uint32_t> j_count_dev;
+    std::vector<uint32_t> joint_perm;
+    std::vector<uint8_t> joint_color_sorted;
+    std::vector<uint32_t> joint_color_start;  // n_joint_colors + 1
+    // async counter read-back (stale by one tick, never waited for inside sfx_step)
+    Counters* h_ctr = nullptr;       // pinned
+    hipEvent_t ev_ctr = nullptr;
+    bool ctr_pending = false, ctr_valid = false;
+    Counters stale{};
+    uint32_t launches = 0;
+    bool ticked = false;
+    // profiling
+    bool profiling = false;
+    std::vector<Event2> ev_used;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    sfx_kernel_time ktime[SFX_K_CLASSES]{};
+    hipEvent_t t_begin = nullptr, t_end = nullptr;
+};
+
+namespace {
+
+int fail(sfx_world* w, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (w) w->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(w, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(w, SFX_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define ALLOC(w, buf, count)                                                             \
+    do {                                                                                 \
+        if ((buf).alloc(count) != 0)                                                     \
+            return fail(w, SFX_ERR_NOMEM, "hipMalloc of %zu bytes failed for " #buf,     \
+                        (size_t)(count) * sizeof(*(buf).p));                             \
+    } while (0)
+
+void resolve_defaults(sfx_config& c) {
+    if (c.substeps == 0) c.substeps = 1;
+    if (c.color_rounds == 0) c.color_rounds = 12;
+    if (c.color_rounds > 60) c.color_rounds = 60;
+    if (c.launch_colors == 0) c.launch_colors = 16;
+    if (c.launch_colors > SFX_MAX_COLORS) c.launch_colors = SFX_MAX_COLORS;
+    if (c.restitution_threshold == 0.0f) c.restitution_threshold = 2.0f;
+}
+
+inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+uint32_t ceil_log2(uint32_t v) {
+    uint32_t l = 0;
+    while ((1u << l) < v && l < 31) ++l;
+    return l;
+}
+
+float shape_diameter(const sfx_world* w, const sfx_collider& c) {
+    switch (c.type) {
+    case SFX_SHAPE_CIRCLE: return 2.0f * c.p[2];
+    case SFX_SHAPE_RECT: return 2.0f * (sqrtf(c.p[0] * c.p[0] + c.p[1] * c.p[1]) + c.p[2]);
+    case SFX_SHAPE_CAPSULE: return 2.0f * (c.p[0] + c.p[2]);
+    case SFX_SHAPE_POLY: {
+        float mx = 0.0f;
+        for (uint32_t k = 0; k < c.poly_count; ++k) {
+            float x = w->h_poly[2 * (c.poly_offset + k)], y = w->h_poly[2 * (c.poly_offset + k) + 1];
+            float d = sqrtf(x * x + y * y);
+            if (d > mx) mx = d;
+        }
+        return 2.0f * (mx + c.p[2]);
+    }
+    default: return 0.0f;
+    }
+}
+
+bool is_dynamic(const sfx_world* w, uint32_t i) { return w->h_inv_mass[i] > 0.0f || w->h_inv_inertia[i] > 0.0f; }
+
+// DESIGN.md "Contract / grid": identical rule in oracle/sfx_oracle.c
+void resolve_grid(sfx_world* w) {
+    float cell = w->cfg.cell_size;
+    if (!(cell > 0.0f)) {
+        float dmax = 0.0f;
+        for (uint32_t i = 0; i < w->n; ++i) {
+            if (!is_dynamic(w, i) || w->h_col[i].type == SFX_SHAPE_NONE) continue;
+            float d = shape_diameter(w, w->h_col[i]);
+            if (d > dmax) dmax = d;
+        }
+        cell = dmax > 0.0f ? 1.25f * (dmax + 2.0f * w->cfg.aabb_margin) : 1.0f;
+    }
+    w->cell = cell;
+    w->inv_cell = 1.0f / cell;
+    uint32_t gx = w->cfg.grid_log2[0], gy = w->cfg.grid_log2[1];
+    if (gx == 0 || gy == 0) {
+        uint32_t side = (uint32_t)std::ceil(std::sqrt(2.0 * (double)(w->n ? w->n : 1)));
+        uint32_t l = ceil_log2(side);
+        if (l < 2) l = 2;
+        if (l > 12) l = 12;
+        gx = gy = l;
+    }
+    gx = std::min(std::max(gx, 2u), 12u);
+    gy = std::min(std::max(gy, 2u), 12u);
+    w->gxl = gx; w->gyl = gy;
+    w->ncell = (1u << gx) * (1u << gy);
+}
+
+GridParams grid_params(const sfx_world* w) {
+    GridParams g;
+    g.inv_cell = w->inv_cell;
+    g.small_lim = 0.9f * w->cell;
+    g.gxl = w->gxl; g.gyl = w->gyl; g.ncell = w->ncell;
+    return g;
+}
+
+// ---- launch bookkeeping -------------------------------------------------------------
+struct Prof {
+    sfx_world* w;
+    int cls;
+    bool on;
+    size_t idx = 0;
+    Prof(sfx_world* w_, int cls_, uint64_t items) : w(w_), cls(cls_), on(w_->profiling) {
+        w->launches++;
+        if (!on) return;
+        if (w->ev_pool.empty()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+            w->ev_pool.emplace_back(a, b);
+        }
+        auto pr = w->ev_pool.back();
+        w->ev_pool.pop_back();
+        w->ev_used.push_back({pr.first, pr.second, cls, items});
+        idx = w->ev_used.size() - 1;
+        (void)hipEventRecord(pr.first, w->stream);
+    }
+    ~Prof() {
+        if (on) (void)hipEventRecord(w->ev_used[idx].b, w->stream);
+    }
+};
+
+int collect_profile(sfx_world* w) {
+    if (w->ev_used.empty()) return SFX_OK;
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    for (auto& e : w->ev_used) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+            w->ktime[e.cls].total_ms += ms;
+            w->ktime[e.cls].launches += 1;
+            w->ktime[e.cls].items += e.items;
+        }
+        w->ev_pool.emplace_back(e.a, e.b);
+    }
+    w->ev_used.clear();
+    return SFX_OK;
+}
+
+BodyArrays body_arrays(sfx_world* w) {
+    BodyArrays B;
+    B.pose = w->pose.p; B.prev = w->prev.p; B.vel = w->vel.p; B.mass = w->mass.p;
+    B.shape = w->shape.p; B.filt = w->filt.p; B.poly = w->poly.p; B.mats = w->mats.p;
+    return B;
+}
+
+ContactArrays contact_arrays(sfx_world* w) {
+    ContactArrays C;
+    C.hdr = w->c_hdr.p; C.misc = w->c_misc.p; C.anc0 = w->c_anc0.p; C.anc1 = w->c_anc1.p; C.lamv = w->c_lamv.p;
+    return C;
+}
+
+// exclusive scan of data[0..count) in place (count <= 4096 * 4096); copy receives the result too
+int scan_u32(sfx_world* w, uint32_t* data, uint32_t count, uint32_t* copy) {
+    const uint32_t nb = cdiv(count, kScanTile);
+    if (nb > 4096) return fail(w, SFX_ERR_UNSUPPORTED, "scan of %u items exceeds 16M", count);
+    if (nb <= 1) {
+        Prof p(w, SFX_K_SCAN, count);
+        hipLaunchKernelGGL(k_scan_local, dim3(1), dim3(kBlock), 0, w->stream, data, count, w->scan_sums.p, copy, 1);
+    } else {
+        { Prof p(w, SFX_K_SCAN, count);
+          hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kBlock), 0, w->stream, data, count, w->scan_sums.p, (uint32_t*)nullptr, 0); }
+        { Prof p(w, SFX_K_SCAN, nb);
+          hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, w->stream, w->scan_sums.p, nb); }
+        { Prof p(w, SFX_K_SCAN, count);
+          hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kBlock), 0, w->stream, data, count, w->scan_sums.p, copy); }
+    }
+    return SFX_OK;
+}
+
+uint32_t edge_grid(uint32_t cap) { return std::min(std::max(cdiv(cap, kBlock), 1u), 2048u); }
+
+// colour ne edges (device count at n_edges) of `pairs`; result in w->pcolor, counters in ctr
+int color_graph(sfx_world* w, const uint2* pairs, const uint32_t* n_edges, uint32_t cap, Counters* ctr) {
+    const uint32_t n = w->n;
+    HIPCHK(w, hipMemsetAsync(w->used.p, 0, sizeof(unsigned long long) * std::max(n, 1u), w->stream));
+    HIPCHK(w, hipMemsetAsync(w->deg.p, 0, sizeof(uint32_t) * std::max(n, 1u), w->stream));
+    HIPCHK(w, hipMemsetAsync(w->claim.p, 0xFF, sizeof(unsigned long long) * 8 * std::max(n, 1u), w->stream));
+    w->launches += 3;
+    ColorArrays A;
+    A.pairs = pairs; A.filt = w->filt.p; A.used = w->used.p; A.deg = w->deg.p; A.claim = w->claim.p;
+    A.color = w->pcolor.p; A.prop = w->prop.p; A.left_list = w->left_list.p; A.n_edges = n_edges; A.ctr = ctr;
+    const uint32_t grid = edge_grid(cap);
+    { Prof p(w, SFX_K_COLOR, cap);
+      hipLaunchKernelGGL(k_color_init, dim3(grid), dim3(kBlock), 0, w->stream, A); }
+    const uint32_t R = w->cfg.color_rounds;
+    for (uint32_t r = 0; r < R; ++r) {
+        { Prof p(w, SFX_K_COLOR, cap);
+          hipLaunchKernelGGL(k_color_propose, dim3(grid), dim3(kBlock), 0, w->stream, A, r); }
+        { Prof p(w, SFX_K_COLOR, cap);
+          hipLaunchKernelGGL(k_color_resolve, dim3(grid), dim3(kBlock), 0, w->stream, A, r, r + 1 == R ? 1 : 0); }
+    }
+    { Prof p(w, SFX_K_COLOR, 1);
+      hipLaunchKernelGGL(k_color_finish, dim3(1), dim3(kBlock), 0, w->stream, A); }
+    { Prof p(w, SFX_K_COLOR_SORT, cap);
+      hipLaunchKernelGGL(k_color_hist, dim3(grid), dim3(kBlock), 0, w->stream, A); }
+    { Prof p(w, SFX_K_COLOR_SORT, 64);
+      hipLaunchKernelGGL(k_color_scan, dim3(1), dim3(64), 0, w->stream, ctr); }
+    return SFX_OK;
+}
+
+int zero_tick_counters(sfx_world* w, Counters* ctr) {
+    HIPCHK(w, hipMemsetAsync(ctr, 0, sizeof(Counters), w->stream));
+    w->launches++;
+    return SFX_OK;
+}
+
+int broadphase(sfx_world* w, float dt) {
+    const uint32_t n = w->n;
+    const GridParams g = grid_params(w);
+    int rc = zero_tick_counters(w, w->ctr.p);
+    if (rc) return rc;
+    HIPCHK(w, hipMemsetAsync(w->cell_start.p, 0, sizeof(uint32_t) * (w->ncell + 1), w->stream));
+    w->launches++;
+    const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
+    { Prof p(w, SFX_K_AABB_COUNT, n);
+      hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p,
+                         w->poly.p, w->cfg.aabb_margin, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start.p,
+                         w->large_tmp.p, w->large_cap, w->ctr.p); }
+    rc = scan_u32(w, w->cell_start.p, w->ncell + 1, w->cell_fill.p);
+    if (rc) return rc;
+    { Prof p(w, SFX_K_SCATTER, n);
+      hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(kBlock), 0, w->stream, n, w->bucket.p, w->cell_fill.p, w->tmp_id.p); }
+    { Prof p(w, SFX_K_SCATTER, n);
+      hipLaunchKernelGGL(k_finalize_slots, dim3(gb), dim3(kBlock), 0, w->stream, n, g, w->cell_start.p, w->tmp_id.p,
+                         w->bucket.p, w->aabb.p, w->cellxy.p, w->large_tmp.p, w->large_cap, w->sorted_id.p,
+                         w->sorted_aabb.p, w->sorted_cell.p, w->ctr.p); }
+    // one 8-lane group per slot: (n + 1) slots / 32 per block
+    const uint32_t gp = std::min(std::max(cdiv(n + 1, kBlock / kGroup), 1u), 8192u);
+    { Prof p(w, SFX_K_PAIR_COUNT, n);
+      hipLaunchKernelGGL(k_pairs<false>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start.p, w->sorted_id.p,
+                         w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, w->slot_cnt.p, w->pairs.p, w->max_pairs,
+                         w->ctr.p, w->large_cap); }
+    rc = scan_u32(w, w->slot_cnt.p, n + 1, nullptr);
+    if (rc) return rc;
+    { Prof p(w, SFX_K_PAIR_FILL, n);
+      hipLaunchKernelGGL(k_pairs<true>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start.p, w->sorted_id.p,
+                         w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, w->slot_cnt.p, w->pairs.p, w->max_pairs,
+                         w->ctr.p, w->large_cap); }
+    { Prof p(w, SFX_K_PAIR_FILL, 1);
+      hipLaunchKernelGGL(k_pairs_finish, dim3(1), dim3(64), 0, w->stream, n, w->slot_cnt.p, w->max_pairs, w->ctr.p); }
+    rc = color_graph(w, w->pairs.p, &w->ctr.p->n_pairs, w->max_pairs, w->ctr.p);
+    if (rc) return rc;
+    {
+        ColorArrays A;
+        A.pairs = w->pairs.p; A.filt = w->filt.p; A.used = w->used.p; A.deg = w->deg.p; A.claim = w->claim.p;
+        A.color = w->pcolor.p; A.prop = w->prop.p; A.left_list = w->left_list.p; A.n_edges = &w->ctr.p->n_pairs;
+        A.ctr = w->ctr.p;
+        Prof p(w, SFX_K_COLOR_SORT, w->max_pairs);
+        hipLaunchKernelGGL(k_color_scatter, dim3(edge_grid(w->max_pairs)), dim3(kBlock), 0, w->stream, A, w->cpairs.p);
+    }
+    HIPCHK(w, hipGetLastError());
+    return SFX_OK;
+}
+
+// poll the async counter copy of an earlier tick (never blocks)
+void poll_counters(sfx_world* w) {
+    if (w->ctr_pending && hipEventQuery(w->ev_ctr) == hipSuccess) {
+        w->stale = *w->h_ctr;
+        w->ctr_valid = true;
+        w->ctr_pending = false;
+    }
+}
+
+int ready(sfx_world* w) {
+    if (!w) return SFX_ERR_INVALID;
+    if (!w->have_bodies || !w->have_colliders || !w->have_mats)
+        return fail(w, SFX_ERR_INVALID, "bodies, colliders and materials must be uploaded before this call");
+    return SFX_OK;
+}
+
+int sync_counters(sfx_world* w, Counters* out, const Counters* dev) {
+    HIPCHK(w, hipMemcpyAsync(out, dev, sizeof(Counters), hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return SFX_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+uint32_t sfx_abi_version(void) { return SFX_ABI_VERSION; }
+
+void sfx_default_config(sfx_config* cfg) {
+    if (!cfg) return;
+    memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = sizeof(sfx_config);
+    cfg->substeps = 4;
+    cfg->gravity[0] = 0.0f; cfg->gravity[1] = -9.81f;
+    cfg->aabb_margin = 0.01f;
+    resolve_defaults(*cfg);
+}
+
+int sfx_create(const sfx_config* cfg, sfx_world** out) {
+    if (!cfg || !out) return fail(nullptr, SFX_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(sfx_config))
+        return fail(nullptr, SFX_ERR_INVALID, "sfx_config.struct_size %u != %zu", cfg->struct_size, sizeof(sfx_config));
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SFX_ERR_DEVICE, "no HIP device available (%s); libsfx has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, SFX_ERR_INVALID, "device %d out of range (%d devices)", cfg->device, ndev);
+    sfx_world* w = new (std::nothrow) sfx_world();
+    if (!w) return fail(nullptr, SFX_ERR_NOMEM, "out of host memory");
+    w->cfg = *cfg;
+    resolve_defaults(w->cfg);
+    w->device = cfg->device;
+    if ((e = hipSetDevice(w->device)) != hipSuccess || (e = hipStreamCreate(&w->stream)) != hipSuccess ||
+        (e = hipEventCreate(&w->ev_ctr)) != hipSuccess || (e = hipEventCreate(&w->t_begin)) != hipSuccess ||
+        (e = hipEventCreate(&w->t_end)) != hipSuccess ||
+        (e = hipHostMalloc(reinterpret_cast<void**>(&w->h_ctr), sizeof(Counters))) != hipSuccess) {
+        fail(nullptr, SFX_ERR_DEVICE, "device set-up failed: %s", hipGetErrorString(e));
+        sfx_destroy(w);
+        return SFX_ERR_DEVICE;
+    }
+    if (w->ctr.alloc(1) || w->jctr.alloc(1) || w->scan_sums.alloc(4096) || w->left_list.alloc(kLeftCap) ||
+        w->j_count_dev.alloc(1)) {
+        fail(nullptr, SFX_ERR_NOMEM, "hipMalloc failed");
+        sfx_destroy(w);
+        return SFX_ERR_NOMEM;
+    }
+    *out = w;
+    return SFX_OK;
+}
+
+void sfx_destroy(sfx_world* w) {
+    if (!w) return;
+    (void)hipSetDevice(w->device);
+    if (w->stream) (void)hipStreamSynchronize(w->stream);
+    for (auto& e : w->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : w->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    w->pose.release(); w->prev.release(); w->vel.release(); w->shape.release(); w->poly.release();
+    w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release();
+    w->bucket.release(); w->cell_start.release(); w->cell_fill.release(); w->tmp_id.release();
+    w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->scan_sums.release();
+    w->cellxy.release(); w->sorted_cell.release(); w->pairs.release(); w->cpairs.release();
+    w->used.release(); w->claim.release(); w->deg.release(); w->left_list.release();
+    w->pcolor.release(); w->prop.release(); w->ctr.release(); w->jctr.release();
+    w->c_hdr.release(); w->c_anc0.release(); w->c_anc1.release(); w->c_lamv.release(); w->c_misc.release();
+    w->j_bodies.release(); w->j_anchors.release(); w->j_params.release(); w->j_count_dev.release();
+    if (w->h_ctr) (void)hipHostFree(w->h_ctr);
+    if (w->ev_ctr) (void)hipEventDestroy(w->ev_ctr);
+    if (w->t_begin) (void)hipEventDestroy(w->t_begin);
+    if (w->t_end) (void)hipEventDestroy(w->t_end);
+    if (w->stream) (void)hipStreamDestroy(w->stream);
+    delete w;
+}
+
+const char* sfx_last_error(sfx_world* w) { return w ? w->err.c_str() : g_create_error.c_str(); }
+
+static int rebuild_filt(sfx_world* w) {
+    if (!w->have_bodies) return SFX_OK;
+    std::vector<uint4> f(std::max(w->n, 1u));
+    for (uint32_t i = 0; i < w->n; ++i) {
+        uint4 v = make_uint4(0, 0, 0, is_dynamic(w, i) ? 1u : 0u);
+        if (w->have_colliders) { v.x = w->h_col[i].category; v.y = w->h_col[i].mask; v.z = w->h_col[i].group; }
+        f[i] = v;
+    }
+    HIPCHK(w, hipMemcpyAsync(w->filt.p, f.data(), sizeof(uint4) * w->n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return SFX_OK;
+}
+
+int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* rot, const float* vel,
+                      const float* angvel, const float* inv_mass, const float* inv_inertia) {
+    if (!w) return SFX_ERR_INVALID;
+    if (n && (!pos || !rot || !vel || !angvel || !inv_mass || !inv_inertia)) return fail(w, SFX_ERR_INVALID, "null array");
+    if (n > (1u << 24)) return fail(w, SFX_ERR_UNSUPPORTED, "more than 16M bodies per world");
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    const bool resize = !w->have_bodies || n != w->n;
+    if (resize) {
+        w->n = n;
+        w->have_colliders = false;
+        w->m = 0;
+        w->joint_perm.clear(); w->joint_color_sorted.clear(); w->joint_color_start.assign(1, 0);
+        const size_t c = std::max(n, 1u);
+        ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
+        ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
+        ALLOC(w, w->bucket, c); ALLOC(w, w->tmp_id, c); ALLOC(w, w->sorted_id, c); ALLOC(w, w->large_tmp, c);
+        ALLOC(w, w->slot_cnt, (size_t)n + 1 + kScanItems); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
+        ALLOC(w, w->used, c); ALLOC(w, w->deg, c); ALLOC(w, w->claim, c * 8);
+        w->large_cap = n;
+    }
+    std::vector<float4> hp(std::max(n, 1u)), hv(std::max(n, 1u));
+    std::vector<float2> hm(std::max(n, 1u));
+    w->h_inv_mass.assign(inv_mass, inv_mass + n);
+    w->h_inv_inertia.assign(inv_inertia, inv_inertia + n);
+    for (uint32_t i = 0; i < n; ++i) {
+        hp[i] = make_float4(pos[2 * i], pos[2 * i + 1], rot[2 * i], rot[2 * i + 1]);
+        hv[i] = make_float4(vel[2 * i], vel[2 * i + 1], angvel[i], 0.0f);
+        hm[i] = make_float2(inv_mass[i], inv_inertia[i]);
+    }
+    HIPCHK(w, hipMemcpyAsync(w->pose.p, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipMemcpyAsync(w->prev.p, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipMemcpyAsync(w->vel.p, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipMemcpyAsync(w->mass.p, hm.data(), sizeof(float2) * n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->have_bodies = true;
+    w->ticked = false;
+    return rebuild_filt(w);
+}
+
+int sfx_upload_materials(sfx_world* w, uint32_t n, const sfx_material* materials) {
+    if (!w || (n && !materials)) return fail(w, SFX_ERR_INVALID, "null argument");
+    if (n == 0 || n > (1u << 24)) return fail(w, SFX_ERR_INVALID, "material count %u out of range", n);
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    std::vector<float4> hm(n);
+    for (uint32_t i = 0; i < n; ++i)
+        hm[i] = make_float4(materials[i].restitution, materials[i].static_friction, materials[i].dynamic_friction, 0.0f);
+    ALLOC(w, w->mats, n);
+    HIPCHK(w, hipMemcpy(w->mats.p, hm.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    w->n_mats = n;
+    w->have_mats = true;
+    return SFX_OK;
+}
+
+int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, const float* poly_verts,
+                         uint32_t n_poly_verts) {
+    if (!w || (n && !col)) return fail(w, SFX_ERR_INVALID, "null argument");
+    if (!w->have_bodies) return fail(w, SFX_ERR_INVALID, "upload bodies before colliders");
+    if (n != w->n) return fail(w, SFX_ERR_UNSUPPORTED, "collider count %u != body count %u (one collider per body)", n, w->n);
+    if (n_poly_verts && !poly_verts) return fail(w, SFX_ERR_INVALID, "null vertex pool");
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->h_col.assign(col, col + n);
+    w->h_poly.assign(poly_verts, poly_verts + 2 * (size_t)n_poly_verts);
+    w->n_poly = n_poly_verts;
+    std::vector<float4> hpoly(std::max(n_poly_verts, 1u), make_float4(0, 0, 0, 0));
+    std::vector<float4> hs(std::max(n, 1u));
+    for (uint32_t i = 0; i < n; ++i) {
+        const sfx_collider& c = col[i];
+        if (c.type > SFX_SHAPE_POLY) return fail(w, SFX_ERR_INVALID, "collider %u: unknown shape type %u", i, c.type);
+        if (c.type != SFX_SHAPE_NONE && w->have_mats && c.material >= w->n_mats)
+            return fail(w, SFX_ERR_INVALID, "collider %u: material %u out of range", i, c.material);
+        if (c.material >= (1u << 24)) return fail(w, SFX_ERR_INVALID, "collider %u: material index too large", i);
+        const uint32_t bits = c.type | (c.material << 8);
+        float4 s = make_float4(0, c.p[0], c.p[1], c.p[2]);
+        memcpy(&s.x, &bits, 4);
+        if (c.type == SFX_SHAPE_POLY) {
+            if (c.poly_count < 3 || c.poly_count > SFX_MAX_POLY_VERTS || (uint64_t)c.poly_offset + c.poly_count > n_poly_verts)
+                return fail(w, SFX_ERR_INVALID, "collider %u: bad polygon range", i);
+            memcpy(&s.y, &c.poly_offset, 4);
+            memcpy(&s.z, &c.poly_count, 4);
+            for (uint32_t k = 0; k < c.poly_count; ++k) {
+                const uint32_t k0 = c.poly_offset + k, k1 = c.poly_offset + (k + 1) % c.poly_count;
+                const float ex = poly_verts[2 * k1] - poly_verts[2 * k0], ey = poly_verts[2 * k1 + 1] - poly_verts[2 * k0 + 1];
+                const float len = sqrtf(ex * ex + ey * ey);
+                hpoly[k0] = make_float4(poly_verts[2 * k0], poly_verts[2 * k0 + 1], ey / len, -ex / len);
+            }
+        }
+        hs[i] = s;
+    }
+    ALLOC(w, w->poly, hpoly.size());
+    HIPCHK(w, hipMemcpy(w->poly.p, hpoly.data(), sizeof(float4) * hpoly.size(), hipMemcpyHostToDevice));
+    HIPCHK(w, hipMemcpy(w->shape.p, hs.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    w->have_colliders = true;
+    resolve_grid(w);
+    w->max_pairs = w->cfg.max_pairs ? w->cfg.max_pairs : 12u * n;
+    if (w->max_pairs < 1024u) w->max_pairs = 1024u;
+    const size_t mp = std::max<size_t>(w->max_pairs, w->m) + kScanItems;
+    ALLOC(w, w->cell_start, (size_t)w->ncell + 1 + kScanItems); ALLOC(w, w->cell_fill, (size_t)w->ncell + 1 + kScanItems);
+    ALLOC(w, w->pairs, mp); ALLOC(w, w->cpairs, mp); ALLOC(w, w->pcolor, mp); ALLOC(w, w->prop, mp);
+    ALLOC(w, w->c_hdr, mp); ALLOC(w, w->c_misc, mp); ALLOC(w, w->c_anc0, mp); ALLOC(w, w->c_anc1, mp); ALLOC(w, w->c_lamv, mp);
+    HIPCHK(w, hipMemset(w->c_misc.p, 0, sizeof(float2) * mp));
+    HIPCHK(w, hipMemset(w->ctr.p, 0, sizeof(Counters)));
+    w->ticked = false;
+    return rebuild_filt(w);
+}
+
+int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constraint* c) {
+    if (!w || (m && !c)) return fail(w, SFX_ERR_INVALID, "null argument");
+    if (!w->have_bodies) return fail(w, SFX_ERR_INVALID, "upload bodies before constraints");
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    for (uint32_t k = 0; k < m; ++k)
+        if ((c[k].body_a != SFX_WORLD_BODY && c[k].body_a >= w->n) || (c[k].body_b != SFX_WORLD_BODY && c[k].body_b >= w->n))
+            return fail(w, SFX_ERR_INVALID, "constraint %u: body index out of range", k);
+    w->m = m;
+    w->joint_perm.assign(m, 0);
+    w->joint_color_sorted.assign(m, 0);
+    w->joint_color_start.assign(1, 0);
+    if (m == 0) return SFX_OK;
+    // colour the joint graph once, on the device, with the same kernels as the contact graph
+    std::vector<uint2> ab(m);
+    for (uint32_t k = 0; k < m; ++k) ab[k] = make_uint2(c[k].body_a, c[k].body_b);
+    DevBuf<uint2> d_ab;
+    DevBuf<uint8_t> color_save, prop_save;
+    ALLOC(w, d_ab, m);
+    // colour/prop scratch must hold m entries even before colliders are uploaded
+    const bool own_scratch = w->pcolor.n < m;
+    if (own_scratch) { ALLOC(w, color_save, m); ALLOC(w, prop_save, m); std::swap(color_save.p, w->pcolor.p); std::swap(prop_save.p, w->prop.p); }
+    HIPCHK(w, hipMemcpy(d_ab.p, ab.data(), sizeof(uint2) * m, hipMemcpyHostToDevice));
+    HIPCHK(w, hipMemcpy(w->j_count_dev.p, &m, sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(w, hipMemsetAsync(w->jctr.p, 0, sizeof(Counters), w->stream));
+    int rc = color_graph(w, d_ab.p, w->j_count_dev.p, m, w->jctr.p);
+    std::vector<uint8_t> colors(m);
+    Counters jc{};
+    if (rc == SFX_OK) {
+        hipError_t e = hipMemcpyAsync(colors.data(), w->pcolor.p, m, hipMemcpyDeviceToHost, w->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&jc, w->jctr.p, sizeof(Counters), hipMemcpyDeviceToHost, w->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+        if (e != hipSuccess) rc = fail(w, SFX_ERR_DEVICE, "joint colouring failed: %s", hipGetErrorString(e));
+    }
+    if (own_scratch) { std::swap(color_save.p, w->pcolor.p); std::swap(prop_save.p, w->prop.p); }
+    d_ab.release(); color_save.release(); prop_save.release();
+    if (rc) return rc;
+    if (jc.overflow) return fail(w, SFX_ERR_CAPACITY, "joint graph needs more than %u colours or %u serial edges", SFX_MAX_COLORS, kLeftCap);
+    const uint32_t nc = jc.n_colors;
+    w->joint_color_start.assign(nc + 1, 0);
+    for (uint32_t k = 0; k < m; ++k) w->joint_color_start[colors[k] + 1]++;
+    for (uint32_t q = 0; q < nc; ++q) w->joint_color_start[q + 1] += w->joint_color_start[q];
+    std::vector<uint32_t> fill(w->joint_color_start.begin(), w->joint_color_start.end() - 1);
+    for (uint32_t k = 0; k < m; ++k) {
+        const uint32_t dst = fill[colors[k]]++;
+        w->joint_perm[dst] = k;
+        w->joint_color_sorted[dst] = colors[k];
+    }
+    std::vector<uint2> hb(m);
+    std::vector<float4> ha(m);
+    std::vector<float2> hp(m);
+    for (uint32_t d = 0; d < m; ++d) {
+        const sfx_distance_constraint& j = c[w->joint_perm[d]];
+        hb[d] = make_uint2(j.body_a, j.body_b);
+        ha[d] = make_float4(j.anchor_a[0], j.anchor_a[1], j.anchor_b[0], j.anchor_b[1]);
+        hp[d] = make_float2(j.rest_length, j.compliance);
+    }
+    ALLOC(w, w->j_bodies, m); ALLOC(w, w->j_anchors, m); ALLOC(w, w->j_params, m);
+    HIPCHK(w, hipMemcpy(w->j_bodies.p, hb.data(), sizeof(uint2) * m, hipMemcpyHostToDevice));
+    HIPCHK(w, hipMemcpy(w->j_anchors.p, ha.data(), sizeof(float4) * m, hipMemcpyHostToDevice));
+    HIPCHK(w, hipMemcpy(w->j_params.p, hp.data(), sizeof(float2) * m, hipMemcpyHostToDevice));
+    return SFX_OK;
+}
+
+int sfx_debug_broadphase(sfx_world* w, float frame_dt) {
+    int rc = ready(w);
+    if (rc) return rc;
+    HIPCHK(w, hipSetDevice(w->device));
+    w->launches = 0;
+    rc = broadphase(w, frame_dt);
+    if (rc) return rc;
+    w->ticked = true;
+    return SFX_OK;
+}
+
+int sfx_step(sfx_world* w, float frame_dt) {
+    int rc = ready(w);
+    if (rc) return rc;
+    if (!(frame_dt > 0.0f)) return fail(w, SFX_ERR_INVALID, "frame_dt must be positive");
+    HIPCHK(w, hipSetDevice(w->device));
+    poll_counters(w);
+    w->launches = 0;
+    rc = broadphase(w, frame_dt);
+    if (rc) return rc;
+    const uint32_t n = w->n;
+    StepParams sp;
+    sp.h = frame_dt / (float)w->cfg.substeps;
+    sp.inv_h = 1.0f / sp.h;
+    sp.inv_h2 = sp.inv_h * sp.inv_h;
+    sp.gx = w->cfg.gravity[0]; sp.gy = w->cfg.gravity[1];
+    const float gl = sqrtf(sp.gx * sp.gx + sp.gy * sp.gy);
+    sp.vthr = w->cfg.restitution_threshold * gl * sp.h;
+    sp.flags = w->cfg.flags;
+    const BodyArrays B = body_arrays(w);
+    const ContactArrays C = contact_arrays(w);
+    JointArrays J;
+    J.bodies = w->j_bodies.p; J.anchors = w->j_anchors.p; J.params = w->j_params.p;
+    // colours that get their own launch: all that held >= 1024 pairs one tick ago (stale
+    // counters, read back asynchronously); the rest share the single-workgroup tail kernel
+    uint32_t K = w->cfg.launch_colors;
+    uint32_t solve_grid = std::min(std::max(cdiv(std::max(n, 1u), kBlock), 1u), 2048u);
+    if (w->ctr_valid) {
+        uint32_t k = 0, biggest = 0;
+        while (k < w->stale.n_colors && k < K && w->stale.color_count[k] >= 1024u) ++k;
+        K = std::max(k, 1u);
+        for (uint32_t c2 = 0; c2 < SFX_MAX_COLORS; ++c2) biggest = std::max(biggest, w->stale.color_count[c2]);
+        solve_grid = std::min(std::max(cdiv(biggest + biggest / 4 + 256, kBlock), 1u), 2048u);
+    }
+    const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
+    const uint32_t njc = (uint32_t)w->joint_color_start.size() - 1;
+    for (uint32_t s = 0; s < w->cfg.substeps; ++s) {
+        { Prof p(w, SFX_K_INTEGRATE, n);
+          hipLaunchKernelGGL(k_integrate, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
+        for (uint32_t jc = 0; jc < njc; ++jc) {
+            const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
+            if (!cnt) continue;
+            Prof p(w, SFX_K_SOLVE_JOINTS, cnt);
+            hipLaunchKernelGGL(k_solve_joints, dim3(cdiv(cnt, kBlock)), dim3(kBlock), 0, w->stream, start, cnt, B, J, sp.inv_h2);
+        }
+        for (uint32_t c2 = 0; c2 < K; ++c2) {
+            Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.color_count[c2] : 0);
+            hipLaunchKernelGGL(k_solve_pos, dim3(solve_grid), dim3(kBlock), 0, w->stream, c2, w->ctr.p, w->cpairs.p, B, C);
+        }
+        { Prof p(w, SFX_K_SOLVE_POS_TAIL, 0);
+          hipLaunchKernelGGL(k_solve_pos_tail, dim3(1), dim3(kBlock), 0, w->stream, K, w->ctr.p, w->cpairs.p, B, C); }
+        { Prof p(w, SFX_K_DERIVE_VEL, n);
+          hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
+        for (uint32_t c2 = 0; c2 < K; ++c2) {
+            Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.color_count[c2] : 0);
+            hipLaunchKernelGGL(k_solve_vel, dim3(solve_grid), dim3(kBlock), 0, w->stream, c2, w->ctr.p, w->cpairs.p, B, C, sp);
+        }
+        { Prof p(w, SFX_K_SOLVE_VEL_TAIL, 0);
+          hipLaunchKernelGGL(k_solve_vel_tail, dim3(1), dim3(kBlock), 0, w->stream, K, w->ctr.p, w->cpairs.p, B, C, sp); }
+    }
+    HIPCHK(w, hipGetLastError());
+    if (!w->ctr_pending) {
+        HIPCHK(w, hipMemcpyAsync(w->h_ctr, w->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(w, hipEventRecord(w->ev_ctr, w->stream));
+        w->ctr_pending = true;
+    }
+    w->ticked = true;
+    if (w->profiling) return collect_profile(w);
+    return SFX_OK;
+}
+
+int sfx_sync(sfx_world* w) {
+    if (!w) return SFX_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    poll_counters(w);
+    if (w->ctr_valid && w->stale.overflow)
+        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list)",
+                    w->stale.overflow);
+    return SFX_OK;
+}
+
+int sfx_download_poses(sfx_world* w, float* pos, float* rot) {
+    if (!w || !w->have_bodies) return fail(w, SFX_ERR_INVALID, "no bodies");
+    HIPCHK(w, hipSetDevice(w->device));
+    std::vector<float4> hp(std::max(w->n, 1u));
+    HIPCHK(w, hipMemcpyAsync(hp.data(), w->pose.p, sizeof(float4) * w->n, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    for (uint32_t i = 0; i < w->n; ++i) {
+        if (pos) { pos[2 * i] = hp[i].x; pos[2 * i + 1] = hp[i].y; }
+        if (rot) { rot[2 * i] = hp[i].z; rot[2 * i + 1] = hp[i].w; }
+    }
+    return SFX_OK;
+}
+
+int sfx_download_velocities(sfx_world* w, float* vel, float* angvel) {
+    if (!w || !w->have_bodies) return fail(w, SFX_ERR_INVALID, "no bodies");
+    HIPCHK(w, hipSetDevice(w->device));
+    std::vector<float4> hv(std::max(w->n, 1u));
+    HIPCHK(w, hipMemcpyAsync(hv.data(), w->vel.p, sizeof(float4) * w->n, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    for (uint32_t i = 0; i < w->n; ++i) {
+        if (vel) { vel[2 * i] = hv[i].x; vel[2 * i + 1] = hv[i].y; }
+        if (angvel) angvel[i] = hv[i].z;
+    }
+    return SFX_OK;
+}
+
+int sfx_debug_aabbs(sfx_world* w, float* out) {
+    int rc = ready(w);
+    if (rc) return rc;
+    if (!out || !w->ticked) return fail(w, SFX_ERR_INVALID, "no broadphase has run");
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipMemcpyAsync(out, w->aabb.p, sizeof(float4) * w->n, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return SFX_OK;
+}
+
+static int fetch_pairs(sfx_world* w, const uint2* dev, std::vector<uint2>& out, Counters& c) {
+    int rc = ready(w);
+    if (rc) return rc;
+    if (!w->ticked) return fail(w, SFX_ERR_INVALID, "no broadphase has run");
+    HIPCHK(w, hipSetDevice(w->device));
+    rc = sync_counters(w, &c, w->ctr.p);
+    if (rc) return rc;
+    out.resize(c.n_pairs);
+    if (c.n_pairs) HIPCHK(w, hipMemcpy(out.data(), dev, sizeof(uint2) * c.n_pairs, hipMemcpyDeviceToHost));
+    return SFX_OK;
+}
+
+int sfx_debug_pairs(sfx_world* w, uint64_t* keys, size_t cap, size_t* n) {
+    std::vector<uint2> p;
+    Counters c;
+    int rc = fetch_pairs(w, w ? w->pairs.p : nullptr, p, c);
+    if (rc) return rc;
+    std::vector<uint64_t> k(p.size());
+    for (size_t i = 0; i < p.size(); ++i) k[i] = ((uint64_t)p[i].x << 32) | p[i].y;
+    std::sort(k.begin(), k.end());
+    if (n) *n = k.size();
+    if (keys) memcpy(keys, k.data(), sizeof(uint64_t) * std::min(cap, k.size()));
+    return SFX_OK;
+}
+
+int sfx_debug_pair_colors(sfx_world* w, uint64_t* keys, uint8_t* colors, size_t cap, size_t* n) {
+    std::vector<uint2> p;
+    Counters c;
+    int rc = fetch_pairs(w, w ? w->cpairs.p : nullptr, p, c);
+    if (rc) return rc;
+    if (n) *n = p.size();
+    for (uint32_t col = 0; col < SFX_MAX_COLORS; ++col)
+        for (uint32_t k = c.color_start[col]; k < c.color_start[col + 1] && k < p.size() && k < cap; ++k) {
+            if (keys) keys[k] = ((uint64_t)p[k].x << 32) | p[k].y;
+            if (colors) colors[k] = (uint8_t)col;
+        }
+    return SFX_OK;
+}
+
+int sfx_debug_contacts(sfx_world* w, sfx_contact* out, size_t cap, size_t* n) {
+    std::vector<uint2> p;
+    Counters c;
+    int rc = fetch_pairs(w, w ? w->pairs.p : nullptr, p, c);
+    if (rc) return rc;
+    std::sort(p.begin(), p.end(), [](const uint2& a, const uint2& b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
+    if (n) *n = p.size();
+    const uint32_t np = (uint32_t)std::min(cap, p.size());
+    if (!np || !out) return SFX_OK;
+    DevBuf<uint2> dp;
+    DevBuf<sfx_contact> dc;
+    ALLOC(w, dp, np); ALLOC(w, dc, np);
+    hipError_t e = hipMemcpy(dp.p, p.data(), sizeof(uint2) * np, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_contacts_debug, dim3(cdiv(np, kBlock)), dim3(kBlock), 0, w->stream, np, dp.p, body_arrays(w), dc.p);
+        e = hipStreamSynchronize(w->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpy(out, dc.p, sizeof(sfx_contact) * np, hipMemcpyDeviceToHost);
+    dp.release(); dc.release();
+    if (e != hipSuccess) return fail(w, SFX_ERR_DEVICE, "contact debug pass failed: %s", hipGetErrorString(e));
+    return SFX_OK;
+}
+
+int sfx_debug_joint_order(sfx_world* w, uint32_t* perm, uint8_t* colors, size_t cap, size_t* n) {
+    if (!w) return SFX_ERR_INVALID;
+    if (n) *n = w->m;
+    for (size_t k = 0; k < w->m && k < cap; ++k) {
+        if (perm) perm[k] = w->joint_perm[k];
+        if (colors) colors[k] = w->joint_color_sorted[k];
+    }
+    return SFX_OK;
+}
+
+int sfx_stats(sfx_world* w, sfx_frame_stats* out) {
+    if (!w || !out) return SFX_ERR_INVALID;
+    memset(out, 0, sizeof(*out));
+    out->n_bodies = w->n;
+    out->n_joint_colors = (uint32_t)w->joint_color_start.size() - 1;
+    out->launches = w->launches;
+    if (!w->have_bodies || !w->have_colliders || !w->ticked) return SFX_OK;
+    HIPCHK(w, hipSetDevice(w->device));
+    const uint32_t saved = w->launches;
+    // the stats live in their own counter block so the tick's counters stay untouched
+    HIPCHK(w, hipMemsetAsync(w->jctr.p, 0, sizeof(Counters), w->stream));
+    const uint32_t grid = std::min(std::max(cdiv(std::max(w->n, 1u), kBlock), 1u), 1024u);
+    hipLaunchKernelGGL(k_stats_bodies, dim3(grid), dim3(kBlock), 0, w->stream, w->n, w->vel.p, w->mass.p, w->jctr.p);
+    if (w->have_mats)
+        hipLaunchKernelGGL(k_stats_pairs, dim3(edge_grid(w->max_pairs)), dim3(kBlock), 0, w->stream, w->ctr.p, w->jctr.p,
+                           w->cpairs.p, body_arrays(w), contact_arrays(w));
+    Counters c{}, s{};
+    int rc = sync_counters(w, &s, w->jctr.p);
+    if (rc) return rc;
+    rc = sync_counters(w, &c, w->ctr.p);
+    if (rc) return rc;
+    w->launches = saved;
+    out->n_small = c.n_small; out->n_large = c.n_large; out->n_pairs = c.n_pairs; out->n_colors = c.n_colors;
+    out->n_leftover = c.n_leftover; out->overflow = c.overflow;
+    out->n_contacts = s.n_contacts;
+    memcpy(&out->max_depth, &s.max_depth_bits, 4);
+    out->kinetic_energy = s.ke;
+    memcpy(out->color_count, c.color_count, sizeof(out->color_count));
+    return SFX_OK;
+}
+
+int sfx_set_profiling(sfx_world* w, int on) {
+    if (!w) return SFX_ERR_INVALID;
+    if (!on && w->profiling) collect_profile(w);
+    w->profiling = on != 0;
+    return SFX_OK;
+}
+
+int sfx_kernel_times(sfx_world* w, sfx_kernel_time* out, int reset) {
+    if (!w || !out) return SFX_ERR_INVALID;
+    int rc = collect_profile(w);
+    if (rc) return rc;
+    memcpy(out, w->ktime, sizeof(w->ktime));
+    if (reset) memset(w->ktime, 0, sizeof(w->ktime));
+    return SFX_OK;
+}
+
+const char* sfx_kernel_class_name(int cls) {
+    static const char* names[SFX_K_CLASSES] = {
+        "aabb_count", "scan", "scatter", "pair_count", "pair_fill", "color", "color_sort", "integrate",
+        "solve_joints", "solve_pos", "solve_pos_tail", "derive_vel", "solve_vel", "solve_vel_tail", "stats", "halo"};
+    return (cls >= 0 && cls < SFX_K_CLASSES) ? names[cls] : "?";
+}
+
+int sfx_timer_begin(sfx_world* w) {
+    if (!w) return SFX_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipEventRecord(w->t_begin, w->stream));
+    return SFX_OK;
+}
+
+int sfx_timer_end(sfx_world* w, double* ms) {
+    if (!w || !ms) return SFX_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipEventRecord(w->t_end, w->stream));
+    HIPCHK(w, hipEventSynchronize(w->t_end));
+    float f = 0.0f;
+    HIPCHK(w, hipEventElapsedTime(&f, w->t_begin, w->t_end));
+    *ms = f;
+    return SFX_OK;
+}
+
+}  // extern "C"

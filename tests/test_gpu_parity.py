@@ -1,0 +1,178 @@
+"""GPU parity tests: libsfx (HIP, through the C ABI) against the CPU oracle on identical inputs.
+
+Oracle = this repository's CPU restatement of the published XPBD algorithm (PARITY UNPINNED
+against starframe itself: its source was unavailable).  Bars (BASELINE.json:5):
+candidate pair sets bit-exact; contact normals/depths and single-tick post-solve positions
+within 1e-5 relative.
+"""
+import numpy as np
+import pytest
+
+from starframe_amd import scenes
+from tests.helpers import coloring_valid, colors_by_key, rel_err, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+DT = 1.0 / 60.0
+TOL = 1e-5
+
+
+def make_pair(scene, **kw):
+    from oracle.oracle import OracleWorld
+    from starframe_amd.world import World
+
+    return World.from_scene(scene, **kw), OracleWorld.from_scene(scene, **kw)
+
+
+SOUPS = [(300, 1, 4.0), (1000, 2, 6.0), (3000, 3, 14.0)]
+
+
+@pytest.mark.parametrize("n,seed,extent", SOUPS)
+def test_aabbs_and_pairs_bit_exact(n, seed, extent):
+    s = scenes.random_soup(n, seed=seed, extent=extent)
+    g, o = make_pair(s)
+    g.broadphase(DT)
+    o.broadphase(DT)
+    assert np.array_equal(g.aabbs().view(np.uint32), o.aabbs().view(np.uint32)), "AABBs differ bitwise"
+    gp, op = g.pairs(), o.pairs()
+    assert len(gp) > n // 2
+    assert np.array_equal(gp, op), "candidate pair set differs from the oracle grid"
+    assert np.array_equal(gp, o.pairs_sweep()), "candidate pair set differs from sort-and-sweep"
+    if n <= 1000:
+        assert np.array_equal(gp, o.pairs_brute())
+    gs, os_ = g.stats(), o.stats()
+    assert (gs.n_small, gs.n_large, gs.n_pairs) == (os_.n_small, os_.n_large, os_.n_pairs)
+
+
+@pytest.mark.parametrize("n,seed,extent", SOUPS)
+def test_colouring_matches_oracle(n, seed, extent):
+    s = scenes.random_soup(n, seed=seed, extent=extent)
+    g, o = make_pair(s)
+    g.broadphase(DT)
+    o.broadphase(DT)
+    gk, gc = colors_by_key(*g.pair_colors())
+    ok, oc = colors_by_key(*o.pair_colors())
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    assert coloring_valid(gk, gc, dyn)
+    assert np.array_equal(gk, ok)
+    assert np.array_equal(gc, oc), "pair colours differ from the restated colouring"
+    gs, os_ = g.stats(), o.stats()
+    assert gs.n_colors == os_.n_colors and gs.n_leftover == os_.n_leftover
+    assert list(gs.color_count) == list(os_.color_count)
+
+
+@pytest.mark.parametrize("n,seed,extent", SOUPS)
+def test_contacts_match_oracle(n, seed, extent):
+    s = scenes.random_soup(n, seed=seed, extent=extent)
+    g, o = make_pair(s)
+    g.broadphase(DT)
+    o.broadphase(DT)
+    gc, oc = g.contacts(), o.contacts()
+    assert len(gc) == len(oc)
+    assert np.array_equal(gc["body_a"], oc["body_a"]) and np.array_equal(gc["body_b"], oc["body_b"])
+    assert np.array_equal(gc["count"], oc["count"]), "manifold point counts differ"
+    assert (gc["count"] > 0).sum() > 20
+    assert rel_err(gc["normal"], oc["normal"], floor=1.0) <= TOL
+    assert rel_err(gc["depth"], oc["depth"], floor=1e-2) <= TOL
+    assert rel_err(gc["point_a"], oc["point_a"], floor=1.0) <= TOL
+    assert rel_err(gc["point_b"], oc["point_b"], floor=1.0) <= TOL
+
+
+@pytest.mark.parametrize("n,seed,extent", SOUPS)
+def test_single_tick_positions(n, seed, extent):
+    """One tick, colour order on both sides: post-solve poses and velocities within 1e-5."""
+    from oracle.oracle import ORDER_COLORED
+
+    s = scenes.random_soup(n, seed=seed, extent=extent)
+    g, o = make_pair(s)
+    g.step(DT)
+    o.step(DT, ORDER_COLORED)
+    gp, gr = g.poses()
+    op, orr = o.poses()
+    gv, gw = g.velocities()
+    ov, ow = o.velocities()
+    assert rel_err(gp, op, floor=1.0) <= TOL
+    assert rel_err(gr, orr, floor=1.0) <= TOL
+    assert rel_err(gv, ov, floor=1.0) <= 1e-4
+    assert rel_err(gw, ow, floor=10.0) <= 1e-4
+    print("ulp pos", ulp_diff(gp, op), "rot", ulp_diff(gr, orr))
+
+
+def test_pyramid_single_tick_and_long_run():
+    """Config 1 (BASELINE.json:7): single tick within tolerance, then 300 frames compared
+    statistically (stack height, kinetic energy, penetration)."""
+    from oracle.oracle import ORDER_COLORED
+
+    s = scenes.pyramid()
+    g, o = make_pair(s)
+    g.step(DT)
+    o.step(DT, ORDER_COLORED)
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= TOL
+    for _ in range(299):
+        g.step(DT)
+        o.step(DT, ORDER_COLORED)
+    gs, os_ = g.stats(), o.stats()
+    gp, op = g.poses()[0], o.poses()[0]
+    assert abs(gp[:-1, 1].max() - op[:-1, 1].max()) < 0.05, "stack height"
+    assert gp[:-1, 1].max() > 30.0
+    assert gs.max_depth < 0.01 and os_.max_depth < 0.01
+    assert gs.kinetic_energy < 1.0 and os_.kinetic_energy < 1.0
+    assert np.isfinite(gp).all()
+
+
+def test_chains_joint_colouring_and_tick():
+    from oracle.oracle import ORDER_COLORED
+
+    s = scenes.chains(n_chains=20, links=30)
+    g, o = make_pair(s)
+    gperm, gcol = g.joint_order()
+    operm, ocol = o.joint_order()
+    assert np.array_equal(np.sort(gperm), np.arange(len(s.constraints)))
+    cg = np.empty(len(gperm), np.uint8); cg[gperm] = gcol
+    co = np.empty(len(operm), np.uint8); co[operm] = ocol
+    assert np.array_equal(cg, co), "joint colours differ"
+    g.step(DT)
+    o.step(DT, ORDER_COLORED)
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= TOL
+    for _ in range(120):
+        g.step(DT)
+        o.step(DT, ORDER_COLORED)
+    gp, op = g.poses()[0], o.poses()[0]
+    assert np.isfinite(gp).all()
+    # statistical: mean sag of the chain tips
+    tips = np.arange(20) * 30 + 29
+    assert abs(gp[tips, 1].mean() - op[tips, 1].mean()) < 0.1
+
+
+def test_empty_and_tiny_worlds():
+    from starframe_amd.scenes import SceneBuilder
+    from starframe_amd.world import World
+
+    b = SceneBuilder("one")
+    b.circle((0, 0), 0.1)
+    w = World.from_scene(b.build())
+    for _ in range(3):
+        w.step(DT)
+    p, _ = w.poses()
+    assert p[0, 1] < 0
+    assert w.stats().n_pairs == 0
+    b = SceneBuilder("none")
+    b.particle((0, 0))
+    b.particle((0, 0))
+    w = World.from_scene(b.build())
+    w.step(DT)
+    assert w.stats().n_pairs == 0
+
+
+def test_pair_capacity_overflow_reported():
+    from starframe_amd.world import SfxError, World
+
+    s = scenes.random_soup(2000, seed=5, extent=3.0)
+    w = World.from_scene(s, max_pairs=1024)
+    w.step(DT)
+    assert w.stats().overflow & 1
+    w.step(DT)
+    with pytest.raises(SfxError):
+        w.sync()
+        w.step(DT)
+        w.sync()
