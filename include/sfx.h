@@ -58,7 +58,9 @@ typedef struct sfx_config {
     int32_t device;         /* HIP device ordinal                                    */
     uint32_t substeps;      /* substeps per tick (>= 1)                              */
     float gravity[2];
-    float aabb_margin;      /* fixed AABB padding (m); velocity*dt is added per frame */
+    float aabb_margin;      /* fixed AABB padding (m)                                 */
+    float vel_pad_max;      /* AABBs also grow by min(|v| * dt, vel_pad_max) per axis;
+                               0 = 0.03 m; negative = no velocity padding              */
     float cell_size;        /* broadphase cell edge (m); 0 = derive from shapes      */
     uint32_t grid_log2[2];  /* wrapped grid is 2^gx by 2^gy cells; 0 = auto          */
     uint32_t max_pairs;     /* candidate pair capacity; 0 = 12 * bodies              */
@@ -66,6 +68,10 @@ typedef struct sfx_config {
     uint32_t launch_colors; /* colours that get their own launch; the rest share a
                                single-workgroup tail kernel; 0 = 16                  */
     float restitution_threshold; /* restitution is dropped when |vn_pre| <= this * |g| * h; 0 = 2.0 */
+    float max_depenetration_velocity; /* a contact corrects at most this * h of penetration per
+                               substep (m/s); 0 = 3.0; negative = unlimited            */
+    float linear_damping;   /* 1/s: v *= 1 / (1 + h * c) every substep; 0 = none        */
+    float angular_damping;  /* 1/s, same for the angular velocity                       */
     uint32_t flags;         /* SFX_CFG_* */
 } sfx_config;
 
@@ -118,7 +124,9 @@ typedef struct sfx_frame_stats {
     uint32_t n_pairs;        /* candidate pairs of the last tick             */
     uint32_t n_colors;       /* colours used by the candidate-pair graph     */
     uint32_t n_leftover;     /* pairs coloured by the serial finish          */
-    uint32_t n_contacts;     /* contact points of the last substep           */
+    uint32_t n_manifolds;    /* pairs that touched in the last substep       */
+    uint32_t n_manifolds2;   /* ... of which with two contact points         */
+    uint32_t n_contacts;     /* active contact points of the last substep    */
     uint32_t n_joint_colors;
     uint32_t overflow;       /* != 0: a capacity was exceeded this tick      */
     uint32_t launches;       /* kernel launches issued by the last tick      */

@@ -69,7 +69,7 @@ struct sfo_world {
     uint32_t color_count[SFX_MAX_COLORS];
     uint32_t* order;   /* processing order (indices into pa/pb) */
     pair_rec* rec;
-    uint32_t n_contacts;
+    uint32_t n_contacts, n_manifolds, n_manifolds2;
     float max_depth;
 };
 
@@ -81,6 +81,10 @@ static void resolve_defaults(sfx_config* c) {
     if (c->color_rounds > 60) c->color_rounds = 60;
     if (c->launch_colors == 0) c->launch_colors = 16;
     if (c->restitution_threshold == 0.0f) c->restitution_threshold = 2.0f;
+    if (c->vel_pad_max == 0.0f) c->vel_pad_max = 0.03f;
+    if (c->max_depenetration_velocity == 0.0f) c->max_depenetration_velocity = 3.0f;
+    if (c->max_depenetration_velocity < 0.0f) c->max_depenetration_velocity = INFINITY;
+    if (c->vel_pad_max < 0.0f) c->vel_pad_max = 0.0f;
 }
 
 sfo_world* sfo_create(const sfx_config* cfg) {
@@ -148,7 +152,7 @@ static uint32_t ceil_log2(uint32_t v) {
     return l;
 }
 
-/* [DESIGN] DESIGN.md "Contract / grid": cell = 1.25 * (largest dynamic diameter + 2 margin);
+/* [DESIGN] DESIGN.md "Contract / grid": cell = 1.25 * (largest dynamic diameter + 2 (margin + vel_pad_max));
  * grid = smallest square power-of-two torus with >= 2 cells per body, 4..4096 per side. */
 static void resolve_grid(sfo_world* w) {
     float cell = w->cfg.cell_size;
@@ -159,7 +163,7 @@ static void resolve_grid(sfo_world* w) {
             float d = shape_diameter(w, &w->col[i]);
             if (d > dmax) dmax = d;
         }
-        cell = dmax > 0.0f ? 1.25f * (dmax + 2.0f * w->cfg.aabb_margin) : 1.0f;
+        cell = dmax > 0.0f ? 1.25f * (dmax + 2.0f * (w->cfg.aabb_margin + w->cfg.vel_pad_max)) : 1.0f;
     }
     w->cell = cell;
     w->inv_cell = 1.0f / cell;
@@ -310,14 +314,14 @@ static uint32_t color_edges(uint32_t n_bodies, uint32_t ne, const uint32_t* ea, 
         int da = a != SFX_WORLD_BODY && dyn[a], db = b != SFX_WORLD_BODY && dyn[b];
         uint64_t freem = ~((da ? used[a] : 0) | (db ? used[b] : 0));
         (*leftover)++;
-        if (freem == 0) { *overflow = 1; color[e] = 63; continue; }
+        if (freem == 0) { *overflow = 1; continue; } /* stays uncoloured: dropped from the solve */
         uint32_t c = (uint32_t)__builtin_ctzll(freem);
         color[e] = (uint8_t)c;
         if (da) used[a] |= 1ull << c;
         if (db) used[b] |= 1ull << c;
     }
     uint32_t nc = 0;
-    for (uint32_t e = 0; e < ne; ++e) if (color[e] + 1u > nc) nc = color[e] + 1u;
+    for (uint32_t e = 0; e < ne; ++e) if (color[e] != NO_COLOR && color[e] + 1u > nc) nc = color[e] + 1u;
     free(used); free(deg); free(claim); free(prop); free(prio);
     return nc;
 }
@@ -389,8 +393,8 @@ static void compute_aabb(const sfo_world* w, uint32_t i, float dt, float* out) {
         out[0] = out[1] = INFINITY; out[2] = out[3] = -INFINITY;
         return;
     }
-    float padx = w->cfg.aabb_margin + fabsf(w->vel[2 * i]) * dt;
-    float pady = w->cfg.aabb_margin + fabsf(w->vel[2 * i + 1]) * dt;
+    float padx = w->cfg.aabb_margin + fminf(fabsf(w->vel[2 * i]) * dt, w->cfg.vel_pad_max);
+    float pady = w->cfg.aabb_margin + fminf(fabsf(w->vel[2 * i + 1]) * dt, w->cfg.vel_pad_max);
     out[0] = (px + minx) - padx;
     out[1] = (py + miny) - pady;
     out[2] = (px + maxx) + padx;
@@ -550,7 +554,7 @@ int sfo_broadphase(sfo_world* w, float frame_dt) {
     w->n_colors = color_edges(w->n, np, w->pa, w->pb, dyn, w->cfg.color_rounds, w->color, &w->n_leftover, &ovf);
     if (ovf) w->overflow = 1;
     memset(w->color_count, 0, sizeof(w->color_count));
-    for (uint32_t e = 0; e < np; ++e) w->color_count[w->color[e]]++;
+    for (uint32_t e = 0; e < np; ++e) if (w->color[e] != NO_COLOR) w->color_count[w->color[e]]++;
     free(dyn);
     return w->overflow ? SFX_ERR_CAPACITY : SFX_OK;
 }
@@ -882,12 +886,18 @@ static void rotate_by(float* c, float* s, float dth) {
 /* [XPBD-RB] Alg. 2 lines 3-9 */
 static void integrate(sfo_world* w, float h) {
     float gx = w->cfg.gravity[0], gy = w->cfg.gravity[1];
+    float dl = 1.0f / (1.0f + h * w->cfg.linear_damping), da = 1.0f / (1.0f + h * w->cfg.angular_damping);
     for (uint32_t i = 0; i < w->n; ++i) {
         w->prev_pos[2 * i] = w->pos[2 * i]; w->prev_pos[2 * i + 1] = w->pos[2 * i + 1];
         w->prev_rot[2 * i] = w->rot[2 * i]; w->prev_rot[2 * i + 1] = w->rot[2 * i + 1];
         if (w->inv_mass[i] > 0.0f) {
             w->vel[2 * i] = w->vel[2 * i] + gx * h;
             w->vel[2 * i + 1] = w->vel[2 * i + 1] + gy * h;
+        }
+        if (is_dynamic(w, i)) {
+            w->vel[2 * i] = w->vel[2 * i] * dl;
+            w->vel[2 * i + 1] = w->vel[2 * i + 1] * dl;
+            w->angvel[i] = w->angvel[i] * da;
         }
         w->pos[2 * i] = w->pos[2 * i] + w->vel[2 * i] * h;
         w->pos[2 * i + 1] = w->pos[2 * i + 1] + w->vel[2 * i + 1] * h;
@@ -957,7 +967,7 @@ static void solve_lcp2(float K00, float K01, float K11, float d0, float d1, floa
 /* [XPBD-RB] sec. 3.5: contact handled with the manifold recomputed from the current poses;
  * normal constraints of the manifold solved as a block.  Friction is not applied here but
  * in the velocity pass (see solve_vel_pair) so that it sees the net motion of the substep. */
-static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec) {
+static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec, float max_corr) {
     manifold_t m;
     manifold(w, a, b, &m);
     rec->count = (uint32_t)m.count;
@@ -988,6 +998,7 @@ static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec) 
         rec->vn_pre[k] = (vbx - vax) * nx + (vby - vay) * ny;
         d[k] = ((w->pos[2 * a] + rax[k]) - (w->pos[2 * b] + rbx[k])) * nx +
                ((w->pos[2 * a + 1] + ray[k]) - (w->pos[2 * b + 1] + rby[k])) * ny;
+        d[k] = fminf(d[k], max_corr); /* [DESIGN] bounded depenetration per substep */
         cna[k] = rax[k] * ny - ray[k] * nx;
         cnb[k] = rbx[k] * ny - rby[k] * nx;
     }
@@ -1064,7 +1075,7 @@ static void solve_vel_pair(sfo_world* w, uint32_t a, uint32_t b, const pair_rec*
     float vthr = w->cfg.restitution_threshold * gl * h;
     float ima = w->inv_mass[a], iia = w->inv_inertia[a], imb = w->inv_mass[b], iib = w->inv_inertia[b];
     float ims = ima + imb;
-    float rax[2], ray[2], rbx[2], rby[2], dv[2], cna[2], cnb[2], K[2];
+    float rax[2], ray[2], rbx[2], rby[2], dv[2], cna[2] = {0.0f, 0.0f}, cnb[2] = {0.0f, 0.0f}, K[2];
     int act[2];
     act[1] = 0; dv[1] = 0.0f; cna[1] = 0.0f; cnb[1] = 0.0f; K[1] = 1.0f;
     for (int k = 0; k < count; ++k) {
@@ -1178,9 +1189,10 @@ static int cmp_key_idx(const void* a, const void* b) {
 
 int sfo_step(sfo_world* w, float frame_dt, int order) {
     if (!w->col || !w->mats) return SFX_ERR_INVALID;
-    int rc = sfo_broadphase(w, frame_dt);
-    if (rc != SFX_OK) return rc;
-    uint32_t np = w->n_pairs;
+    (void)sfo_broadphase(w, frame_dt); /* capacity overflow is reported by sfo_stats, the tick goes on */
+    uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
+    uint32_t nord = np;
+    for (uint32_t e = 0; e < np; ++e) w->rec[e].count = 0;
     if (order == SFO_ORDER_SEQUENTIAL) {
         key_idx* ki = (key_idx*)malloc((np ? np : 1) * sizeof(key_idx));
         for (uint32_t e = 0; e < np; ++e) { ki[e].key = ((uint64_t)w->pa[e] << 32) | w->pb[e]; ki[e].idx = e; }
@@ -1191,7 +1203,8 @@ int sfo_step(sfo_world* w, float frame_dt, int order) {
         uint32_t start[SFX_MAX_COLORS + 1];
         start[0] = 0;
         for (uint32_t c = 0; c < SFX_MAX_COLORS; ++c) start[c + 1] = start[c] + w->color_count[c];
-        for (uint32_t e = 0; e < np; ++e) w->order[start[w->color[e]]++] = e;
+        nord = 0;
+        for (uint32_t e = 0; e < np; ++e) if (w->color[e] != NO_COLOR) { w->order[start[w->color[e]]++] = e; ++nord; }
     }
     float h = frame_dt / (float)w->cfg.substeps;
     float inv_h = 1.0f / h;
@@ -1202,19 +1215,21 @@ int sfo_step(sfo_world* w, float frame_dt, int order) {
             uint32_t jk = order == SFO_ORDER_SEQUENTIAL ? k : w->joint_perm[k];
             solve_joint(w, &w->joints[jk], inv_h2);
         }
-        for (uint32_t k = 0; k < np; ++k) {
+        for (uint32_t k = 0; k < nord; ++k) {
             uint32_t e = w->order[k];
-            solve_pos_pair(w, w->pa[e], w->pb[e], &w->rec[e]);
+            solve_pos_pair(w, w->pa[e], w->pb[e], &w->rec[e], w->cfg.max_depenetration_velocity * h);
         }
         derive_velocities(w, inv_h);
-        for (uint32_t k = 0; k < np; ++k) {
+        for (uint32_t k = 0; k < nord; ++k) {
             uint32_t e = w->order[k];
             if (w->rec[e].count) solve_vel_pair(w, w->pa[e], w->pb[e], &w->rec[e], h, inv_h);
         }
     }
     /* stats of the last substep, measured on the records */
-    w->n_contacts = 0; w->max_depth = 0.0f;
+    w->n_contacts = 0; w->max_depth = 0.0f; w->n_manifolds = 0; w->n_manifolds2 = 0;
     for (uint32_t e = 0; e < np; ++e) {
+        if (w->rec[e].count) w->n_manifolds++;
+        if (w->rec[e].count == 2) w->n_manifolds2++;
         for (uint32_t k = 0; k < w->rec[e].count; ++k)
             if (w->rec[e].lam[k] > 0.0f) w->n_contacts++;
     }
@@ -1237,7 +1252,8 @@ int sfo_stats(const sfo_world* w, sfx_frame_stats* out) {
     memset(out, 0, sizeof(*out));
     out->n_bodies = w->n; out->n_small = w->n_small; out->n_large = w->n_large;
     out->n_pairs = w->n_pairs; out->n_colors = w->n_colors; out->n_leftover = w->n_leftover;
-    out->n_contacts = w->n_contacts; out->n_joint_colors = w->n_joint_colors;
+    out->n_contacts = w->n_contacts; out->n_manifolds = w->n_manifolds; out->n_manifolds2 = w->n_manifolds2;
+    out->n_joint_colors = w->n_joint_colors;
     out->overflow = w->overflow;
     memcpy(out->color_count, w->color_count, sizeof(w->color_count));
     /* deepest penetration at the current poses */

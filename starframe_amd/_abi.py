@@ -35,12 +35,16 @@ class SfxConfig(C.Structure):
         ("substeps", C.c_uint32),
         ("gravity", C.c_float * 2),
         ("aabb_margin", C.c_float),
+        ("vel_pad_max", C.c_float),
         ("cell_size", C.c_float),
         ("grid_log2", C.c_uint32 * 2),
         ("max_pairs", C.c_uint32),
         ("color_rounds", C.c_uint32),
         ("launch_colors", C.c_uint32),
         ("restitution_threshold", C.c_float),
+        ("max_depenetration_velocity", C.c_float),
+        ("linear_damping", C.c_float),
+        ("angular_damping", C.c_float),
         ("flags", C.c_uint32),
     ]
 
@@ -53,6 +57,8 @@ class SfxFrameStats(C.Structure):
         ("n_pairs", C.c_uint32),
         ("n_colors", C.c_uint32),
         ("n_leftover", C.c_uint32),
+        ("n_manifolds", C.c_uint32),
+        ("n_manifolds2", C.c_uint32),
         ("n_contacts", C.c_uint32),
         ("n_joint_colors", C.c_uint32),
         ("overflow", C.c_uint32),
@@ -113,12 +119,16 @@ def make_config(
     substeps=4,
     gravity=(0.0, -9.81),
     aabb_margin=0.01,
+    vel_pad_max=0.0,
     cell_size=0.0,
     grid_log2=(0, 0),
     max_pairs=0,
     color_rounds=0,
     launch_colors=0,
     restitution_threshold=0.0,
+    max_depenetration_velocity=0.0,
+    linear_damping=0.0,
+    angular_damping=0.0,
     flags=0,
     device=0,
 ):
@@ -128,12 +138,16 @@ def make_config(
     cfg.substeps = substeps
     cfg.gravity[0], cfg.gravity[1] = gravity
     cfg.aabb_margin = aabb_margin
+    cfg.vel_pad_max = vel_pad_max
     cfg.cell_size = cell_size
     cfg.grid_log2[0], cfg.grid_log2[1] = grid_log2
     cfg.max_pairs = max_pairs
     cfg.color_rounds = color_rounds
     cfg.launch_colors = launch_colors
     cfg.restitution_threshold = restitution_threshold
+    cfg.max_depenetration_velocity = max_depenetration_velocity
+    cfg.linear_damping = linear_damping
+    cfg.angular_damping = angular_damping
     cfg.flags = flags
     return cfg
 

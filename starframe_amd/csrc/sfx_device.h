@@ -52,7 +52,8 @@ __device__ __forceinline__ void rotate_by(float& c, float& s, float dth) {
 
 // ---- AABB (DESIGN.md "Contract / AABB") --------------------------------------------
 __device__ __forceinline__ float4 compute_aabb(const float4& pose, const float4& vel, const float4& shape,
-                                               const float4* __restrict__ poly, float margin, float dt) {
+                                               const float4* __restrict__ poly, float margin, float vel_pad_max,
+                                               float dt) {
     const float px = pose.x, py = pose.y, rc = pose.z, rs = pose.w;
     float minx, maxx, miny, maxy;
     const uint32_t type = shape_type(shape);
@@ -79,8 +80,8 @@ __device__ __forceinline__ float4 compute_aabb(const float4& pose, const float4&
     } else {
         return make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
     }
-    float padx = margin + fabsf(vel.x) * dt;
-    float pady = margin + fabsf(vel.y) * dt;
+    float padx = margin + fminf(fabsf(vel.x) * dt, vel_pad_max);
+    float pady = margin + fminf(fabsf(vel.y) * dt, vel_pad_max);
     return make_float4((px + minx) - padx, (py + miny) - pady, (px + maxx) + padx, (py + maxy) + pady);
 }
 
@@ -473,7 +474,7 @@ __device__ __forceinline__ void solve_lcp2(float K00, float K01, float K11, floa
 // Position solve of one candidate pair: narrowphase at the current poses, block solve of
 // the manifold's normal constraints, poses written back.  Mueller et al. 2020 sec. 3.5.
 __device__ __forceinline__ void solve_pos_pair(const BodyArrays& B, const ContactArrays& C, uint32_t slot,
-                                               uint32_t a, uint32_t b) {
+                                               uint32_t a, uint32_t b, float max_corr) {
     float4 pa = B.pose[a], pb = B.pose[b];
     const float4 sa = B.shape[a], sb = B.shape[b];
     Manifold m;
@@ -512,6 +513,7 @@ __device__ __forceinline__ void solve_pos_pair(const BodyArrays& B, const Contac
             float vbx = vb.x - vb.z * rby, vby = vb.y + vb.z * rbx;
             vpre[k] = (vbx - vax) * nx + (vby - vay) * ny;
             d[k] = ((pa.x + rax) - (pb.x + rbx)) * nx + ((pa.y + ray) - (pb.y + rby)) * ny;
+            d[k] = fminf(d[k], max_corr);  // bounded depenetration per substep
             cna[k] = rax * ny - ray * nx;
             cnb[k] = rbx * ny - rby * nx;
         }
@@ -572,6 +574,8 @@ struct StepParams {
     float h, inv_h, inv_h2;
     float gx, gy;
     float vthr;      // restitution threshold velocity: cfg.restitution_threshold * |g| * h
+    float max_corr;  // cfg.max_depenetration_velocity * h
+    float damp_lin, damp_ang;  // 1 / (1 + h * damping)
     uint32_t flags;
 };
 

@@ -128,6 +128,10 @@ void resolve_defaults(sfx_config& c) {
     if (c.launch_colors == 0) c.launch_colors = 16;
     if (c.launch_colors > SFX_MAX_COLORS) c.launch_colors = SFX_MAX_COLORS;
     if (c.restitution_threshold == 0.0f) c.restitution_threshold = 2.0f;
+    if (c.vel_pad_max == 0.0f) c.vel_pad_max = 0.03f;
+    if (c.max_depenetration_velocity == 0.0f) c.max_depenetration_velocity = 3.0f;
+    if (c.max_depenetration_velocity < 0.0f) c.max_depenetration_velocity = INFINITY;
+    if (c.vel_pad_max < 0.0f) c.vel_pad_max = 0.0f;
 }
 
 inline uint32_t cdiv(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
@@ -168,7 +172,7 @@ void resolve_grid(sfx_world* w) {
             float d = shape_diameter(w, w->h_col[i]);
             if (d > dmax) dmax = d;
         }
-        cell = dmax > 0.0f ? 1.25f * (dmax + 2.0f * w->cfg.aabb_margin) : 1.0f;
+        cell = dmax > 0.0f ? 1.25f * (dmax + 2.0f * (w->cfg.aabb_margin + w->cfg.vel_pad_max)) : 1.0f;
     }
     w->cell = cell;
     w->inv_cell = 1.0f / cell;
@@ -313,7 +317,7 @@ int broadphase(sfx_world* w, float dt) {
     const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
     { Prof p(w, SFX_K_AABB_COUNT, n);
       hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p,
-                         w->poly.p, w->cfg.aabb_margin, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start.p,
+                         w->poly.p, w->cfg.aabb_margin, w->cfg.vel_pad_max, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start.p,
                          w->large_tmp.p, w->large_cap, w->ctr.p); }
     rc = scan_u32(w, w->cell_start.p, w->ncell + 1, w->cell_fill.p);
     if (rc) return rc;
@@ -664,6 +668,9 @@ int sfx_step(sfx_world* w, float frame_dt) {
     const float gl = sqrtf(sp.gx * sp.gx + sp.gy * sp.gy);
     sp.vthr = w->cfg.restitution_threshold * gl * sp.h;
     sp.flags = w->cfg.flags;
+    sp.max_corr = w->cfg.max_depenetration_velocity * sp.h;
+    sp.damp_lin = 1.0f / (1.0f + sp.h * w->cfg.linear_damping);
+    sp.damp_ang = 1.0f / (1.0f + sp.h * w->cfg.angular_damping);
     const BodyArrays B = body_arrays(w);
     const ContactArrays C = contact_arrays(w);
     JointArrays J;
@@ -692,10 +699,10 @@ int sfx_step(sfx_world* w, float frame_dt) {
         }
         for (uint32_t c2 = 0; c2 < K; ++c2) {
             Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.color_count[c2] : 0);
-            hipLaunchKernelGGL(k_solve_pos, dim3(solve_grid), dim3(kBlock), 0, w->stream, c2, w->ctr.p, w->cpairs.p, B, C);
+            hipLaunchKernelGGL(k_solve_pos, dim3(solve_grid), dim3(kBlock), 0, w->stream, c2, w->ctr.p, w->cpairs.p, B, C, sp.max_corr);
         }
         { Prof p(w, SFX_K_SOLVE_POS_TAIL, 0);
-          hipLaunchKernelGGL(k_solve_pos_tail, dim3(1), dim3(kBlock), 0, w->stream, K, w->ctr.p, w->cpairs.p, B, C); }
+          hipLaunchKernelGGL(k_solve_pos_tail, dim3(1), dim3(kBlock), 0, w->stream, K, w->ctr.p, w->cpairs.p, B, C, sp.max_corr); }
         { Prof p(w, SFX_K_DERIVE_VEL, n);
           hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
         for (uint32_t c2 = 0; c2 < K; ++c2) {
@@ -793,7 +800,7 @@ int sfx_debug_pair_colors(sfx_world* w, uint64_t* keys, uint8_t* colors, size_t 
     Counters c;
     int rc = fetch_pairs(w, w ? w->cpairs.p : nullptr, p, c);
     if (rc) return rc;
-    if (n) *n = p.size();
+    if (n) *n = std::min<size_t>(p.size(), c.color_start[SFX_MAX_COLORS]);
     for (uint32_t col = 0; col < SFX_MAX_COLORS; ++col)
         for (uint32_t k = c.color_start[col]; k < c.color_start[col + 1] && k < p.size() && k < cap; ++k) {
             if (keys) keys[k] = ((uint64_t)p[k].x << 32) | p[k].y;
@@ -860,6 +867,8 @@ int sfx_stats(sfx_world* w, sfx_frame_stats* out) {
     out->n_small = c.n_small; out->n_large = c.n_large; out->n_pairs = c.n_pairs; out->n_colors = c.n_colors;
     out->n_leftover = c.n_leftover; out->overflow = c.overflow;
     out->n_contacts = s.n_contacts;
+    out->n_manifolds = s.n_manifolds;
+    out->n_manifolds2 = s.n_manifolds2;
     memcpy(&out->max_depth, &s.max_depth_bits, 4);
     out->kinetic_energy = s.ke;
     memcpy(out->color_count, c.color_count, sizeof(out->color_count));

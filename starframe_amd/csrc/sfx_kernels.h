@@ -34,7 +34,8 @@ struct Counters {
     uint32_t n_contacts;    // stats kernel
     uint32_t max_depth_bits;
     float ke;
-    uint32_t pad[7];
+    uint32_t n_manifolds, n_manifolds2;
+    uint32_t pad[5];
     uint32_t color_count[SFX_MAX_COLORS];      // zeroed per tick
     uint32_t color_start[SFX_MAX_COLORS + 1];
     uint32_t color_fill[SFX_MAX_COLORS];       // zeroed per tick
@@ -64,6 +65,11 @@ __global__ __launch_bounds__(kBlock) void k_integrate(uint32_t n, float4* __rest
     if (w.x > 0.0f) {
         v.x = v.x + sp.gx * sp.h;
         v.y = v.y + sp.gy * sp.h;
+    }
+    if (w.x > 0.0f || w.y > 0.0f) {
+        v.x = v.x * sp.damp_lin;
+        v.y = v.y * sp.damp_lin;
+        v.z = v.z * sp.damp_ang;
         vel[i] = v;
     }
     p.x = p.x + v.x * sp.h;
@@ -92,15 +98,15 @@ __global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, const float4* __r
 // ---------------------------------------------------------------- K2 AABB + histogram
 __global__ __launch_bounds__(kBlock) void k_aabb_count(uint32_t n, const float4* __restrict__ pose,
                                                         const float4* __restrict__ vel, const float4* __restrict__ shape,
-                                                        const float4* __restrict__ poly, float margin, float dt,
-                                                        GridParams g, float4* __restrict__ aabb,
+                                                        const float4* __restrict__ poly, float margin, float vel_pad_max,
+                                                        float dt, GridParams g, float4* __restrict__ aabb,
                                                         uint32_t* __restrict__ bucket, int2* __restrict__ cellxy,
                                                         uint32_t* __restrict__ cell_count, uint32_t* __restrict__ large_tmp,
                                                         uint32_t large_cap, Counters* __restrict__ ctr) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float4 sh = shape[i];
-    const float4 A = compute_aabb(pose[i], vel[i], sh, poly, margin, dt);
+    const float4 A = compute_aabb(pose[i], vel[i], sh, poly, margin, vel_pad_max, dt);
     aabb[i] = A;
     uint32_t bk = SFX_NO_BUCKET;
     if (shape_type(sh) != SFX_SHAPE_NONE) {
@@ -475,14 +481,11 @@ __global__ __launch_bounds__(kBlock) void k_color_finish(ColorArrays A) {
             const uint2 ab = A.pairs[e];
             const bool da = edge_dyn(A, ab.x), db = edge_dyn(A, ab.y);
             const unsigned long long freem = ~((da ? A.used[ab.x] : 0ull) | (db ? A.used[ab.y] : 0ull));
-            uint32_t c = 63u;
-            if (freem == 0ull) atomicOr(&A.ctr->overflow, kOvfColors);
-            else c = (uint32_t)__builtin_ctzll(freem);
+            if (freem == 0ull) { atomicOr(&A.ctr->overflow, kOvfColors); continue; }  // dropped from the solve
+            const uint32_t c = (uint32_t)__builtin_ctzll(freem);
             A.color[e] = (uint8_t)c;
-            if (freem != 0ull) {
-                if (da) A.used[ab.x] |= 1ull << c;
-                if (db) A.used[ab.y] |= 1ull << c;
-            }
+            if (da) A.used[ab.x] |= 1ull << c;
+            if (db) A.used[ab.y] |= 1ull << c;
         }
     }
 }
@@ -548,22 +551,24 @@ __global__ __launch_bounds__(kBlock) void k_color_scatter(ColorArrays A, uint2* 
 // owns the bodies of its pair.  Colours >= first_tail share one single-workgroup kernel that
 // walks them in order with a workgroup barrier in between (the tail colours are tiny).
 __global__ __launch_bounds__(kBlock) void k_solve_pos(uint32_t color, const Counters* __restrict__ ctr,
-                                                       const uint2* __restrict__ cpairs, BodyArrays B, ContactArrays C) {
+                                                       const uint2* __restrict__ cpairs, BodyArrays B, ContactArrays C,
+                                                       float max_corr) {
     const uint32_t start = ctr->color_start[color], cnt = ctr->color_count[color];
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < cnt; k += gridDim.x * kBlock) {
         const uint2 ab = cpairs[start + k];
-        solve_pos_pair(B, C, start + k, ab.x, ab.y);
+        solve_pos_pair(B, C, start + k, ab.x, ab.y, max_corr);
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_solve_pos_tail(uint32_t first, const Counters* __restrict__ ctr,
-                                                          const uint2* __restrict__ cpairs, BodyArrays B, ContactArrays C) {
+                                                          const uint2* __restrict__ cpairs, BodyArrays B, ContactArrays C,
+                                                          float max_corr) {
     const uint32_t nc = ctr->n_colors;
     for (uint32_t color = first; color < nc; ++color) {
         const uint32_t start = ctr->color_start[color], cnt = ctr->color_count[color];
         for (uint32_t k = threadIdx.x; k < cnt; k += kBlock) {
             const uint2 ab = cpairs[start + k];
-            solve_pos_pair(B, C, start + k, ab.x, ab.y);
+            solve_pos_pair(B, C, start + k, ab.x, ab.y, max_corr);
         }
         __syncthreads();
     }
@@ -625,8 +630,8 @@ __global__ __launch_bounds__(kBlock) void k_stats_bodies(uint32_t n, const float
 // last substep, over all candidate pairs
 __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restrict__ cin, Counters* __restrict__ ctr,
                                                          const uint2* __restrict__ cpairs, BodyArrays B, ContactArrays C) {
-    const uint32_t np = cin->n_pairs;
-    uint32_t contacts = 0;
+    const uint32_t np = cin->color_start[SFX_MAX_COLORS];  // coloured pairs (all, unless colours overflowed)
+    uint32_t contacts = 0, mf = 0, mf2 = 0;
     float md = 0.0f;
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < np; k += gridDim.x * kBlock) {
         const uint2 ab = cpairs[k];
@@ -635,12 +640,16 @@ __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restri
         for (int q = 0; q < m.count; ++q) md = fmaxf(md, m.depth[q]);
         const uint32_t cnt = __float_as_uint(C.misc[k].y);
         if (cnt) {
+            mf += 1u;
+            mf2 += (cnt == 2) ? 1u : 0u;
             const float4 lv = C.lamv[k];
             contacts += (lv.x > 0.0f) ? 1u : 0u;
             contacts += (cnt == 2 && lv.y > 0.0f) ? 1u : 0u;
         }
     }
     if (contacts) atomicAdd(&ctr->n_contacts, contacts);
+    if (mf) atomicAdd(&ctr->n_manifolds, mf);
+    if (mf2) atomicAdd(&ctr->n_manifolds2, mf2);
     if (md > 0.0f) atomicMax(&ctr->max_depth_bits, __float_as_uint(md));
 }
 

@@ -52,6 +52,18 @@ class Scene:
     def n_dynamic(self):
         return int(np.count_nonzero((self.inv_mass > 0) | (self.inv_inertia > 0)))
 
+    def with_state(self, pos, rot, vel=None, angvel=None, name=None):
+        """Copy of the scene with another body state (e.g. the settled pile)."""
+        import copy
+
+        s = copy.copy(self)
+        s.name = name or self.name
+        s.pos = np.ascontiguousarray(pos, np.float32)
+        s.rot = np.ascontiguousarray(rot, np.float32)
+        s.vel = np.zeros_like(s.pos) if vel is None else np.ascontiguousarray(vel, np.float32)
+        s.angvel = np.zeros(s.n, np.float32) if angvel is None else np.ascontiguousarray(angvel, np.float32)
+        return s
+
     def subset(self, idx, name=None):
         """Scene restricted to bodies idx (constraints are dropped)."""
         idx = np.asarray(idx)
@@ -209,8 +221,10 @@ def pyramid(base=31, substeps=10):
     return b.build()
 
 
-def _container(floor_hw, wall_hh):
-    return [(0.0, -0.5, floor_hw, 0.5), (-floor_hw + 0.5, wall_hh, 0.5, wall_hh), (floor_hw - 0.5, wall_hh, 0.5, wall_hh)]
+def _container(floor_hw, wall_hh, t=5.0):
+    """Floor (top at y = 0) and two walls (inner faces at x = +-floor_hw), each 2 t thick so that
+    fast bodies cannot tunnel through them between two broadphase passes."""
+    return [(0.0, -t, floor_hw + 2 * t, t), (-floor_hw - t, wall_hh, t, wall_hh + t), (floor_hw + t, wall_hh, t, wall_hh + t)]
 
 
 def _lattice(n, width, pitch, jitter, u, y0=0.3):
@@ -233,9 +247,13 @@ def circles_container(n=10_000, seed=0x5EED0002, width=100, pitch=0.22, floor_hw
     return s
 
 
-def mixed_pile(n=100_000, seed=0x5EED0003, width=400, pitch=0.30, floor_hw=62.0, wall_hh=60.0, substeps=4):
+def mixed_pile(n=100_000, seed=0x5EED0003, width=1000, pitch=0.30, floor_hw=None, wall_hh=40.0, substeps=4):
     """Config 3, the headline (BASELINE.json:9): 40 % circles, 30 % rects, 30 % capsules,
-    random initial rotation, on a lattice above the container."""
+    random initial rotation, on a lattice above the container.  The lattice is 1000 bodies
+    wide (SURVEY.md 8d guessed 400) so that the settled pile is ~50 layers deep: XPBD with
+    4 substeps cannot carry a deeper 2D pile without compressing it (Scenes)."""
+    if floor_hw is None:
+        floor_hw = width * pitch / 2.0 + 2.0
     u = splitmix64_uniform(seed, 7 * n)
     kind, u1, u2, u3, ang = u[:n], u[n:2 * n], u[2 * n:3 * n], u[3 * n:4 * n], u[4 * n:5 * n]
     types = np.where(kind < 0.4, SHAPE_CIRCLE, np.where(kind < 0.7, SHAPE_RECT, SHAPE_CAPSULE)).astype(np.uint32)
@@ -273,8 +291,9 @@ def chains(n_chains=1000, links=100, r=0.05, rest=0.12, substeps=4):
     return s
 
 
-def granular_slab(n=4_000_000, seed=0x5EED0005, width=8000, pitch=0.22, wall_hh=80.0, substeps=4, x_range=None):
-    """Config 5 (BASELINE.json:11): n circles on a `width`-wide lattice over a long floor."""
+def granular_slab(n=4_000_000, seed=0x5EED0005, width=40000, pitch=0.22, wall_hh=40.0, substeps=4):
+    """Config 5 (BASELINE.json:11): n circles on a `width`-wide lattice over a long floor
+    (100 rows at the default sizes, for the same reason as mixed_pile)."""
     u = splitmix64_uniform(seed, 3 * n)
     r = 0.05 + 0.05 * u[:n].astype(np.float64)
     pos = _lattice(n, width, pitch, 0.01, u[n:])
