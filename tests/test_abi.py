@@ -1,0 +1,111 @@
+"""CPU tests of the drop-in boundary: the built libsfx.so exports every symbol include/sfx.h
+declares, the ctypes layouts match the C header, and without a GPU the library fails loudly
+(no fallback).  No compute call is made here."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+import pytest
+
+from starframe_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sfx.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sfx_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_all_exported(libsfx):
+    syms = declared_symbols()
+    assert len(syms) >= 24
+    assert sorted(_abi.SFX_SYMBOLS) == syms, "starframe_amd/_abi.py symbol list out of date"
+    for s in syms:
+        assert hasattr(libsfx, s), f"libsfx.so does not export {s}"
+    assert libsfx.sfx_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    prog = r"""
+#include <stdio.h>
+#include <stddef.h>
+#include "sfx.h"
+int main(void) {
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sfx_config), sizeof(sfx_collider),
+         sizeof(sfx_material), sizeof(sfx_distance_constraint), sizeof(sfx_contact), sizeof(sfx_frame_stats),
+         sizeof(sfx_kernel_time), offsetof(sfx_config, flags), offsetof(sfx_frame_stats, color_count),
+         (size_t)SFX_K_CLASSES);
+  return 0;
+}
+"""
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        out = subprocess.check_output([exe]).decode().split()
+    sizes = list(map(int, out))
+    assert sizes[0] == C.sizeof(_abi.SfxConfig)
+    assert sizes[1] == _abi.collider_dtype.itemsize
+    assert sizes[2] == _abi.material_dtype.itemsize
+    assert sizes[3] == _abi.constraint_dtype.itemsize
+    assert sizes[4] == _abi.contact_dtype.itemsize
+    assert sizes[5] == C.sizeof(_abi.SfxFrameStats)
+    assert sizes[6] == C.sizeof(_abi.SfxKernelTime)
+    assert sizes[7] == _abi.SfxConfig.flags.offset
+    assert sizes[8] == _abi.SfxFrameStats.color_count.offset
+    assert sizes[9] == _abi.K_CLASSES
+
+
+def test_default_config(libsfx):
+    cfg = _abi.SfxConfig()
+    libsfx.sfx_default_config(C.byref(cfg))
+    assert cfg.struct_size == C.sizeof(_abi.SfxConfig)
+    assert cfg.substeps == 4 and abs(cfg.gravity[1] + 9.81) < 1e-6
+    assert cfg.color_rounds == 12 and cfg.launch_colors == 16
+
+
+def test_create_fails_loudly_without_gpu(libsfx):
+    """On a box without a GPU there is no CPU fallback behind the ABI."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    cfg = _abi.make_config()
+    h = C.c_void_p()
+    rc = libsfx.sfx_create(C.byref(cfg), C.byref(h))
+    assert rc == _abi.SFX_ERR_DEVICE and not h.value
+    assert b"no CPU fallback" in libsfx.sfx_last_error(None)
+    from starframe_amd.world import SfxError, World
+
+    with pytest.raises(SfxError):
+        World()
+
+
+def test_bad_config_rejected(libsfx):
+    cfg = _abi.make_config()
+    cfg.struct_size = 12
+    h = C.c_void_p()
+    assert libsfx.sfx_create(C.byref(cfg), C.byref(h)) == _abi.SFX_ERR_INVALID
+    assert libsfx.sfx_create(None, C.byref(h)) == _abi.SFX_ERR_INVALID
+    libsfx.sfx_destroy(None)  # no-op
+
+
+def test_product_package_does_not_touch_the_oracle():
+    """Nothing under starframe_amd/ may import, link or execute the oracle."""
+    pkg = os.path.join(ROOT, "starframe_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert not re.search(r'#\s*include\s*[<"][^>"]*oracle', text), f
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
+                assert "libsfx_oracle" not in text and "dlopen" not in text, f
+    out = subprocess.check_output(["ldd", _abi.LIBSFX_PATH]).decode()
+    assert "oracle" not in out

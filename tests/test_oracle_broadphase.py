@@ -1,0 +1,111 @@
+"""CPU tests of the oracle's broadphase and colouring restatement: the candidate pair set is
+a pure function of the AABBs (three independent enumerations agree and the grid parameters do
+not matter), and the colouring is a valid edge colouring."""
+import numpy as np
+import pytest
+
+from oracle.oracle import OracleWorld
+from starframe_amd import scenes
+from starframe_amd.scenes import SceneBuilder
+from tests.helpers import coloring_valid, colors_by_key
+
+DT = 1.0 / 60.0
+
+
+@pytest.mark.parametrize("n,seed,extent", [(200, 1, 3.0), (800, 2, 6.0), (2500, 3, 12.0)])
+def test_three_enumerations_agree(n, seed, extent):
+    w = OracleWorld.from_scene(scenes.random_soup(n, seed=seed, extent=extent))
+    w.broadphase(DT)
+    g, s = w.pairs(), w.pairs_sweep()
+    assert len(g) > n // 2
+    assert np.array_equal(g, s)
+    if n <= 800:
+        assert np.array_equal(g, w.pairs_brute())
+    assert np.all(np.diff(g.astype(np.int64)) > 0), "keys must be strictly ascending (no duplicates)"
+
+
+@pytest.mark.parametrize("kw", [dict(grid_log2=(2, 2)), dict(grid_log2=(3, 7)), dict(cell_size=0.9),
+                                dict(cell_size=3.0), dict(cell_size=0.2)])
+def test_pair_set_independent_of_grid(kw):
+    s = scenes.random_soup(600, seed=7, extent=5.0)
+    ref = OracleWorld.from_scene(s)
+    ref.broadphase(DT)
+    w = OracleWorld.from_scene(s, **kw)
+    w.broadphase(DT)
+    assert np.array_equal(w.pairs(), ref.pairs())
+    assert np.array_equal(w.pairs(), w.pairs_sweep())
+
+
+def test_negative_and_far_coordinates_wrap():
+    s = scenes.random_soup(400, seed=9, extent=4.0)
+    s.pos += np.float32((-1234.5, 987.25))
+    w = OracleWorld.from_scene(s, grid_log2=(3, 3))
+    w.broadphase(DT)
+    assert len(w.pairs()) > 200
+    assert np.array_equal(w.pairs(), w.pairs_sweep())
+
+
+def test_filters_group_mask_static():
+    b = SceneBuilder("filters")
+    b.circle((0, 0), 0.5)
+    b.circle((0.2, 0), 0.5, group=3)
+    b.circle((0.4, 0), 0.5, group=3)                  # same group as body 1: filtered
+    b.circle((0.1, 0.1), 0.5, category=2, mask=0xFFFFFFFE)  # does not collide with category 1
+    b.circle((0.3, 0.1), 0.5, category=2, mask=0xFFFFFFFF)
+    b.static_rect((0, -1), 5, 0.6)
+    b.static_rect((0, -1.2), 5, 0.6)                 # static-static: filtered
+    b.particle((0, 0))                               # no collider
+    w = OracleWorld.from_scene(b.build())
+    w.broadphase(DT)
+    keys = set(int(k) for k in w.pairs())
+    key = lambda a, c: (a << 32) | c
+    assert key(1, 2) not in keys
+    assert key(0, 3) not in keys and key(1, 3) not in keys and key(2, 3) not in keys
+    assert key(3, 4) in keys        # both category 2, 4's mask has bit 2, 3's mask has bit 2
+    assert key(0, 4) in keys        # 4 is category 2 with a full mask, 0 accepts everything
+    assert key(5, 6) not in keys
+    assert all((k >> 32) != 7 and (k & 0xFFFFFFFF) != 7 for k in keys)
+    assert key(0, 1) in keys and key(0, 5) in keys
+
+
+@pytest.mark.parametrize("rounds", [1, 3, 12])
+def test_colouring_is_valid_and_deterministic(rounds):
+    s = scenes.random_soup(1500, seed=4, extent=7.0)
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    w = OracleWorld.from_scene(s, color_rounds=rounds)
+    w.broadphase(DT)
+    k1, c1 = w.pair_colors()
+    assert coloring_valid(k1, c1, dyn)
+    st = w.stats()
+    assert st.n_colors <= 40
+    assert sum(st.color_count) == st.n_pairs
+    if rounds == 1:
+        assert st.n_leftover > 0  # the serial finish did real work
+    w2 = OracleWorld.from_scene(s, color_rounds=rounds)
+    w2.broadphase(DT)
+    k2, c2 = w2.pair_colors()
+    assert np.array_equal(k1, k2) and np.array_equal(c1, c2)
+
+
+def test_chain_joint_colouring_two_colours_possible():
+    s = scenes.chains(n_chains=5, links=40)
+    w = OracleWorld.from_scene(s)
+    perm, col = w.joint_order()
+    assert sorted(perm.tolist()) == list(range(200))
+    assert np.all(np.diff(col.astype(int)) >= 0), "colour-major order"
+    # validity: within a colour no body twice
+    for c in np.unique(col):
+        idx = perm[col == c]
+        ends = np.concatenate([s.constraints["body_a"][idx], s.constraints["body_b"][idx]])
+        ends = ends[ends != 0xFFFFFFFF]
+        assert len(np.unique(ends)) == len(ends)
+    assert w.stats().n_joint_colors <= 8
+
+
+def test_auto_grid_and_cell_resolution():
+    s = scenes.random_soup(300, seed=1)
+    w = OracleWorld.from_scene(s)
+    rc = w.resolved_config()
+    assert rc.cell_size > 0.4
+    assert rc.grid_log2[0] == rc.grid_log2[1] == 5
+    assert rc.max_pairs == 12 * s.n

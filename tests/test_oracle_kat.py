@@ -1,0 +1,276 @@
+"""Known-answer tests that pin the CPU oracle (oracle/sfx_oracle.c) to closed-form results.
+
+The reference implementation is unavailable (PARITY UNPINNED), so these analytic
+cases are what anchors the oracle: contact geometry from elementary geometry, one XPBD step of
+a distance constraint from the closed-form delta-lambda (Mueller et al. 2020 eq. 4-6 with
+alpha~ = alpha / h^2), Coulomb friction stopping distances, free fall under semi-implicit Euler.
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle.oracle import ORDER_COLORED, ORDER_SEQUENTIAL, OracleWorld
+from starframe_amd._abi import WORLD_BODY
+from starframe_amd.scenes import SceneBuilder
+
+DT = 1.0 / 60.0
+
+
+def world(builder, **kw):
+    return OracleWorld.from_scene(builder.build(), **kw)
+
+
+def test_circle_circle_contact():
+    b = SceneBuilder("cc")
+    b.circle((0.0, 0.0), 0.5)
+    b.circle((0.6, 0.8), 0.7)  # centre distance exactly 1.0
+    c = world(b).contact_pair(0, 1)
+    assert c["count"] == 1
+    np.testing.assert_allclose(c["normal"], (0.6, 0.8), rtol=1e-6)
+    np.testing.assert_allclose(c["depth"][0], 0.5 + 0.7 - 1.0, rtol=1e-5)
+    np.testing.assert_allclose(c["point_a"][0], (0.3, 0.4), rtol=1e-6)
+    np.testing.assert_allclose(c["point_b"][0], (0.6 - 0.42, 0.8 - 0.56), rtol=1e-5)
+    # separated circles: nothing
+    b = SceneBuilder("cc2")
+    b.circle((0.0, 0.0), 0.5)
+    b.circle((1.3, 0.0), 0.7)
+    assert world(b).contact_pair(0, 1)["count"] == 0
+
+
+def test_box_on_box_two_points():
+    b = SceneBuilder("bb")
+    b.rect((0.0, 0.0), 1.0, 0.5)
+    b.rect((0.5, 0.9), 0.5, 0.5)  # overlaps the lower box by 0.1
+    c = world(b).contact_pair(0, 1)
+    assert c["count"] == 2
+    np.testing.assert_allclose(c["normal"], (0.0, 1.0), atol=1e-6)
+    np.testing.assert_allclose(c["depth"], (0.1, 0.1), rtol=1e-5)
+    xs = sorted(c["point_b"][:, 0])
+    np.testing.assert_allclose(xs, (0.0, 1.0), atol=1e-6)  # clipped to the upper box's width
+    np.testing.assert_allclose(c["point_b"][:, 1], (0.4, 0.4), atol=1e-6)
+    np.testing.assert_allclose(c["point_a"][:, 1], (0.5, 0.5), atol=1e-6)
+    # swapped argument order flips the normal
+    c2 = world(b).contact_pair(1, 0)
+    np.testing.assert_allclose(c2["normal"], (0.0, -1.0), atol=1e-6)
+
+
+def test_box_corner_into_face_single_point():
+    b = SceneBuilder("corner")
+    b.rect((0.0, 0.0), 2.0, 0.5)
+    b.rect((0.0, 0.5 + math.sqrt(0.5) - 0.05), 0.5, 0.5, angle=math.pi / 4)  # corner 0.05 deep
+    c = world(b).contact_pair(0, 1)
+    assert c["count"] == 1
+    np.testing.assert_allclose(c["normal"], (0.0, 1.0), atol=1e-6)
+    np.testing.assert_allclose(c["depth"][0], 0.05, rtol=1e-4)
+    np.testing.assert_allclose(c["point_b"][0], (0.0, 0.45), atol=1e-5)
+
+
+def test_capsule_circle_and_capsule_end():
+    b = SceneBuilder("cap")
+    b.capsule((0.0, 0.0), 1.0, 0.2)          # segment (-1,0)-(1,0), radius 0.2
+    b.circle((0.3, 0.45), 0.3)               # above the segment interior
+    b.circle((1.3, 0.4), 0.35)               # beyond the end cap: distance to (1,0) is 0.5
+    w = world(b)
+    c = w.contact_pair(0, 1)
+    assert c["count"] == 1
+    np.testing.assert_allclose(c["normal"], (0.0, 1.0), atol=1e-6)
+    np.testing.assert_allclose(c["depth"][0], 0.2 + 0.3 - 0.45, rtol=1e-5)
+    c = w.contact_pair(0, 2)
+    assert c["count"] == 1
+    np.testing.assert_allclose(c["normal"], (0.6, 0.8), rtol=1e-5)
+    np.testing.assert_allclose(c["depth"][0], 0.2 + 0.35 - 0.5, rtol=1e-4)
+
+
+def test_capsule_capsule_end_to_end_vertex_path():
+    b = SceneBuilder("capcap")
+    b.capsule((0.0, 0.0), 1.0, 0.2)
+    b.capsule((2.3, 0.0), 1.0, 0.2)   # collinear, end points 0.3 apart, radii sum 0.4
+    c = world(b).contact_pair(0, 1)
+    assert c["count"] == 1
+    np.testing.assert_allclose(c["normal"], (1.0, 0.0), atol=1e-6)
+    np.testing.assert_allclose(c["depth"][0], 0.1, rtol=1e-4)
+
+
+def test_circle_inside_rect_pushes_through_nearest_face():
+    b = SceneBuilder("inside")
+    b.rect((0.0, 0.0), 1.0, 1.0)
+    b.circle((0.8, 0.1), 0.1)   # centre inside, nearest face is +x at distance 0.2
+    c = world(b).contact_pair(0, 1)
+    assert c["count"] == 1
+    np.testing.assert_allclose(c["normal"], (1.0, 0.0), atol=1e-6)
+    np.testing.assert_allclose(c["depth"][0], 0.1 + 0.2, rtol=1e-5)
+
+
+def test_rounded_rect_circle_corner_region():
+    b = SceneBuilder("round")
+    b.rect((0.0, 0.0), 0.5, 0.5, rounding=0.1)
+    b.circle((0.5 + 0.3, 0.5 + 0.4), 0.45)   # 0.5 from the core corner (0.5, 0.5)
+    c = world(b).contact_pair(0, 1)
+    assert c["count"] == 1
+    np.testing.assert_allclose(c["normal"], (0.6, 0.8), rtol=1e-5)
+    np.testing.assert_allclose(c["depth"][0], 0.1 + 0.45 - 0.5, rtol=1e-4)
+
+
+def test_polygon_triangle_on_ground():
+    b = SceneBuilder("tri")
+    b.static_rect((0.0, -0.5), 5.0, 0.5)
+    b.poly((0.0, 0.0), [(-0.5, -0.3), (0.5, -0.3), (0.0, 0.6)])
+    s = b.build()
+    # put the triangle's flat bottom edge 0.02 into the ground
+    low = s.poly_verts[:, 1].min()
+    s.pos[1] = (0.0, -low - 0.02)
+    c = OracleWorld.from_scene(s).contact_pair(0, 1)
+    assert c["count"] == 2
+    np.testing.assert_allclose(c["normal"], (0.0, 1.0), atol=1e-6)
+    np.testing.assert_allclose(c["depth"], (0.02, 0.02), rtol=1e-3)
+
+
+def test_free_fall_semi_implicit_euler():
+    b = SceneBuilder("fall", substeps=4)
+    b.circle((0.0, 10.0), 0.1)
+    w = world(b)
+    frames = 30
+    for _ in range(frames):
+        w.step(DT, ORDER_SEQUENTIAL)
+    h, k = DT / 4, frames * 4
+    v = -9.81 * h * k
+    y = 10.0 - 9.81 * h * h * k * (k + 1) / 2
+    pos, _ = w.poses()
+    vel, _ = w.velocities()
+    # f32: the velocity is re-derived from pose differences near y = 10 every substep
+    assert abs(pos[0, 1] - y) < 5e-3
+    assert abs(vel[0, 1] - v) < 2e-2
+
+
+def test_free_spin_keeps_angular_velocity():
+    """derive_velocities is the exact inverse of the first-order rotor update."""
+    b = SceneBuilder("spin", substeps=4)
+    b.rect((0.0, 0.0), 0.3, 0.2, angvel=7.0)
+    w = world(b, gravity=(0.0, 0.0))
+    for _ in range(60):
+        w.step(DT)
+    _, rot = w.poses()
+    _, av = w.velocities()
+    assert abs(av[0] - 7.0) < 1e-3
+    assert abs(np.hypot(*rot[0]) - 1.0) < 1e-6
+    # angle advanced by atan(h w) per substep
+    ang = math.atan2(rot[0, 1], rot[0, 0]) % (2 * math.pi)
+    exp = (240 * math.atan(7.0 * DT / 4)) % (2 * math.pi)
+    assert abs(ang - exp) < 1e-3
+
+
+@pytest.mark.parametrize("compliance", [0.0, 1e-3])
+def test_distance_constraint_single_step_closed_form(compliance):
+    b = SceneBuilder("dist", substeps=1)
+    b.circle((0.0, 0.0), 0.05, density=1.0)
+    b.circle((1.5, 0.0), 0.05, density=3.0)
+    b.distance(0, 1, rest=1.0, compliance=compliance)
+    s = b.build()
+    w = OracleWorld.from_scene(s, gravity=(0.0, 0.0))
+    w.step(DT, ORDER_SEQUENTIAL)
+    w1, w2 = float(s.inv_mass[0]), float(s.inv_mass[1])
+    C = 0.5
+    dl = C / (w1 + w2 + compliance / DT**2)
+    pos, _ = w.poses()
+    np.testing.assert_allclose(pos[0, 0], 0.0 + dl * w1, rtol=1e-5)
+    np.testing.assert_allclose(pos[1, 0], 1.5 - dl * w2, rtol=1e-5)
+    if compliance == 0.0:
+        np.testing.assert_allclose(pos[1, 0] - pos[0, 0], 1.0, rtol=1e-5)
+
+
+def test_pendulum_keeps_length_and_swings():
+    b = SceneBuilder("pend", substeps=8)
+    b.circle((1.0, 0.0), 0.05)
+    b.distance(WORLD_BODY, 0, anchor_a=(0.0, 0.0), rest=1.0)
+    w = world(b)
+    ymin = 0.0
+    for _ in range(120):
+        w.step(DT)
+        pos, _ = w.poses()
+        assert abs(np.hypot(*pos[0]) - 1.0) < 2e-3
+        ymin = min(ymin, pos[0, 1])
+    assert ymin < -0.95  # reached the bottom of the swing
+
+
+def test_sliding_box_stops_at_coulomb_distance():
+    b = SceneBuilder("slide", substeps=10, materials=[(0.0, 0.5, 0.4)])
+    b.rect((0.0, 0.5), 0.5, 0.5, vel=(1.0, 0.0))
+    b.static_rect((0.0, -0.5), 40.0, 0.5)
+    w = world(b)
+    for _ in range(90):
+        w.step(DT, ORDER_SEQUENTIAL)
+    pos, rot = w.poses()
+    vel, _ = w.velocities()
+    assert abs(vel[0, 0]) < 1e-4
+    assert abs(pos[0, 0] - 1.0 / (2 * 0.4 * 9.81)) < 0.01
+    assert abs(rot[0, 1]) < 1e-4
+
+
+@pytest.mark.parametrize("deg,slides", [(20, False), (35, True)])
+def test_box_on_slope_static_and_dynamic_friction(deg, slides):
+    th = math.radians(deg)
+    n = np.array([-math.sin(th), math.cos(th)])
+    b = SceneBuilder("slope", substeps=4, materials=[(0.0, 0.5, 0.4)])
+    b.rect(tuple(n * 0.5), 0.5, 0.5, angle=th)
+    b.static_rect(tuple(-0.5 * n), 30.0, 0.5, angle=th)
+    w = world(b)
+    p0 = w.poses()[0][0].copy()
+    for _ in range(120):
+        w.step(DT, ORDER_SEQUENTIAL)
+    moved = float(np.linalg.norm(w.poses()[0][0] - p0))
+    if slides:
+        expect = 0.5 * 9.81 * (math.sin(th) - 0.4 * math.cos(th)) * 2.0**2
+        assert abs(moved - expect) / expect < 0.05
+    else:
+        assert moved < 1e-4
+
+
+def test_restitution_bounce():
+    b = SceneBuilder("bounce", substeps=8, materials=[(0.5, 0.0, 0.0)])
+    b.circle((0.0, 1.0), 0.1)
+    b.static_rect((0.0, -0.5), 5.0, 0.5)
+    w = world(b)
+    vmin, vmax_after = 0.0, 0.0
+    hit = False
+    for _ in range(90):
+        w.step(DT)
+        vy = float(w.velocities()[0][0, 1])
+        if not hit:
+            vmin = min(vmin, vy)
+            hit = vy > 0.5
+        if hit:
+            vmax_after = max(vmax_after, vy)
+    assert hit
+    assert abs(vmax_after / -vmin - 0.5) < 0.05
+
+
+def test_box_stack_rests_without_creep():
+    b = SceneBuilder("stack", substeps=4)
+    b.rect((0.0, 0.5), 0.5, 0.5)
+    b.rect((0.3, 1.5), 0.5, 0.5)
+    b.rect((0.0, 2.5), 0.5, 0.5)
+    b.static_rect((0.0, -0.5), 40.0, 0.5)
+    w = world(b)
+    for _ in range(300):
+        w.step(DT, ORDER_SEQUENTIAL)
+    pos, rot = w.poses()
+    np.testing.assert_allclose(pos[:3, 0], (0.0, 0.3, 0.0), atol=2e-3)
+    np.testing.assert_allclose(pos[:3, 1], (0.5, 1.5, 2.5), atol=5e-3)
+    assert np.abs(rot[:3, 1]).max() < 1e-3
+    assert w.stats().kinetic_energy < 1e-6
+
+
+def test_pyramid_stands():
+    from starframe_amd import scenes
+
+    for order in (ORDER_SEQUENTIAL, ORDER_COLORED):
+        w = OracleWorld.from_scene(scenes.pyramid(base=12))
+        for _ in range(240):
+            w.step(DT, order)
+        pos, rot = w.poses()
+        st = w.stats()
+        assert pos[:-1, 1].max() > 11.45
+        assert st.kinetic_energy < 1e-3
+        assert st.max_depth < 5e-3
+        assert np.abs(rot[:-1, 1]).max() < 5e-3
