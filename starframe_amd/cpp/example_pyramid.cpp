@@ -1,0 +1,27 @@
+// Example / link test for starframe_physics.hpp: the sandbox-style box pyramid.
+//   g++ -std=c++17 example_pyramid.cpp -L../csrc -lsfx -Wl,-rpath,'$ORIGIN/../csrc' -o example_pyramid
+#include <cstdio>
+
+#include "starframe_physics.hpp"
+
+int main() {
+    sf::PhysicsConfig cfg;
+    cfg.substeps = 10;
+    sf::Physics physics(cfg);
+    const sf::Collider box = sf::Collider::new_rect(1.0f, 1.0f);
+    const int base = 12;
+    for (int row = 0; row < base; ++row)
+        for (int j = 0; j < base - row; ++j)
+            physics.add(sf::Body::new_dynamic(box, 1.0f), box, sf::Pose{{(j - (base - row - 1) / 2.0f) * 1.05f, 0.5f + row}, 0.0f});
+    const sf::Collider ground = sf::Collider::new_rect(80.0f, 1.0f);
+    physics.add(sf::Body::new_static(), ground, sf::Pose{{0.0f, -0.5f}, 0.0f});
+    for (int frame = 0; frame < 240; ++frame) physics.tick(1.0f / 60.0f);
+    std::vector<float> pos, rot;
+    physics.read_poses(pos, rot);
+    float top = 0;
+    for (size_t k = 0; k + 1 < physics.body_count(); ++k) top = pos[2 * k + 1] > top ? pos[2 * k + 1] : top;
+    const sfx_frame_stats st = physics.stats();
+    std::printf("pyramid: %zu bodies, top at %.3f (ideal %.1f), KE %.2e, %u pairs, %u colours\n", physics.body_count(), top,
+                base - 0.5f, st.kinetic_energy, st.n_pairs, st.n_colors);
+    return top > base - 0.6f ? 0 : 1;
+}

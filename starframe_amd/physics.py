@@ -1,0 +1,131 @@
+"""Host-side mirror of starframe's physics API shape over the libsfx C ABI (Python harness).
+
+BASELINE.json:5 names the API surface that stays on the host: a physics config, body / collider /
+material components and the per-frame tick entry point.  Upstream's exact names are not
+verifiable (its source is absent), so these follow SURVEY.md's [RECALL] hints.  The C++
+equivalent is starframe_amd/cpp/starframe_physics.hpp; the Rust one bindings/rust/.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._abi import WORLD_BODY
+from .scenes import SceneBuilder
+from .world import World
+
+
+@dataclass
+class PhysicsConfig:
+    substeps: int = 4
+    gravity: tuple = (0.0, -9.81)
+    aabb_margin: float = 0.01
+    max_depenetration_velocity: float = 3.0
+    device: int = 0
+
+
+@dataclass(frozen=True)
+class Material:
+    restitution: float = 0.1
+    static_friction: float = 0.5
+    dynamic_friction: float = 0.4
+
+
+@dataclass
+class Collider:
+    kind: str
+    a: float = 0.0
+    b: float = 0.0
+    r: float = 0.0
+    verts: tuple = ()
+    material: Material = Material()
+    category: int = 1
+    mask: int = 0xFFFFFFFF
+    group: int = 0
+
+    @staticmethod
+    def circle(r, **kw):
+        return Collider("circle", r=r, **kw)
+
+    @staticmethod
+    def rect(width, height, rounding=0.0, **kw):
+        return Collider("rect", a=0.5 * width - rounding, b=0.5 * height - rounding, r=rounding, **kw)
+
+    @staticmethod
+    def capsule(length, radius, **kw):
+        return Collider("capsule", a=0.5 * length, r=radius, **kw)
+
+    @staticmethod
+    def polygon(verts, rounding=0.0, **kw):
+        return Collider("poly", r=rounding, verts=tuple(map(tuple, verts)), **kw)
+
+
+@dataclass
+class Body:
+    kind: str
+    density: float = 1.0
+
+    @staticmethod
+    def dynamic(collider=None, density=1.0):
+        return Body("dynamic", density)
+
+    @staticmethod
+    def static():
+        return Body("static", 0.0)
+
+
+class Physics:
+    """Collects components, uploads once, then `tick(dt)` per frame."""
+
+    def __init__(self, config=None):
+        self.config = config or PhysicsConfig()
+        self._b = SceneBuilder("physics", substeps=self.config.substeps, materials=[])
+        self._mats = {}
+        self._world = None
+
+    def _mat(self, m):
+        if m not in self._mats:
+            self._mats[m] = len(self._b.materials)
+            self._b.materials.append((m.restitution, m.static_friction, m.dynamic_friction))
+        return self._mats[m]
+
+    def add(self, body, collider, position, angle=0.0, velocity=(0.0, 0.0), angular_velocity=0.0):
+        if self._world is not None:
+            raise RuntimeError("add bodies before the first tick")
+        kw = dict(angle=angle, material=self._mat(collider.material), category=collider.category,
+                  mask=collider.mask, group=collider.group)
+        dens = body.density if body.kind == "dynamic" else 0.0
+        dyn = dict(density=dens, vel=velocity, angvel=angular_velocity)
+        if collider.kind == "circle":
+            return self._b.circle(position, collider.r, **dyn, **kw)
+        if collider.kind == "rect":
+            return self._b.rect(position, collider.a, collider.b, rounding=collider.r, **dyn, **kw)
+        if collider.kind == "capsule":
+            return self._b.capsule(position, collider.a, collider.r, **dyn, **kw)
+        if collider.kind == "poly":
+            return self._b.poly(position, collider.verts, rounding=collider.r, **dyn, **kw)
+        raise ValueError(collider.kind)
+
+    def add_distance_constraint(self, a, b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), rest_length=None, compliance=0.0):
+        self._b.distance(WORLD_BODY if a is None else a, WORLD_BODY if b is None else b, anchor_a, anchor_b,
+                         rest_length, compliance)
+
+    def tick(self, frame_dt):
+        """The per-frame tick entry point: asynchronous, one sfx_step."""
+        if self._world is None:
+            if not self._b.materials:
+                self._mat(Material())
+            c = self.config
+            self._world = World.from_scene(self._b.build(), substeps=c.substeps, gravity=c.gravity,
+                                           aabb_margin=c.aabb_margin, device=c.device,
+                                           max_depenetration_velocity=c.max_depenetration_velocity)
+        self._world.step(frame_dt)
+
+    def poses(self):
+        pos, rot = self._world.poses()
+        return pos, np.arctan2(rot[:, 1], rot[:, 0])
+
+    def velocities(self):
+        return self._world.velocities()
+
+    def stats(self):
+        return self._world.stats()
