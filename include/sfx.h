@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 1u
+#define SFX_ABI_VERSION 2u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -51,6 +51,11 @@ typedef enum sfx_shape_type {
 #define SFX_MAX_POLY_VERTS 8u
 #define SFX_WORLD_BODY 0xFFFFFFFFu /* constraint end attached to the world */
 #define SFX_MAX_COLORS 64u
+/* solver tiles (DESIGN.md "Contract / tiles"): a tile that owns more candidate pairs, or whose
+ * 2x2 tile block holds more grid-sorted colliders, hands its pairs to the fallback list */
+#define SFX_TILE_MAX_PAIRS 2048u
+#define SFX_TILE_MAX_BODIES 512u
+#define SFX_FALLBACK_TILE 0xFFFFFFFFu
 
 /* physics config struct (BASELINE.json:5 "physics config") */
 typedef struct sfx_config {
@@ -65,11 +70,13 @@ typedef struct sfx_config {
     uint32_t grid_log2[2];  /* wrapped grid is 2^gx by 2^gy cells; 0 = auto          */
     uint32_t max_pairs;     /* candidate pair capacity; 0 = 12 * bodies              */
     uint32_t color_rounds;  /* parallel colouring rounds before the serial finish; 0 = 12 */
-    uint32_t launch_colors; /* colours that get their own launch; the rest share a
-                               single-workgroup tail kernel; 0 = 16                  */
+    uint32_t tile_cells;    /* solver tile edge in grid cells: 1, 2, 4 or 8; 0 = 1        */
     float restitution_threshold; /* restitution is dropped when |vn_pre| <= this * |g| * h; 0 = 2.0 */
     float max_depenetration_velocity; /* a contact corrects at most this * h of penetration per
                                substep (m/s); 0 = 3.0; negative = unlimited            */
+    float speculative_margin; /* the narrowphase keeps contact points up to this far apart
+                               (negative depth; they only push once they penetrate);
+                               0 = 0.005 m; negative = none                              */
     float linear_damping;   /* 1/s: v *= 1 / (1 + h * c) every substep; 0 = none        */
     float angular_damping;  /* 1/s, same for the angular velocity                       */
     uint32_t flags;         /* SFX_CFG_* */
@@ -122,25 +129,28 @@ typedef struct sfx_frame_stats {
     uint32_t n_small;        /* colliders sorted into the grid               */
     uint32_t n_large;        /* colliders tested against everything          */
     uint32_t n_pairs;        /* candidate pairs of the last tick             */
-    uint32_t n_colors;       /* colours used by the candidate-pair graph     */
-    uint32_t n_leftover;     /* pairs coloured by the serial finish          */
+    uint32_t n_colors;       /* most colours used by any tile / the fallback list */
+    uint32_t n_leftover;     /* pairs coloured by the serial finishes        */
     uint32_t n_manifolds;    /* pairs that touched in the last substep       */
     uint32_t n_manifolds2;   /* ... of which with two contact points         */
     uint32_t n_contacts;     /* active contact points of the last substep    */
     uint32_t n_joint_colors;
     uint32_t overflow;       /* != 0: a capacity was exceeded this tick      */
     uint32_t launches;       /* kernel launches issued by the last tick      */
+    uint32_t n_tiles;        /* tiles that own pairs (solved in LDS)         */
+    uint32_t n_fallback;     /* pairs on the fallback list                   */
+    uint32_t max_tile_pairs; /* most pairs owned by one tile                 */
+    uint32_t max_tile_bodies;/* most grid-sorted colliders in one tile block */
     float max_depth;         /* deepest penetration seen in the last substep */
     float kinetic_energy;    /* sum 1/2 m v^2 + 1/2 I w^2 over dynamic bodies */
-    uint32_t color_count[SFX_MAX_COLORS];
+    uint32_t color_count[SFX_MAX_COLORS]; /* pairs per colour, summed over tiles + fallback */
 } sfx_frame_stats;
 
 /* per kernel-class device time, filled while profiling is on */
 typedef enum sfx_kernel_class {
     SFX_K_AABB_COUNT = 0, SFX_K_SCAN, SFX_K_SCATTER, SFX_K_PAIR_COUNT, SFX_K_PAIR_FILL,
-    SFX_K_COLOR, SFX_K_COLOR_SORT, SFX_K_INTEGRATE, SFX_K_SOLVE_JOINTS, SFX_K_SOLVE_POS,
-    SFX_K_SOLVE_POS_TAIL, SFX_K_DERIVE_VEL, SFX_K_SOLVE_VEL, SFX_K_SOLVE_VEL_TAIL,
-    SFX_K_STATS, SFX_K_HALO, SFX_K_CLASSES
+    SFX_K_TILE_LIST, SFX_K_COLOR, SFX_K_INTEGRATE, SFX_K_SOLVE_JOINTS, SFX_K_SOLVE_POS,
+    SFX_K_DERIVE_VEL, SFX_K_SOLVE_VEL, SFX_K_STATS, SFX_K_HALO, SFX_K_CLASSES
 } sfx_kernel_class;
 
 typedef struct sfx_kernel_time {
@@ -186,8 +196,9 @@ int sfx_download_velocities(sfx_world* w, float* vel, float* angvel);
 int sfx_debug_aabbs(sfx_world* w, float* out);
 /* candidate pairs of the last tick as ascending keys (a << 32 | b), a < b */
 int sfx_debug_pairs(sfx_world* w, uint64_t* keys, size_t cap, size_t* n);
-/* the same pairs in device (colour-sorted) order with their colour */
-int sfx_debug_pair_colors(sfx_world* w, uint64_t* keys, uint8_t* colors, size_t cap, size_t* n);
+/* the same pairs in device order with their owner tile (SFX_FALLBACK_TILE = fallback list)
+ * and their colour inside that tile / list; tiles may be NULL */
+int sfx_debug_pair_colors(sfx_world* w, uint64_t* keys, uint8_t* colors, uint32_t* tiles, size_t cap, size_t* n);
 /* runs only the broadphase + colouring of a tick (no substeps), for dt = frame_dt */
 int sfx_debug_broadphase(sfx_world* w, float frame_dt);
 /* narrowphase of every candidate pair at the current poses, in sfx_debug_pairs order */

@@ -55,7 +55,7 @@ def load():
     for n in ("sfo_pairs_grid", "sfo_pairs_sweep", "sfo_pairs_brute"):
         getattr(lib, n).argtypes = [vp, vp, C.c_size_t]
         getattr(lib, n).restype = C.c_size_t
-    lib.sfo_pair_colors.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.sfo_pair_colors.argtypes = [vp, vp, vp, vp, C.c_size_t]
     lib.sfo_pair_colors.restype = C.c_size_t
     lib.sfo_contacts.argtypes = [vp, vp, C.c_size_t]
     lib.sfo_contacts.restype = C.c_size_t
@@ -135,8 +135,9 @@ class OracleWorld(WorldBase):
         cap = max(int(self.stats().n_pairs), 1)
         keys = np.empty(cap, np.uint64)
         col = np.empty(cap, np.uint8)
-        n = self.lib.sfo_pair_colors(self.handle, vptr(keys), vptr(col), cap)
-        return keys[:n], col[:n]
+        tiles = np.empty(cap, np.uint32)
+        n = self.lib.sfo_pair_colors(self.handle, vptr(keys), vptr(col), vptr(tiles), cap)
+        return keys[:n], col[:n], tiles[:n]
 
     def contacts(self):
         cap = max(int(self.stats().n_pairs), 1)

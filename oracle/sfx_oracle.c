@@ -22,6 +22,7 @@
 
 #define EPS_LEN 1e-9f
 #define NO_COLOR 0xFFu
+#define SFO_FALLBACK 0xFFFFFFFFu
 
 typedef struct { float x, y; } v2;
 
@@ -64,10 +65,18 @@ struct sfo_world {
     uint32_t n_small, n_large;
     uint32_t max_pairs, n_pairs;
     uint32_t *pa, *pb; /* emission order */
-    uint8_t* color;
+    int32_t *ccx, *ccy;  /* home cell of every small collider (last broadphase) */
+    uint8_t* is_small;   /* sorted into the grid (else: large list or no collider) */
+    uint32_t tl;         /* log2 of the tile edge in cells */
+    uint8_t* color;      /* colour of the pair inside its batch (tile or fallback list) */
+    uint32_t* owner;     /* wrapped owner tile of the pair, SFO_FALLBACK for the fallback list */
     uint32_t n_colors, n_leftover, overflow;
+    uint32_t n_tiles, n_fallback, max_tile_pairs, max_tile_bodies;
     uint32_t color_count[SFX_MAX_COLORS];
     uint32_t* order;   /* processing order (indices into pa/pb) */
+    uint32_t* batch_end; /* order[] is cut into batches: batch k = [batch_end[k-1], batch_end[k]) */
+    uint32_t n_batches, n_order;
+    int order_valid;
     pair_rec* rec;
     uint32_t n_contacts, n_manifolds, n_manifolds2;
     float max_depth;
@@ -79,12 +88,17 @@ static void resolve_defaults(sfx_config* c) {
     if (c->substeps == 0) c->substeps = 1;
     if (c->color_rounds == 0) c->color_rounds = 12;
     if (c->color_rounds > 60) c->color_rounds = 60;
-    if (c->launch_colors == 0) c->launch_colors = 16;
+    if (c->tile_cells == 0) c->tile_cells = 1;
+    if (c->tile_cells >= 8) c->tile_cells = 8;
+    else if (c->tile_cells >= 4) c->tile_cells = 4;
+    else if (c->tile_cells >= 2) c->tile_cells = 2;
     if (c->restitution_threshold == 0.0f) c->restitution_threshold = 2.0f;
     if (c->vel_pad_max == 0.0f) c->vel_pad_max = 0.03f;
     if (c->max_depenetration_velocity == 0.0f) c->max_depenetration_velocity = 3.0f;
     if (c->max_depenetration_velocity < 0.0f) c->max_depenetration_velocity = INFINITY;
     if (c->vel_pad_max < 0.0f) c->vel_pad_max = 0.0f;
+    if (c->speculative_margin == 0.0f) c->speculative_margin = 0.005f;
+    if (c->speculative_margin < 0.0f) c->speculative_margin = 0.0f;
 }
 
 sfo_world* sfo_create(const sfx_config* cfg) {
@@ -101,6 +115,7 @@ void sfo_destroy(sfo_world* w) {
     free(w->inv_inertia); free(w->prev_pos); free(w->prev_rot); free(w->col); free(w->poly);
     free(w->poly_nrm); free(w->mats); free(w->joints); free(w->joint_perm); free(w->joint_color);
     free(w->aabb); free(w->pa); free(w->pb); free(w->color); free(w->order); free(w->rec);
+    free(w->ccx); free(w->ccy); free(w->is_small); free(w->owner); free(w->batch_end);
     free(w);
 }
 
@@ -153,7 +168,7 @@ static uint32_t ceil_log2(uint32_t v) {
 }
 
 /* [DESIGN] DESIGN.md "Contract / grid": cell = 1.25 * (largest dynamic diameter + 2 (margin + vel_pad_max));
- * grid = smallest square power-of-two torus with >= 2 cells per body, 4..4096 per side. */
+ * grid = smallest square power-of-two torus with >= 2 cells per body, (4 tiles)..4096 per side. */
 static void resolve_grid(sfo_world* w) {
     float cell = w->cfg.cell_size;
     if (!(cell > 0.0f)) {
@@ -171,12 +186,13 @@ static void resolve_grid(sfo_world* w) {
     if (gx == 0 || gy == 0) {
         uint32_t side = (uint32_t)ceil(sqrt(2.0 * (double)(w->n ? w->n : 1)));
         uint32_t l = ceil_log2(side);
-        if (l < 2) l = 2;
         if (l > 12) l = 12;
         gx = gy = l;
     }
-    if (gx < 2) gx = 2;
-    if (gy < 2) gy = 2;
+    /* at least 4 tiles per side, so that the 2x2 tile blocks of one phase never meet on the torus */
+    w->tl = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : w->cfg.tile_cells == 2 ? 1u : 0u;
+    if (gx < w->tl + 2) gx = w->tl + 2;
+    if (gy < w->tl + 2) gy = w->tl + 2;
     if (gx > 12) gx = 12;
     if (gy > 12) gy = 12;
     w->gxl = gx; w->gyl = gy;
@@ -206,6 +222,7 @@ int sfo_upload_colliders(sfo_world* w, uint32_t n, const sfx_collider* colliders
     }
     resolve_grid(w);
     free(w->aabb); free(w->pa); free(w->pb); free(w->color); free(w->order); free(w->rec);
+    free(w->ccx); free(w->ccy); free(w->is_small); free(w->owner); free(w->batch_end);
     w->max_pairs = w->cfg.max_pairs ? w->cfg.max_pairs : 12u * n;
     if (w->max_pairs < 1024u) w->max_pairs = 1024u;
     w->aabb = (float*)calloc(4u * n + 4, sizeof(float));
@@ -214,7 +231,12 @@ int sfo_upload_colliders(sfo_world* w, uint32_t n, const sfx_collider* colliders
     w->color = (uint8_t*)malloc(w->max_pairs);
     w->order = (uint32_t*)malloc(w->max_pairs * sizeof(uint32_t));
     w->rec = (pair_rec*)calloc(w->max_pairs, sizeof(pair_rec));
-    w->n_pairs = 0;
+    w->owner = (uint32_t*)malloc(w->max_pairs * sizeof(uint32_t));
+    w->batch_end = (uint32_t*)malloc(((size_t)w->max_pairs + 2) * sizeof(uint32_t));
+    w->ccx = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
+    w->ccy = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
+    w->is_small = (uint8_t*)calloc(n ? n : 1, 1);
+    w->n_pairs = 0; w->order_valid = 0;
     return SFX_OK;
 }
 
@@ -232,15 +254,18 @@ void sfo_resolved_config(const sfo_world* w, sfx_config* out) {
     out->grid_log2[0] = w->gxl;
     out->grid_log2[1] = w->gyl;
     out->max_pairs = w->max_pairs;
+    out->tile_cells = 1u << w->tl;
 }
 
 /* ------------------------------------------------------------------ colouring
- * [DESIGN] DESIGN.md "Contract / colouring".  Edge colouring of the constraint graph:
- * two constraints that share a dynamic body never get the same colour.  `rounds` parallel
- * rounds (each uncoloured edge proposes a hashed colour out of a small window of colours
- * free at both ends; per (body, colour mod 8) the lowest priority wins; an edge is coloured
- * when it wins at both dynamic ends), then a serial first-fit finish.  Deterministic in the
- * edge order. */
+ * [DESIGN] DESIGN.md "Contract / colouring".  Edge colouring of a constraint graph: two
+ * constraints that share a dynamic body never get the same colour.  `rounds` parallel rounds
+ * (each uncoloured edge proposes a hashed colour out of a small window of colours free at
+ * both ends; per (body, colour mod 4) the lowest priority wins; an edge is coloured when it
+ * wins at both dynamic ends), then a serial first-fit finish in ascending key order.
+ * Priorities and hashes depend only on the edge's key (u, v) -- the two body ids of a
+ * candidate pair, or the index of a joint -- never on its place in a list, so the result is
+ * the same for every enumeration order of the same edge set. */
 
 static uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
@@ -252,77 +277,125 @@ static int kth_set_bit(uint64_t m, uint32_t k) {
     return __builtin_ctzll(m);
 }
 
-/* dyn_a/dyn_b: whether the end is a dynamic body.  Returns number of colours, fills
- * color[], *leftover, *overflow. */
-static uint32_t color_edges(uint32_t n_bodies, uint32_t ne, const uint32_t* ea, const uint32_t* eb,
-                            const uint8_t* dyn, uint32_t rounds, uint8_t* color,
-                            uint32_t* leftover, uint32_t* overflow) {
-    uint64_t* used = (uint64_t*)calloc(n_bodies ? n_bodies : 1, sizeof(uint64_t));
-    uint32_t* deg = (uint32_t*)calloc(n_bodies ? n_bodies : 1, sizeof(uint32_t));
-    uint64_t* claim = (uint64_t*)malloc((size_t)(n_bodies ? n_bodies : 1) * 8 * sizeof(uint64_t));
+static uint32_t edge_hash(uint32_t u, uint32_t v, uint32_t r) {
+    return mix32((u * 0x9E3779B1u) ^ mix32(v + r * 0x7F4A7C15u + 0x165667B1u));
+}
+
+/* 6 bits of (63 - round) | 10 bits of hash | 24 + 24 bits of key: unique per edge and round */
+static uint64_t edge_prio(uint32_t u, uint32_t v, uint32_t r, uint32_t h) {
+    return ((uint64_t)(63u - r) << 58) | ((uint64_t)(h >> 22) << 48) |
+           ((uint64_t)(u & 0xFFFFFFu) << 24) | (uint64_t)(v & 0xFFFFFFu);
+}
+
+typedef struct {
+    uint64_t* used;  /* [n_bodies] colours taken, all 0 between calls   */
+    uint32_t* deg;   /* [n_bodies] uncoloured incident edges, 0 between */
+    uint64_t* claim; /* [n_bodies][4], all ~0 between calls             */
+} color_scratch;
+
+static int color_scratch_init(color_scratch* cs, uint32_t n_bodies) {
+    size_t n = n_bodies ? n_bodies : 1;
+    cs->used = (uint64_t*)calloc(n, sizeof(uint64_t));
+    cs->deg = (uint32_t*)calloc(n, sizeof(uint32_t));
+    cs->claim = (uint64_t*)malloc(n * 4 * sizeof(uint64_t));
+    if (!cs->used || !cs->deg || !cs->claim) return -1;
+    memset(cs->claim, 0xFF, n * 4 * sizeof(uint64_t));
+    return 0;
+}
+
+static void color_scratch_free(color_scratch* cs) { free(cs->used); free(cs->deg); free(cs->claim); }
+
+typedef struct { uint64_t key; uint32_t idx; } key_idx;
+static int cmp_key_idx(const void* a, const void* b) {
+    const key_idx *x = (const key_idx*)a, *y = (const key_idx*)b;
+    return x->key < y->key ? -1 : x->key > y->key;
+}
+
+/* Colours the ne edges idx[0..ne) of (ea, eb); keys (ku[e], kv[e]).  dyn[] says which bodies
+ * are dynamic (SFX_WORLD_BODY ends never are).  Returns the number of colours; *leftover
+ * counts the edges the serial finish took; *overflow is set when an edge found no free colour
+ * (it stays NO_COLOR and is dropped from the solve).  The scratch tables are left clean. */
+static uint32_t color_edges(color_scratch* cs, uint32_t ne, const uint32_t* idx, const uint32_t* ea,
+                            const uint32_t* eb, const uint32_t* ku, const uint32_t* kv, const uint8_t* dyn,
+                            uint32_t rounds, uint8_t* color, uint32_t* leftover, uint32_t* overflow) {
+    uint64_t *used = cs->used, *claim = cs->claim;
+    uint32_t* deg = cs->deg;
     uint8_t* prop = (uint8_t*)malloc(ne ? ne : 1);
     uint64_t* prio = (uint64_t*)malloc((ne ? ne : 1) * sizeof(uint64_t));
-    memset(claim, 0xFF, (size_t)(n_bodies ? n_bodies : 1) * 8 * sizeof(uint64_t));
-    *overflow = 0;
-    for (uint32_t e = 0; e < ne; ++e) {
+#define DYN(x) ((x) != SFX_WORLD_BODY && dyn[(x)])
+    for (uint32_t q = 0; q < ne; ++q) {
+        uint32_t e = idx ? idx[q] : q;
         color[e] = NO_COLOR;
-        if (ea[e] != SFX_WORLD_BODY && dyn[ea[e]]) deg[ea[e]]++;
-        if (eb[e] != SFX_WORLD_BODY && dyn[eb[e]]) deg[eb[e]]++;
+        if (DYN(ea[e])) deg[ea[e]]++;
+        if (DYN(eb[e])) deg[eb[e]]++;
     }
     for (uint32_t r = 0; r < rounds; ++r) {
-        /* propose */
-        for (uint32_t e = 0; e < ne; ++e) {
+        for (uint32_t q = 0; q < ne; ++q) { /* propose */
+            uint32_t e = idx ? idx[q] : q;
             if (color[e] != NO_COLOR) continue;
             uint32_t a = ea[e], b = eb[e];
-            int da = a != SFX_WORLD_BODY && dyn[a], db = b != SFX_WORLD_BODY && dyn[b];
-            uint64_t ma = da ? used[a] : 0, mb = db ? used[b] : 0;
-            uint64_t freem = ~(ma | mb);
-            if (freem == 0) { prop[e] = NO_COLOR; *overflow = 1; continue; }
+            int da = DYN(a), db = DYN(b);
+            uint64_t freem = ~((da ? used[a] : 0) | (db ? used[b] : 0));
+            if (freem == 0) { prop[q] = NO_COLOR; *overflow = 1; continue; }
             uint32_t dg = 1;
             if (da && deg[a] > dg) dg = deg[a];
             if (db && deg[b] > dg) dg = deg[b];
             if (dg > 8) dg = 8;
             uint32_t nfree = (uint32_t)__builtin_popcountll(freem);
             if (dg > nfree) dg = nfree;
-            uint32_t h = mix32(e * 0x9E3779B1u + r * 0x7F4A7C15u + 0x165667B1u);
+            uint32_t h = edge_hash(ku[e], kv[e], r);
             uint32_t k = mix32(h ^ 0xA5A5A5A5u) % dg;
             uint32_t c = (uint32_t)kth_set_bit(freem, k);
-            prop[e] = (uint8_t)c;
-            uint64_t p = ((uint64_t)(63u - r) << 58) | ((uint64_t)(h >> 6) << 32) | e;
-            prio[e] = p;
-            if (da && p < claim[(size_t)a * 8 + (c & 7)]) claim[(size_t)a * 8 + (c & 7)] = p;
-            if (db && p < claim[(size_t)b * 8 + (c & 7)]) claim[(size_t)b * 8 + (c & 7)] = p;
+            prop[q] = (uint8_t)c;
+            uint64_t p = edge_prio(ku[e], kv[e], r, h);
+            prio[q] = p;
+            if (da && p < claim[(size_t)a * 4 + (c & 3)]) claim[(size_t)a * 4 + (c & 3)] = p;
+            if (db && p < claim[(size_t)b * 4 + (c & 3)]) claim[(size_t)b * 4 + (c & 3)] = p;
         }
-        /* resolve */
-        for (uint32_t e = 0; e < ne; ++e) {
-            if (color[e] != NO_COLOR || prop[e] == NO_COLOR) continue;
-            uint32_t a = ea[e], b = eb[e], c = prop[e];
-            int da = a != SFX_WORLD_BODY && dyn[a], db = b != SFX_WORLD_BODY && dyn[b];
-            int win = (!da || claim[(size_t)a * 8 + (c & 7)] == prio[e]) &&
-                      (!db || claim[(size_t)b * 8 + (c & 7)] == prio[e]);
+        for (uint32_t q = 0; q < ne; ++q) { /* resolve */
+            uint32_t e = idx ? idx[q] : q;
+            if (color[e] != NO_COLOR || prop[q] == NO_COLOR) continue;
+            uint32_t a = ea[e], b = eb[e], c = prop[q];
+            int da = DYN(a), db = DYN(b);
+            int win = (!da || claim[(size_t)a * 4 + (c & 3)] == prio[q]) &&
+                      (!db || claim[(size_t)b * 4 + (c & 3)] == prio[q]);
             if (!win) continue;
             color[e] = (uint8_t)c;
             if (da) { used[a] |= 1ull << c; deg[a]--; }
             if (db) { used[b] |= 1ull << c; deg[b]--; }
         }
     }
-    /* serial first-fit finish */
-    *leftover = 0;
-    for (uint32_t e = 0; e < ne; ++e) {
+    /* serial first-fit finish, ascending key */
+    uint32_t nl = 0;
+    key_idx* left = (key_idx*)malloc((ne ? ne : 1) * sizeof(key_idx));
+    for (uint32_t q = 0; q < ne; ++q) {
+        uint32_t e = idx ? idx[q] : q;
         if (color[e] != NO_COLOR) continue;
-        uint32_t a = ea[e], b = eb[e];
-        int da = a != SFX_WORLD_BODY && dyn[a], db = b != SFX_WORLD_BODY && dyn[b];
+        left[nl].key = ((uint64_t)(ku[e] & 0xFFFFFFu) << 24) | (kv[e] & 0xFFFFFFu);
+        left[nl].idx = e;
+        ++nl;
+    }
+    qsort(left, nl, sizeof(key_idx), cmp_key_idx);
+    for (uint32_t q = 0; q < nl; ++q) {
+        uint32_t e = left[q].idx, a = ea[e], b = eb[e];
+        int da = DYN(a), db = DYN(b);
         uint64_t freem = ~((da ? used[a] : 0) | (db ? used[b] : 0));
-        (*leftover)++;
-        if (freem == 0) { *overflow = 1; continue; } /* stays uncoloured: dropped from the solve */
+        if (freem == 0) { *overflow = 1; continue; }
         uint32_t c = (uint32_t)__builtin_ctzll(freem);
         color[e] = (uint8_t)c;
         if (da) used[a] |= 1ull << c;
         if (db) used[b] |= 1ull << c;
     }
+    *leftover += nl;
     uint32_t nc = 0;
-    for (uint32_t e = 0; e < ne; ++e) if (color[e] != NO_COLOR && color[e] + 1u > nc) nc = color[e] + 1u;
-    free(used); free(deg); free(claim); free(prop); free(prio);
+    for (uint32_t q = 0; q < ne; ++q) {
+        uint32_t e = idx ? idx[q] : q, a = ea[e], b = eb[e];
+        if (color[e] != NO_COLOR && color[e] + 1u > nc) nc = color[e] + 1u;
+        if (DYN(a)) { used[a] = 0; deg[a] = 0; memset(&claim[(size_t)a * 4], 0xFF, 4 * sizeof(uint64_t)); }
+        if (DYN(b)) { used[b] = 0; deg[b] = 0; memset(&claim[(size_t)b * 4], 0xFF, 4 * sizeof(uint64_t)); }
+    }
+#undef DYN
+    free(prop); free(prio); free(left);
     return nc;
 }
 
@@ -335,23 +408,31 @@ int sfo_upload_constraints(sfo_world* w, uint32_t m, const sfx_distance_constrai
     w->joint_color = (uint8_t*)malloc(m ? m : 1);
     uint32_t* ea = (uint32_t*)malloc((m ? m : 1) * sizeof(uint32_t));
     uint32_t* eb = (uint32_t*)malloc((m ? m : 1) * sizeof(uint32_t));
+    uint32_t* ku = (uint32_t*)malloc((m ? m : 1) * sizeof(uint32_t));
+    uint32_t* kv = (uint32_t*)malloc((m ? m : 1) * sizeof(uint32_t));
     uint8_t* dyn = (uint8_t*)malloc(w->n ? w->n : 1);
     for (uint32_t i = 0; i < w->n; ++i) dyn[i] = (uint8_t)is_dynamic(w, i);
     for (uint32_t k = 0; k < m; ++k) {
         ea[k] = c[k].body_a; eb[k] = c[k].body_b;
+        ku[k] = k >> 24; kv[k] = k & 0xFFFFFFu; /* joints are keyed by their index */
         if ((ea[k] != SFX_WORLD_BODY && ea[k] >= w->n) || (eb[k] != SFX_WORLD_BODY && eb[k] >= w->n)) {
-            free(ea); free(eb); free(dyn);
+            free(ea); free(eb); free(ku); free(kv); free(dyn);
             return SFX_ERR_INVALID;
         }
     }
-    uint32_t left, ovf;
-    w->n_joint_colors = color_edges(w->n, m, ea, eb, dyn, w->cfg.color_rounds, w->joint_color, &left, &ovf);
+    uint32_t left = 0, ovf = 0;
+    color_scratch cs;
+    color_scratch_init(&cs, w->n);
+    w->n_joint_colors = color_edges(&cs, m, NULL, ea, eb, ku, kv, dyn, w->cfg.color_rounds, w->joint_color, &left, &ovf);
+    color_scratch_free(&cs);
     /* colour-major, stable */
     uint32_t pos = 0;
     for (uint32_t col = 0; col < w->n_joint_colors; ++col)
         for (uint32_t k = 0; k < m; ++k)
             if (w->joint_color[k] == col) w->joint_perm[pos++] = k;
-    free(ea); free(eb); free(dyn);
+    for (uint32_t k = 0; k < m; ++k) /* uncoloured (colour overflow): listed last, never solved */
+        if (w->joint_color[k] == NO_COLOR) w->joint_perm[pos++] = k;
+    free(ea); free(eb); free(ku); free(kv); free(dyn);
     return ovf ? SFX_ERR_CAPACITY : SFX_OK;
 }
 
@@ -496,14 +577,14 @@ static void grid_pairs(sfo_world* w) {
     uint32_t n = w->n, GX = 1u << w->gxl, GY = 1u << w->gyl, ncell = GX * GY;
     uint32_t* start = (uint32_t*)calloc((size_t)ncell + 1, sizeof(uint32_t));
     uint32_t* bucket = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
-    int32_t* ccx = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
-    int32_t* ccy = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+    int32_t *ccx = w->ccx, *ccy = w->ccy;
     uint32_t* slot_id = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
     uint32_t* large = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
     uint32_t ns = 0, nl = 0;
     float lim = 0.9f * w->cell;
     for (uint32_t i = 0; i < n; ++i) {
         bucket[i] = 0xFFFFFFFFu;
+        w->is_small[i] = 0;
         if (w->col[i].type == SFX_SHAPE_NONE) continue;
         const float* A = &w->aabb[4 * i];
         if ((A[2] - A[0]) <= lim && (A[3] - A[1]) <= lim) {
@@ -511,6 +592,7 @@ static void grid_pairs(sfo_world* w) {
             ccy[i] = cell_coord(A[1], w->inv_cell);
             bucket[i] = (((uint32_t)ccy[i] & (GY - 1)) << w->gxl) | ((uint32_t)ccx[i] & (GX - 1));
             start[bucket[i] + 1]++;
+            w->is_small[i] = 1;
             ++ns;
         } else {
             large[nl++] = i;
@@ -540,22 +622,115 @@ static void grid_pairs(sfo_world* w) {
     }
     for (uint32_t l = 0; l < nl; ++l)
         for (uint32_t l2 = l + 1; l2 < nl; ++l2) emit_pair(w, large[l], large[l2]);
-    free(start); free(bucket); free(ccx); free(ccy); free(slot_id); free(large); free(fill);
+    free(start); free(bucket); free(slot_id); free(large); free(fill);
+}
+
+/* ------------------------------------------------------------------ tile order
+ * [DESIGN] DESIGN.md "Contract / tiles".  Tiles are 2^tl x 2^tl blocks of grid cells (true
+ * cell coordinates, wrapped onto the torus like the cells).  A candidate pair of two small
+ * colliders is owned by the tile (min tx, min ty) of its two home tiles; a pair of a small
+ * collider and a large non-dynamic one by the small one's tile; everything else, and every
+ * pair of a tile that owns more than SFX_TILE_MAX_PAIRS pairs or whose 2x2 tile block holds
+ * more than SFX_TILE_MAX_BODIES small colliders, goes to the fallback list.  All bodies of a
+ * tile's pairs lie inside its block (tx..tx+1, ty..ty+1), and blocks of tiles with the same
+ * parity (tx & 1, ty & 1) are disjoint: the four parities are the four phases of a sweep.
+ * Each tile's pairs, and the fallback list, are edge-coloured on their own. */
+
+static uint32_t wrapped_tile(const sfo_world* w, int32_t tx, int32_t ty) {
+    uint32_t lx = w->gxl - w->tl, ly = w->gyl - w->tl;
+    return (((uint32_t)ty & ((1u << ly) - 1u)) << lx) | ((uint32_t)tx & ((1u << lx) - 1u));
+}
+
+static int32_t tile_coord(int32_t c, uint32_t tl) { return c >= 0 ? (int32_t)((uint32_t)c >> tl) : -(int32_t)(((uint32_t)(-(c + 1)) >> tl) + 1u); }
+
+static void build_order(sfo_world* w) {
+    uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
+    uint32_t lx = w->gxl - w->tl, ly = w->gyl - w->tl, ntiles = 1u << (lx + ly);
+    uint32_t* tbodies = (uint32_t*)calloc(ntiles, sizeof(uint32_t));
+    uint32_t* tcnt = (uint32_t*)calloc(ntiles, sizeof(uint32_t));
+    uint8_t* tover = (uint8_t*)calloc(ntiles, 1);
+    uint8_t* dyn = (uint8_t*)malloc(w->n ? w->n : 1);
+    for (uint32_t i = 0; i < w->n; ++i) {
+        dyn[i] = (uint8_t)is_dynamic(w, i);
+        if (w->is_small[i]) tbodies[wrapped_tile(w, tile_coord(w->ccx[i], w->tl), tile_coord(w->ccy[i], w->tl))]++;
+    }
+    for (uint32_t e = 0; e < np; ++e) {
+        uint32_t a = w->pa[e], b = w->pb[e], own = SFO_FALLBACK;
+        int32_t txa = tile_coord(w->ccx[a], w->tl), tya = tile_coord(w->ccy[a], w->tl);
+        int32_t txb = tile_coord(w->ccx[b], w->tl), tyb = tile_coord(w->ccy[b], w->tl);
+        if (w->is_small[a] && w->is_small[b]) own = wrapped_tile(w, txa < txb ? txa : txb, tya < tyb ? tya : tyb);
+        else if (w->is_small[a] && !dyn[b]) own = wrapped_tile(w, txa, tya);
+        else if (w->is_small[b] && !dyn[a]) own = wrapped_tile(w, txb, tyb);
+        w->owner[e] = own;
+        if (own != SFO_FALLBACK) tcnt[own]++;
+    }
+    w->max_tile_pairs = 0; w->max_tile_bodies = 0; w->n_tiles = 0;
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        if (!tcnt[t]) continue;
+        uint32_t tx = t & ((1u << lx) - 1u), ty = t >> lx, nb = 0;
+        for (int dy = 0; dy < 2; ++dy)
+            for (int dx = 0; dx < 2; ++dx) nb += tbodies[wrapped_tile(w, (int32_t)tx + dx, (int32_t)ty + dy)];
+        if (tcnt[t] > SFX_TILE_MAX_PAIRS || nb > SFX_TILE_MAX_BODIES) { tover[t] = 1; continue; }
+        if (tcnt[t] > w->max_tile_pairs) w->max_tile_pairs = tcnt[t];
+        if (nb > w->max_tile_bodies) w->max_tile_bodies = nb;
+        w->n_tiles++;
+    }
+    /* stable counting sort of the pair indices by owner tile; overflowing tiles join the fallback */
+    uint32_t* tstart = (uint32_t*)calloc((size_t)ntiles + 2, sizeof(uint32_t));
+    for (uint32_t e = 0; e < np; ++e) {
+        if (w->owner[e] != SFO_FALLBACK && tover[w->owner[e]]) w->owner[e] = SFO_FALLBACK;
+        tstart[(w->owner[e] == SFO_FALLBACK ? ntiles : w->owner[e]) + 1]++;
+    }
+    for (uint32_t t = 0; t <= ntiles; ++t) tstart[t + 1] += tstart[t];
+    uint32_t* bytile = (uint32_t*)malloc((np ? np : 1) * sizeof(uint32_t));
+    uint32_t* fill = (uint32_t*)malloc(((size_t)ntiles + 1) * sizeof(uint32_t));
+    memcpy(fill, tstart, ((size_t)ntiles + 1) * sizeof(uint32_t));
+    for (uint32_t e = 0; e < np; ++e) bytile[fill[w->owner[e] == SFO_FALLBACK ? ntiles : w->owner[e]]++] = e;
+    w->n_fallback = tstart[ntiles + 1] - tstart[ntiles];
+
+    color_scratch cs;
+    color_scratch_init(&cs, w->n);
+    memset(w->color_count, 0, sizeof(w->color_count));
+    w->n_colors = 0; w->n_leftover = 0; w->n_batches = 0; w->n_order = 0;
+    uint32_t ovf = 0;
+    /* batches: phase by phase, inside a phase tile by tile (independent of each other), the
+     * fallback list last; inside a batch colour-major */
+    for (uint32_t ph = 0; ph <= 4; ++ph) {
+        for (uint32_t t = 0; t <= ntiles; ++t) {
+            if (ph < 4) {
+                if (t == ntiles) continue;
+                uint32_t tx = t & ((1u << lx) - 1u), ty = t >> lx;
+                if (((tx & 1u) | ((ty & 1u) << 1)) != ph) continue;
+            } else if (t != ntiles) continue;
+            uint32_t s0 = tstart[t], cnt = tstart[t + 1] - s0;
+            if (!cnt) continue;
+            uint32_t nc = color_edges(&cs, cnt, &bytile[s0], w->pa, w->pb, w->pa, w->pb, dyn, w->cfg.color_rounds,
+                                      w->color, &w->n_leftover, &ovf);
+            if (nc > w->n_colors) w->n_colors = nc;
+            for (uint32_t c = 0; c < nc; ++c)
+                for (uint32_t q = 0; q < cnt; ++q) {
+                    uint32_t e = bytile[s0 + q];
+                    if (w->color[e] == c) { w->order[w->n_order++] = e; w->color_count[c]++; }
+                }
+            w->batch_end[w->n_batches++] = w->n_order;
+        }
+    }
+    color_scratch_free(&cs);
+    if (ovf) w->overflow = 1;
+    w->order_valid = 1;
+    free(tbodies); free(tcnt); free(tover); free(dyn); free(tstart); free(bytile); free(fill);
+}
+
+static void broadphase_core(sfo_world* w, float frame_dt) {
+    for (uint32_t i = 0; i < w->n; ++i) compute_aabb(w, i, frame_dt, &w->aabb[4 * i]);
+    grid_pairs(w);
+    w->order_valid = 0;
 }
 
 int sfo_broadphase(sfo_world* w, float frame_dt) {
     if (!w->col) return SFX_ERR_INVALID;
-    for (uint32_t i = 0; i < w->n; ++i) compute_aabb(w, i, frame_dt, &w->aabb[4 * i]);
-    grid_pairs(w);
-    uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
-    uint8_t* dyn = (uint8_t*)malloc(w->n ? w->n : 1);
-    for (uint32_t i = 0; i < w->n; ++i) dyn[i] = (uint8_t)is_dynamic(w, i);
-    uint32_t ovf = 0;
-    w->n_colors = color_edges(w->n, np, w->pa, w->pb, dyn, w->cfg.color_rounds, w->color, &w->n_leftover, &ovf);
-    if (ovf) w->overflow = 1;
-    memset(w->color_count, 0, sizeof(w->color_count));
-    for (uint32_t e = 0; e < np; ++e) if (w->color[e] != NO_COLOR) w->color_count[w->color[e]]++;
-    free(dyn);
+    broadphase_core(w, frame_dt);
+    build_order(w);
     return w->overflow ? SFX_ERR_CAPACITY : SFX_OK;
 }
 
@@ -572,11 +747,13 @@ size_t sfo_pairs_grid(const sfo_world* w, uint64_t* keys, size_t cap) {
     return w->n_pairs;
 }
 
-size_t sfo_pair_colors(const sfo_world* w, uint64_t* keys, uint8_t* colors, size_t cap) {
+size_t sfo_pair_colors(const sfo_world* w, uint64_t* keys, uint8_t* colors, uint32_t* tiles, size_t cap) {
     uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
+    if (!w->order_valid) return 0;
     for (uint32_t e = 0; e < np && e < cap; ++e) {
         keys[e] = ((uint64_t)w->pa[e] << 32) | w->pb[e];
         colors[e] = w->color[e];
+        if (tiles) tiles[e] = w->owner[e];
     }
     return np;
 }
@@ -648,17 +825,18 @@ typedef struct {
     float depth[2];
 } manifold_t;
 
-static void cc_manifold(const core_t* A, const core_t* B, manifold_t* m) {
+static void cc_manifold(const core_t* A, const core_t* B, float sm, manifold_t* m) {
     float dx = B->vx[0] - A->vx[0], dy = B->vy[0] - A->vy[0];
     float d2 = dx * dx + dy * dy;
     float rsum = A->r + B->r;
+    float reach = rsum + sm;
     m->count = 0;
-    if (d2 > rsum * rsum) return;
+    if (d2 > reach * reach) return;
     float dist = sqrtf(d2);
     float nx = 0.0f, ny = 1.0f;
     if (dist > EPS_LEN) { nx = dx / dist; ny = dy / dist; }
     float depth = rsum - dist;
-    if (!(depth > 0.0f)) return;
+    if (!(depth > -sm)) return;
     m->count = 1; m->nx = nx; m->ny = ny; m->depth[0] = depth;
     m->p1x[0] = A->vx[0] + nx * A->r; m->p1y[0] = A->vy[0] + ny * A->r;
     m->p2x[0] = B->vx[0] - nx * B->r; m->p2y[0] = B->vy[0] - ny * B->r;
@@ -684,21 +862,22 @@ static void closest_on_poly(const core_t* P, float cx, float cy, float* qx, floa
 }
 
 /* polygon P (n >= 2) against circle C: normal points from P to C */
-static void pc_manifold(const core_t* P, const core_t* C, manifold_t* m) {
+static void pc_manifold(const core_t* P, const core_t* C, float sm, manifold_t* m) {
     float cx = C->vx[0], cy = C->vy[0];
     float rsum = P->r + C->r;
+    float reach = rsum + sm;
     float sep = -INFINITY; int ks = 0;
     m->count = 0;
     for (int k = 0; k < P->n; ++k) {
         float s = P->nx[k] * (cx - P->vx[k]) + P->ny[k] * (cy - P->vy[k]);
         if (s > sep) { sep = s; ks = k; }
     }
-    if (sep > rsum) return;
+    if (sep > reach) return;
     float nx, ny, qx, qy, depth;
     if (P->n == 2 || sep > 0.0f) {
         float d2;
         closest_on_poly(P, cx, cy, &qx, &qy, &d2);
-        if (d2 > rsum * rsum) return;
+        if (d2 > reach * reach) return;
         float dist = sqrtf(d2);
         if (dist > EPS_LEN) { nx = (cx - qx) / dist; ny = (cy - qy) / dist; }
         else { nx = P->nx[ks]; ny = P->ny[ks]; }
@@ -708,7 +887,7 @@ static void pc_manifold(const core_t* P, const core_t* C, manifold_t* m) {
         qx = cx - nx * sep; qy = cy - ny * sep;
         depth = rsum - sep;
     }
-    if (!(depth > 0.0f)) return;
+    if (!(depth > -sm)) return;
     m->count = 1; m->nx = nx; m->ny = ny; m->depth[0] = depth;
     m->p1x[0] = qx + nx * P->r; m->p1y[0] = qy + ny * P->r;
     m->p2x[0] = cx - nx * C->r; m->p2y[0] = cy - ny * C->r;
@@ -729,14 +908,15 @@ static float sat_sep(const core_t* P, const core_t* Q, int* kbest) {
 }
 
 /* polygon (n >= 2) against polygon (n >= 2); normal from A to B */
-static void pp_manifold(const core_t* A, const core_t* B, manifold_t* m) {
+static void pp_manifold(const core_t* A, const core_t* B, float sm, manifold_t* m) {
     int ka, kb;
     float rsum = A->r + B->r;
+    float reach = rsum + sm;
     m->count = 0;
     float sa = sat_sep(A, B, &ka);
-    if (sa > rsum) return;
+    if (sa > reach) return;
     float sb = sat_sep(B, A, &kb);
-    if (sb > rsum) return;
+    if (sb > reach) return;
     int flip = sb > sa;
     const core_t* R = flip ? B : A; /* reference */
     const core_t* I = flip ? A : B; /* incident  */
@@ -782,7 +962,7 @@ static void pp_manifold(const core_t* A, const core_t* B, manifold_t* m) {
             float cx = i1x + tt[k] * ex, cy = i1y + tt[k] * ey;
             float s = (cx - r1x) * nrx + (cy - r1y) * nry;
             float d = rsum - s;
-            if (!(d > 0.0f)) continue;
+            if (!(d > -sm)) continue;
             /* foot on the reference edge pushed out by its radius / incident point pulled in */
             prx[cnt] = (cx - nrx * s) + nrx * rr; pry[cnt] = (cy - nry * s) + nry * rr;
             pix[cnt] = cx - nrx * ri;             piy[cnt] = cy - nry * ri;
@@ -794,12 +974,12 @@ static void pp_manifold(const core_t* A, const core_t* B, manifold_t* m) {
         float vx = (u1 + u2 < 0.0f) ? r1x : r2x, vy = (u1 + u2 < 0.0f) ? r1y : r2y;
         float qx, qy, d2;
         closest_on_poly(I, vx, vy, &qx, &qy, &d2);
-        if (d2 > rsum * rsum) return;
+        if (d2 > reach * reach) return;
         float dist = sqrtf(d2);
         if (dist > EPS_LEN) { nx = (qx - vx) / dist; ny = (qy - vy) / dist; }
         else { nx = nrx; ny = nry; }
         float d = rsum - dist;
-        if (d > 0.0f) {
+        if (d > -sm) {
             prx[0] = vx + nx * rr; pry[0] = vy + ny * rr;
             pix[0] = qx - nx * ri; piy[0] = qy - ny * ri;
             dep[0] = d;
@@ -816,18 +996,20 @@ static void pp_manifold(const core_t* A, const core_t* B, manifold_t* m) {
     if (!flip) { m->nx = nx; m->ny = ny; } else { m->nx = -nx; m->ny = -ny; }
 }
 
-/* manifold of bodies a, b (normal from a to b) */
+/* manifold of bodies a, b (normal from a to b); points closer than the speculative margin
+ * are kept with their (negative) depth */
 static void manifold(const sfo_world* w, uint32_t a, uint32_t b, manifold_t* m) {
     core_t A, B;
+    float sm = w->cfg.speculative_margin;
     build_core(w, a, &A);
     build_core(w, b, &B);
     m->count = 0;
     if (A.n == 0 || B.n == 0) return;
-    if (A.n == 1 && B.n == 1) { cc_manifold(&A, &B, m); return; }
-    if (B.n == 1) { pc_manifold(&A, &B, m); return; }
+    if (A.n == 1 && B.n == 1) { cc_manifold(&A, &B, sm, m); return; }
+    if (B.n == 1) { pc_manifold(&A, &B, sm, m); return; }
     if (A.n == 1) {
         manifold_t t;
-        pc_manifold(&B, &A, &t);
+        pc_manifold(&B, &A, sm, &t);
         m->count = t.count;
         if (t.count) {
             m->nx = -t.nx; m->ny = -t.ny; m->depth[0] = t.depth[0];
@@ -836,7 +1018,7 @@ static void manifold(const sfo_world* w, uint32_t a, uint32_t b, manifold_t* m) 
         }
         return;
     }
-    pp_manifold(&A, &B, m);
+    pp_manifold(&A, &B, sm, m);
 }
 
 static void fill_contact(uint32_t a, uint32_t b, const manifold_t* m, sfx_contact* c) {
@@ -964,13 +1146,15 @@ static void solve_lcp2(float K00, float K01, float K11, float d0, float d1, floa
     else { *l0 = 0.0f; *l1 = fmaxf(d1, 0.0f) / K11; }
 }
 
-/* [XPBD-RB] sec. 3.5: contact handled with the manifold recomputed from the current poses;
- * normal constraints of the manifold solved as a block.  Friction is not applied here but
- * in the velocity pass (see solve_vel_pair) so that it sees the net motion of the substep. */
-static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec, float max_corr) {
+/* [XPBD-RB] sec. 3.5, first half: narrowphase of one candidate pair at the poses of the
+ * batch start ([DESIGN] DESIGN.md "Contract / batches": a batch is one tile in one phase, the
+ * fallback list, or -- in sequential order -- the whole substep).  Leaves body-local anchors,
+ * the normal, the pre-solve normal velocities and the combined material in the record. */
+static void prepare_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec) {
     manifold_t m;
     manifold(w, a, b, &m);
     rec->count = (uint32_t)m.count;
+    rec->lam[0] = 0.0f; rec->lam[1] = 0.0f;
     if (!m.count) return;
     const sfx_material* ma = &w->mats[w->col[a].material];
     const sfx_material* mb = &w->mats[w->col[b].material];
@@ -978,24 +1162,34 @@ static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec, 
     rec->mu_d = 0.5f * (ma->dynamic_friction + mb->dynamic_friction);
     rec->rest = fmaxf(ma->restitution, mb->restitution);
     rec->nx = m.nx; rec->ny = m.ny;
-    float nx = m.nx, ny = m.ny;
-    float ima = w->inv_mass[a], iia = w->inv_inertia[a], imb = w->inv_mass[b], iib = w->inv_inertia[b];
-    float rax[2], ray[2], rbx[2], rby[2], d[2], cna[2] = {0.0f, 0.0f}, cnb[2] = {0.0f, 0.0f};
-    /* body-local anchors from the poses the manifold was built on */
+    float ca = w->rot[2 * a], sa = w->rot[2 * a + 1], cb = w->rot[2 * b], sb = w->rot[2 * b + 1];
     for (int k = 0; k < m.count; ++k) {
         float ax = m.p1x[k] - w->pos[2 * a], ay = m.p1y[k] - w->pos[2 * a + 1];
         float bx = m.p2x[k] - w->pos[2 * b], by = m.p2y[k] - w->pos[2 * b + 1];
-        float ca = w->rot[2 * a], sa = w->rot[2 * a + 1], cb = w->rot[2 * b], sb = w->rot[2 * b + 1];
         rec->ra[k][0] = ca * ax + sa * ay; rec->ra[k][1] = ca * ay - sa * ax;
         rec->rb[k][0] = cb * bx + sb * by; rec->rb[k][1] = cb * by - sb * bx;
+        /* pre-solve normal velocity of b relative to a (velocities are still the integrated ones) */
+        float rax, ray, rbx, rby;
+        anchor_world(w, a, rec->ra[k], &rax, &ray);
+        anchor_world(w, b, rec->rb[k], &rbx, &rby);
+        float vax = w->vel[2 * a] - w->angvel[a] * ray, vay = w->vel[2 * a + 1] + w->angvel[a] * rax;
+        float vbx = w->vel[2 * b] - w->angvel[b] * rby, vby = w->vel[2 * b + 1] + w->angvel[b] * rbx;
+        rec->vn_pre[k] = (vbx - vax) * m.nx + (vby - vay) * m.ny;
     }
-    for (int k = 0; k < m.count; ++k) {
+}
+
+/* [XPBD-RB] sec. 3.5, second half: penetration re-evaluated from the record's anchors at the
+ * current poses; the manifold's normal constraints solved as a block; poses updated.
+ * Friction is not applied here but in the velocity pass (see solve_vel_pair). */
+static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec, float max_corr) {
+    int count = (int)rec->count;
+    if (!count) return;
+    float nx = rec->nx, ny = rec->ny;
+    float ima = w->inv_mass[a], iia = w->inv_inertia[a], imb = w->inv_mass[b], iib = w->inv_inertia[b];
+    float rax[2], ray[2], rbx[2], rby[2], d[2] = {0.0f, 0.0f}, cna[2] = {0.0f, 0.0f}, cnb[2] = {0.0f, 0.0f};
+    for (int k = 0; k < count; ++k) {
         anchor_world(w, a, rec->ra[k], &rax[k], &ray[k]);
         anchor_world(w, b, rec->rb[k], &rbx[k], &rby[k]);
-        /* pre-solve normal velocity of b relative to a (velocities are still the integrated ones) */
-        float vax = w->vel[2 * a] - w->angvel[a] * ray[k], vay = w->vel[2 * a + 1] + w->angvel[a] * rax[k];
-        float vbx = w->vel[2 * b] - w->angvel[b] * rby[k], vby = w->vel[2 * b + 1] + w->angvel[b] * rbx[k];
-        rec->vn_pre[k] = (vbx - vax) * nx + (vby - vay) * ny;
         d[k] = ((w->pos[2 * a] + rax[k]) - (w->pos[2 * b] + rbx[k])) * nx +
                ((w->pos[2 * a + 1] + ray[k]) - (w->pos[2 * b + 1] + rby[k])) * ny;
         d[k] = fminf(d[k], max_corr); /* [DESIGN] bounded depenetration per substep */
@@ -1005,9 +1199,8 @@ static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec, 
     float l0 = 0.0f, l1 = 0.0f;
     float ims = ima + imb;
     float K00 = (ims + iia * (cna[0] * cna[0])) + iib * (cnb[0] * cnb[0]);
-    rec->lam[0] = 0.0f; rec->lam[1] = 0.0f;
     if (!(K00 > 0.0f)) return;
-    if (m.count == 2) {
+    if (count == 2) {
         float K11 = (ims + iia * (cna[1] * cna[1])) + iib * (cnb[1] * cnb[1]);
         float K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
         solve_lcp2(K00, K01, K11, d[0], d[1], &l0, &l1);
@@ -1181,48 +1374,50 @@ static void solve_joint(sfo_world* w, const sfx_distance_constraint* j, float in
     if (b != SFX_WORLD_BODY) apply_pos(w, b, rbx, rby, nx * corr, ny * corr, -1.0f);
 }
 
-typedef struct { uint64_t key; uint32_t idx; } key_idx;
-static int cmp_key_idx(const void* a, const void* b) {
-    const key_idx *x = (const key_idx*)a, *y = (const key_idx*)b;
-    return x->key < y->key ? -1 : x->key > y->key;
-}
-
 int sfo_step(sfo_world* w, float frame_dt, int order) {
     if (!w->col || !w->mats) return SFX_ERR_INVALID;
-    (void)sfo_broadphase(w, frame_dt); /* capacity overflow is reported by sfo_stats, the tick goes on */
+    broadphase_core(w, frame_dt); /* capacity overflow is reported by sfo_stats, the tick goes on */
     uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
-    uint32_t nord = np;
+    uint32_t nord = np, nbatch = 1;
     for (uint32_t e = 0; e < np; ++e) w->rec[e].count = 0;
     if (order == SFO_ORDER_SEQUENTIAL) {
+        /* one batch, ascending pair key: what a single-threaded engine does */
         key_idx* ki = (key_idx*)malloc((np ? np : 1) * sizeof(key_idx));
         for (uint32_t e = 0; e < np; ++e) { ki[e].key = ((uint64_t)w->pa[e] << 32) | w->pb[e]; ki[e].idx = e; }
         qsort(ki, np, sizeof(key_idx), cmp_key_idx);
         for (uint32_t e = 0; e < np; ++e) w->order[e] = ki[e].idx;
         free(ki);
+        w->batch_end[0] = np;
     } else {
-        uint32_t start[SFX_MAX_COLORS + 1];
-        start[0] = 0;
-        for (uint32_t c = 0; c < SFX_MAX_COLORS; ++c) start[c + 1] = start[c] + w->color_count[c];
-        nord = 0;
-        for (uint32_t e = 0; e < np; ++e) if (w->color[e] != NO_COLOR) { w->order[start[w->color[e]]++] = e; ++nord; }
+        build_order(w);
+        nord = w->n_order; nbatch = w->n_batches;
     }
+    (void)nord;
     float h = frame_dt / (float)w->cfg.substeps;
     float inv_h = 1.0f / h;
     float inv_h2 = inv_h * inv_h;
+    float max_corr = w->cfg.max_depenetration_velocity * h;
     for (uint32_t s = 0; s < w->cfg.substeps; ++s) {
         integrate(w, h);
         for (uint32_t k = 0; k < w->m; ++k) {
             uint32_t jk = order == SFO_ORDER_SEQUENTIAL ? k : w->joint_perm[k];
+            if (order != SFO_ORDER_SEQUENTIAL && w->joint_color[jk] == NO_COLOR) continue;
             solve_joint(w, &w->joints[jk], inv_h2);
         }
-        for (uint32_t k = 0; k < nord; ++k) {
-            uint32_t e = w->order[k];
-            solve_pos_pair(w, w->pa[e], w->pb[e], &w->rec[e], w->cfg.max_depenetration_velocity * h);
+        for (uint32_t bt = 0, k0 = 0; bt < nbatch; ++bt) {
+            uint32_t k1 = w->batch_end[bt];
+            for (uint32_t k = k0; k < k1; ++k) prepare_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]]);
+            for (uint32_t k = k0; k < k1; ++k) solve_pos_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]], max_corr);
+            k0 = k1;
         }
         derive_velocities(w, inv_h);
-        for (uint32_t k = 0; k < nord; ++k) {
-            uint32_t e = w->order[k];
-            if (w->rec[e].count) solve_vel_pair(w, w->pa[e], w->pb[e], &w->rec[e], h, inv_h);
+        for (uint32_t bt = 0, k0 = 0; bt < nbatch; ++bt) {
+            uint32_t k1 = w->batch_end[bt];
+            for (uint32_t k = k0; k < k1; ++k) {
+                uint32_t e = w->order[k];
+                if (w->rec[e].count) solve_vel_pair(w, w->pa[e], w->pb[e], &w->rec[e], h, inv_h);
+            }
+            k0 = k1;
         }
     }
     /* stats of the last substep, measured on the records */
@@ -1255,6 +1450,8 @@ int sfo_stats(const sfo_world* w, sfx_frame_stats* out) {
     out->n_contacts = w->n_contacts; out->n_manifolds = w->n_manifolds; out->n_manifolds2 = w->n_manifolds2;
     out->n_joint_colors = w->n_joint_colors;
     out->overflow = w->overflow;
+    out->n_tiles = w->n_tiles; out->n_fallback = w->n_fallback;
+    out->max_tile_pairs = w->max_tile_pairs; out->max_tile_bodies = w->max_tile_bodies;
     memcpy(out->color_count, w->color_count, sizeof(w->color_count));
     /* deepest penetration at the current poses */
     float md = 0.0f;

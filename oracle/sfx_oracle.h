@@ -33,7 +33,8 @@ typedef struct sfo_world sfo_world;
 /* constraint processing order of a tick */
 #define SFO_ORDER_SEQUENTIAL 0 /* ascending pair key, upload order for joints: plain Gauss-Seidel,
                                   what a single-threaded CPU engine does ("reference-like")        */
-#define SFO_ORDER_COLORED 1    /* colour-major order from the restated colouring: what libsfx does  */
+#define SFO_ORDER_COLORED 1    /* tile phases, colour-major inside a tile, fallback list last: what
+                                  libsfx does (DESIGN.md "Contract / tiles")                        */
 
 sfo_world* sfo_create(const sfx_config* cfg);
 void sfo_destroy(sfo_world* w);
@@ -61,8 +62,9 @@ int sfo_aabbs(const sfo_world* w, float* out);             /* [n][4] of the last
 size_t sfo_pairs_grid(const sfo_world* w, uint64_t* keys, size_t cap);  /* last broadphase */
 size_t sfo_pairs_sweep(const sfo_world* w, uint64_t* keys, size_t cap); /* sort & sweep on the same AABBs */
 size_t sfo_pairs_brute(const sfo_world* w, uint64_t* keys, size_t cap); /* O(n^2) */
-/* pairs in emission order with colours */
-size_t sfo_pair_colors(const sfo_world* w, uint64_t* keys, uint8_t* colors, size_t cap);
+/* pairs in emission order with their owner tile (0xFFFFFFFF = fallback list) and their colour
+ * inside that tile / list; 0 until a coloured-order broadphase or step has run */
+size_t sfo_pair_colors(const sfo_world* w, uint64_t* keys, uint8_t* colors, uint32_t* tiles, size_t cap);
 /* narrowphase on all candidate pairs at current poses, ascending key order */
 size_t sfo_contacts(const sfo_world* w, sfx_contact* out, size_t cap);
 /* narrowphase of one explicit pair at current poses (a < b not required) */

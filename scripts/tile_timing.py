@@ -1,0 +1,25 @@
+"""Development: stage timing of k_tile_pos (needs a -DSFX_TILE_TIMING build of libsfx)."""
+import sys, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from starframe_amd import scenes, _abi
+from starframe_amd.world import World
+import bench
+lib = _abi.load_libsfx(os.environ.get("SFX_LIB"))
+_abi._lib = lib
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+s = scenes.mixed_pile(n=n, width=max(50, n // 100))
+s = bench.settle(s, 0, frames=400)
+w = World.from_scene(s)
+out = (C.c_ulonglong * 8)()
+lib.sfx_debug_tile_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+for _ in range(10):
+    w.step(bench.DT)
+lib.sfx_debug_tile_timing(w.handle, out, 1)
+for _ in range(10):
+    w.step(bench.DT)
+lib.sfx_debug_tile_timing(w.handle, out, 1)
+o = list(out)
+tiles = max(o[4], 1)
+print("per tile (us): load %.2f narrow %.2f colours %.2f total %.2f  tiles/launch %.0f  mean colours %.2f" % (
+    o[0] / tiles / 100, o[1] / tiles / 100, o[2] / tiles / 100, o[3] / tiles / 100, tiles / 160, o[5] / tiles))

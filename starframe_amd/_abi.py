@@ -23,6 +23,9 @@ SHAPE_NONE, SHAPE_CIRCLE, SHAPE_RECT, SHAPE_CAPSULE, SHAPE_POLY = 0, 1, 2, 3, 4
 MAX_POLY_VERTS = 8
 WORLD_BODY = 0xFFFFFFFF
 MAX_COLORS = 64
+TILE_MAX_PAIRS = 2048
+TILE_MAX_BODIES = 512
+FALLBACK_TILE = 0xFFFFFFFF
 
 CFG_USE_GRAPH = 1
 CFG_NO_FRICTION = 2
@@ -40,9 +43,10 @@ class SfxConfig(C.Structure):
         ("grid_log2", C.c_uint32 * 2),
         ("max_pairs", C.c_uint32),
         ("color_rounds", C.c_uint32),
-        ("launch_colors", C.c_uint32),
+        ("tile_cells", C.c_uint32),
         ("restitution_threshold", C.c_float),
         ("max_depenetration_velocity", C.c_float),
+        ("speculative_margin", C.c_float),
         ("linear_damping", C.c_float),
         ("angular_damping", C.c_float),
         ("flags", C.c_uint32),
@@ -63,6 +67,10 @@ class SfxFrameStats(C.Structure):
         ("n_joint_colors", C.c_uint32),
         ("overflow", C.c_uint32),
         ("launches", C.c_uint32),
+        ("n_tiles", C.c_uint32),
+        ("n_fallback", C.c_uint32),
+        ("max_tile_pairs", C.c_uint32),
+        ("max_tile_bodies", C.c_uint32),
         ("max_depth", C.c_float),
         ("kinetic_energy", C.c_float),
         ("color_count", C.c_uint32 * MAX_COLORS),
@@ -73,7 +81,7 @@ class SfxKernelTime(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("launches", C.c_uint64), ("items", C.c_uint64)]
 
 
-K_CLASSES = 16
+K_CLASSES = 14
 
 collider_dtype = np.dtype(
     [
@@ -124,9 +132,10 @@ def make_config(
     grid_log2=(0, 0),
     max_pairs=0,
     color_rounds=0,
-    launch_colors=0,
+    tile_cells=0,
     restitution_threshold=0.0,
     max_depenetration_velocity=0.0,
+    speculative_margin=0.0,
     linear_damping=0.0,
     angular_damping=0.0,
     flags=0,
@@ -143,9 +152,10 @@ def make_config(
     cfg.grid_log2[0], cfg.grid_log2[1] = grid_log2
     cfg.max_pairs = max_pairs
     cfg.color_rounds = color_rounds
-    cfg.launch_colors = launch_colors
+    cfg.tile_cells = tile_cells
     cfg.restitution_threshold = restitution_threshold
     cfg.max_depenetration_velocity = max_depenetration_velocity
+    cfg.speculative_margin = speculative_margin
     cfg.linear_damping = linear_damping
     cfg.angular_damping = angular_damping
     cfg.flags = flags
@@ -196,7 +206,7 @@ def load_libsfx(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIBSFX_PATH
+    p = path or os.environ.get("SFX_LIBRARY") or LIBSFX_PATH  # SFX_LIBRARY: another build of libsfx (tuning runs)
     if not os.path.exists(p):
         raise RuntimeError(
             f"libsfx.so not found at {p}: build it with __graft_entry__.build() "
@@ -219,7 +229,7 @@ def load_libsfx(path=None):
     lib.sfx_sync.restype = C.c_int
     lib.sfx_debug_aabbs.argtypes = [vp, P(C.c_float)]
     lib.sfx_debug_pairs.argtypes = [vp, vp, C.c_size_t, P(C.c_size_t)]
-    lib.sfx_debug_pair_colors.argtypes = [vp, vp, vp, C.c_size_t, P(C.c_size_t)]
+    lib.sfx_debug_pair_colors.argtypes = [vp, vp, vp, vp, C.c_size_t, P(C.c_size_t)]
     lib.sfx_debug_broadphase.argtypes = [vp, C.c_float]
     lib.sfx_debug_contacts.argtypes = [vp, vp, C.c_size_t, P(C.c_size_t)]
     lib.sfx_debug_joint_order.argtypes = [vp, vp, vp, C.c_size_t, P(C.c_size_t)]

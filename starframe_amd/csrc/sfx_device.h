@@ -109,6 +109,17 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     return x;
 }
 
+__device__ __forceinline__ uint32_t edge_hash(uint32_t u, uint32_t v, uint32_t r) {
+    return mix32((u * 0x9E3779B1u) ^ mix32(v + r * 0x7F4A7C15u + 0x165667B1u));
+}
+
+// 6 bits of (63 - round) | 10 bits of hash | 24 + 24 bits of key: unique per edge and round,
+// independent of where the edge sits in any list
+__device__ __forceinline__ unsigned long long edge_prio(uint32_t u, uint32_t v, uint32_t r, uint32_t h) {
+    return ((unsigned long long)(63u - r) << 58) | ((unsigned long long)(h >> 22) << 48) |
+           ((unsigned long long)(u & 0xFFFFFFu) << 24) | (unsigned long long)(v & 0xFFFFFFu);
+}
+
 __device__ __forceinline__ uint32_t kth_set_bit(uint64_t m, uint32_t k) {
     for (uint32_t i = 0; i < k; ++i) m &= m - 1;
     return (uint32_t)__builtin_ctzll(m);
@@ -189,17 +200,18 @@ __device__ __forceinline__ void build_core(const float4& pose, const float4& sha
     }
 }
 
-__device__ __forceinline__ void cc_manifold(float ax, float ay, float ar, float bx, float by, float br, Manifold& m) {
+__device__ __forceinline__ void cc_manifold(float ax, float ay, float ar, float bx, float by, float br, float sm, Manifold& m) {
     float dx = bx - ax, dy = by - ay;
     float d2 = dx * dx + dy * dy;
     float rsum = ar + br;
+    float reach = rsum + sm;
     m.count = 0;
-    if (d2 > rsum * rsum) return;
+    if (d2 > reach * reach) return;
     float dist = sqrtf(d2);
     float nx = 0.0f, ny = 1.0f;
     if (dist > SFX_EPS_LEN) { nx = dx / dist; ny = dy / dist; }
     float depth = rsum - dist;
-    if (!(depth > 0.0f)) return;
+    if (!(depth > -sm)) return;
     m.count = 1; m.nx = nx; m.ny = ny; m.depth[0] = depth;
     m.p1x[0] = ax + nx * ar; m.p1y[0] = ay + ny * ar;
     m.p2x[0] = bx - nx * br; m.p2y[0] = by - ny * br;
@@ -232,8 +244,9 @@ __device__ __forceinline__ void closest_on_poly(const Core<MAXV>& P, float cx, f
 
 // polygon P (n >= 2) against a circle: normal from P to the circle
 template <int MAXV>
-__device__ __forceinline__ void pc_manifold(const Core<MAXV>& P, float cx, float cy, float cr, Manifold& m) {
+__device__ __forceinline__ void pc_manifold(const Core<MAXV>& P, float cx, float cy, float cr, float sm, Manifold& m) {
     float rsum = P.r + cr;
+    float reach = rsum + sm;
     float sep = -INFINITY, snx = 0.0f, sny = 0.0f;
     m.count = 0;
 #pragma unroll
@@ -243,12 +256,12 @@ __device__ __forceinline__ void pc_manifold(const Core<MAXV>& P, float cx, float
             if (s > sep) { sep = s; snx = P.nx[k]; sny = P.ny[k]; }
         }
     }
-    if (sep > rsum) return;
+    if (sep > reach) return;
     float nx, ny, qx, qy, depth;
     if (P.n == 2 || sep > 0.0f) {
         float d2;
         closest_on_poly<MAXV>(P, cx, cy, qx, qy, d2);
-        if (d2 > rsum * rsum) return;
+        if (d2 > reach * reach) return;
         float dist = sqrtf(d2);
         if (dist > SFX_EPS_LEN) { nx = (cx - qx) / dist; ny = (cy - qy) / dist; }
         else { nx = snx; ny = sny; }
@@ -258,16 +271,20 @@ __device__ __forceinline__ void pc_manifold(const Core<MAXV>& P, float cx, float
         qx = cx - nx * sep; qy = cy - ny * sep;
         depth = rsum - sep;
     }
-    if (!(depth > 0.0f)) return;
+    if (!(depth > -sm)) return;
     m.count = 1; m.nx = nx; m.ny = ny; m.depth[0] = depth;
     m.p1x[0] = qx + nx * P.r; m.p1y[0] = qy + ny * P.r;
     m.p2x[0] = cx - nx * cr;  m.p2y[0] = cy - ny * cr;
 }
 
+// Largest separation of Q from the faces of P (first maximum wins).  The winning face is
+// returned by value (normal, its two end points), never as an index: an index would have to be
+// looked up in the register arrays again, which the compiler turns into scratch memory.
 template <int MAXV>
-__device__ __forceinline__ float sat_sep(const Core<MAXV>& P, const Core<MAXV>& Q, int& kbest) {
+__device__ __forceinline__ float sat_sep(const Core<MAXV>& P, const Core<MAXV>& Q, float& fnx, float& fny,
+                                         float& f1x, float& f1y, float& f2x, float& f2y) {
     float best = -INFINITY;
-    int bk = 0;
+    fnx = 0.0f; fny = 0.0f; f1x = 0.0f; f1y = 0.0f; f2x = 0.0f; f2y = 0.0f;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
         if (k < P.n) {
@@ -279,50 +296,57 @@ __device__ __forceinline__ float sat_sep(const Core<MAXV>& P, const Core<MAXV>& 
                     if (d < s) s = d;
                 }
             }
-            if (s > best) { best = s; bk = k; }
+            const bool wrap = (k + 1 == P.n) || (k + 1 == MAXV);
+            const float x1 = wrap ? P.vx[0] : P.vx[(k + 1) % MAXV];
+            const float y1 = wrap ? P.vy[0] : P.vy[(k + 1) % MAXV];
+            if (s > best) {
+                best = s;
+                fnx = P.nx[k]; fny = P.ny[k];
+                f1x = P.vx[k]; f1y = P.vy[k];
+                f2x = x1; f2y = y1;
+            }
         }
     }
-    kbest = bk;
     return best;
 }
 
 // polygon against polygon (both n >= 2); normal from A to B
 template <int MAXV>
-__device__ __forceinline__ void pp_manifold(const Core<MAXV>& A, const Core<MAXV>& B, Manifold& m) {
-    int ka, kb;
+__device__ __forceinline__ void pp_manifold(const Core<MAXV>& A, const Core<MAXV>& B, float sm, Manifold& m) {
     const float rsum = A.r + B.r;
+    const float reach = rsum + sm;
     m.count = 0;
-    float sa = sat_sep<MAXV>(A, B, ka);
-    if (sa > rsum) return;
-    float sb = sat_sep<MAXV>(B, A, kb);
-    if (sb > rsum) return;
+    float anx, any, a1x, a1y, a2x, a2y, bnx, bny, b1x, b1y, b2x, b2y;
+    float sa = sat_sep<MAXV>(A, B, anx, any, a1x, a1y, a2x, a2y);
+    if (sa > reach) return;
+    float sb = sat_sep<MAXV>(B, A, bnx, bny, b1x, b1y, b2x, b2y);
+    if (sb > reach) return;
     const bool flip = sb > sa;
-    // reference R / incident I, selected element-wise (keeps everything in registers)
-    Core<MAXV> R, I;
-    R.n = flip ? B.n : A.n; I.n = flip ? A.n : B.n;
-    R.r = flip ? B.r : A.r; I.r = flip ? A.r : B.r;
+    // reference face (by value) and incident polygon I, selected element-wise
+    const float nrx = flip ? bnx : anx, nry = flip ? bny : any;
+    const float r1x = flip ? b1x : a1x, r1y = flip ? b1y : a1y, r2x = flip ? b2x : a2x, r2y = flip ? b2y : a2y;
+    Core<MAXV> I;
+    I.n = flip ? A.n : B.n;
+    I.r = flip ? A.r : B.r;
+    const float rr_sel = flip ? B.r : A.r;
 #pragma unroll
     for (int k = 0; k < MAXV; ++k) {
-        R.vx[k] = flip ? B.vx[k] : A.vx[k]; R.vy[k] = flip ? B.vy[k] : A.vy[k];
-        R.nx[k] = flip ? B.nx[k] : A.nx[k]; R.ny[k] = flip ? B.ny[k] : A.ny[k];
         I.vx[k] = flip ? A.vx[k] : B.vx[k]; I.vy[k] = flip ? A.vy[k] : B.vy[k];
         I.nx[k] = flip ? A.nx[k] : B.nx[k]; I.ny[k] = flip ? A.ny[k] : B.ny[k];
     }
-    const int kr = flip ? kb : ka;
-    const int kr1 = (kr + 1 == R.n) ? 0 : kr + 1;
-    const float nrx = pick(R.nx, kr), nry = pick(R.ny, kr);
-    const float r1x = pick(R.vx, kr), r1y = pick(R.vy, kr), r2x = pick(R.vx, kr1), r2y = pick(R.vy, kr1);
+    // incident edge: most anti-parallel normal, first minimum, again tracked by value
     float bestd = INFINITY;
-    int ki = 0;
+    float i1x = 0.0f, i1y = 0.0f, i2x = 0.0f, i2y = 0.0f;
 #pragma unroll
     for (int j = 0; j < MAXV; ++j) {
         if (j < I.n) {
             float d = I.nx[j] * nrx + I.ny[j] * nry;
-            if (d < bestd) { bestd = d; ki = j; }
+            const bool wrap = (j + 1 == I.n) || (j + 1 == MAXV);
+            const float x1 = wrap ? I.vx[0] : I.vx[(j + 1) % MAXV];
+            const float y1 = wrap ? I.vy[0] : I.vy[(j + 1) % MAXV];
+            if (d < bestd) { bestd = d; i1x = I.vx[j]; i1y = I.vy[j]; i2x = x1; i2y = y1; }
         }
     }
-    const int ki1 = (ki + 1 == I.n) ? 0 : ki + 1;
-    const float i1x = pick(I.vx, ki), i1y = pick(I.vy, ki), i2x = pick(I.vx, ki1), i2y = pick(I.vy, ki1);
     const float tx = -nry, ty = nrx;
     const float L = (r2x - r1x) * tx + (r2y - r1y) * ty;
     const float u1 = (i1x - r1x) * tx + (i1y - r1y) * ty;
@@ -340,7 +364,7 @@ __device__ __forceinline__ void pp_manifold(const Core<MAXV>& A, const Core<MAXV
         empty = true;
     }
     if (ta > tb) empty = true;
-    const float rr = R.r, ri = I.r;
+    const float rr = rr_sel, ri = I.r;
     float nx, ny;
     float prx[2], pry[2], pix[2], piy[2], dep[2];
     int cnt = 0;
@@ -355,7 +379,7 @@ __device__ __forceinline__ void pp_manifold(const Core<MAXV>& A, const Core<MAXV
                 float cx = i1x + tk * ex, cy = i1y + tk * ey;
                 float s = (cx - r1x) * nrx + (cy - r1y) * nry;
                 float d = rsum - s;
-                if (d > 0.0f) {
+                if (d > -sm) {
                     float fx = (cx - nrx * s) + nrx * rr, fy = (cy - nry * s) + nry * rr;
                     float gx = cx - nrx * ri, gy = cy - nry * ri;
                     if (cnt == 0) { prx[0] = fx; pry[0] = fy; pix[0] = gx; piy[0] = gy; dep[0] = d; }
@@ -369,12 +393,12 @@ __device__ __forceinline__ void pp_manifold(const Core<MAXV>& A, const Core<MAXV
         float vx = lowend ? r1x : r2x, vy = lowend ? r1y : r2y;
         float qx, qy, d2;
         closest_on_poly<MAXV>(I, vx, vy, qx, qy, d2);
-        if (d2 > rsum * rsum) return;
+        if (d2 > reach * reach) return;
         float dist = sqrtf(d2);
         if (dist > SFX_EPS_LEN) { nx = (qx - vx) / dist; ny = (qy - vy) / dist; }
         else { nx = nrx; ny = nry; }
         float d = rsum - dist;
-        if (d > 0.0f) {
+        if (d > -sm) {
             prx[0] = vx + nx * rr; pry[0] = vy + ny * rr;
             pix[0] = qx - nx * ri; piy[0] = qy - ny * ri;
             dep[0] = d;
@@ -397,45 +421,46 @@ __device__ __forceinline__ void pp_manifold(const Core<MAXV>& A, const Core<MAXV
 
 template <int MAXV>
 __device__ __forceinline__ void manifold_poly(const float4& pa, const float4& sa, const float4& pb, const float4& sb,
-                                              const float4* __restrict__ poly, Manifold& m) {
+                                              const float4* __restrict__ poly, float sm, Manifold& m) {
     const uint32_t ta = shape_type(sa), tb = shape_type(sb);
     if (tb == SFX_SHAPE_CIRCLE) {
         Core<MAXV> A;
         build_core<MAXV>(pa, sa, poly, A);
-        if (A.n >= 2) pc_manifold<MAXV>(A, pb.x, pb.y, sb.w, m);
+        if (A.n >= 2) pc_manifold<MAXV>(A, pb.x, pb.y, sb.w, sm, m);
     } else if (ta == SFX_SHAPE_CIRCLE) {
         Core<MAXV> B;
         build_core<MAXV>(pb, sb, poly, B);
         if (B.n >= 2) {
-            Manifold t;
-            pc_manifold<MAXV>(B, pa.x, pa.y, sa.w, t);
-            m.count = t.count;
-            if (t.count) {
-                m.nx = -t.nx; m.ny = -t.ny; m.depth[0] = t.depth[0];
-                m.p1x[0] = t.p2x[0]; m.p1y[0] = t.p2y[0];
-                m.p2x[0] = t.p1x[0]; m.p2y[0] = t.p1y[0];
+            // solved as B against the circle, then turned round in place
+            pc_manifold<MAXV>(B, pa.x, pa.y, sa.w, sm, m);
+            if (m.count) {
+                m.nx = -m.nx; m.ny = -m.ny;
+                const float tx = m.p1x[0], ty = m.p1y[0];
+                m.p1x[0] = m.p2x[0]; m.p1y[0] = m.p2y[0];
+                m.p2x[0] = tx; m.p2y[0] = ty;
             }
         }
     } else {
         Core<MAXV> A, B;
         build_core<MAXV>(pa, sa, poly, A);
         build_core<MAXV>(pb, sb, poly, B);
-        if (A.n >= 2 && B.n >= 2) pp_manifold<MAXV>(A, B, m);
+        if (A.n >= 2 && B.n >= 2) pp_manifold<MAXV>(A, B, sm, m);
     }
 }
 
-// manifold of two posed shapes, normal from a to b
+// manifold of two posed shapes, normal from a to b; points up to `sm` apart are kept with
+// their negative depth (speculative margin)
 __device__ __forceinline__ void manifold(const float4& pa, const float4& sa, const float4& pb, const float4& sb,
-                                         const float4* __restrict__ poly, Manifold& m) {
+                                         const float4* __restrict__ poly, float sm, Manifold& m) {
     const uint32_t ta = shape_type(sa), tb = shape_type(sb);
     m.count = 0;
     if (ta == SFX_SHAPE_NONE || tb == SFX_SHAPE_NONE) return;
     if (ta == SFX_SHAPE_CIRCLE && tb == SFX_SHAPE_CIRCLE) {
-        cc_manifold(pa.x, pa.y, sa.w, pb.x, pb.y, sb.w, m);
+        cc_manifold(pa.x, pa.y, sa.w, pb.x, pb.y, sb.w, sm, m);
     } else if (ta == SFX_SHAPE_POLY || tb == SFX_SHAPE_POLY) {
-        manifold_poly<8>(pa, sa, pb, sb, poly, m);
+        manifold_poly<8>(pa, sa, pb, sb, poly, sm, m);
     } else {
-        manifold_poly<4>(pa, sa, pb, sb, poly, m);
+        manifold_poly<4>(pa, sa, pb, sb, poly, sm, m);
     }
 }
 
@@ -471,47 +496,69 @@ __device__ __forceinline__ void solve_lcp2(float K00, float K01, float K11, floa
     else { l0 = 0.0f; l1 = fmaxf(d1, 0.0f) / K11; }
 }
 
-// Position solve of one candidate pair: narrowphase at the current poses, block solve of
-// the manifold's normal constraints, poses written back.  Mueller et al. 2020 sec. 3.5.
-__device__ __forceinline__ void solve_pos_pair(const BodyArrays& B, const ContactArrays& C, uint32_t slot,
-                                               uint32_t a, uint32_t b, float max_corr) {
-    float4 pa = B.pose[a], pb = B.pose[b];
-    const float4 sa = B.shape[a], sb = B.shape[b];
+// What the narrowphase of one candidate pair leaves for the solves, in registers.
+struct PairRec {
+    int count;             // 0, 1 or 2 points
+    float nx, ny;          // from a to b
+    float mu_s, mu_d, rest;
+    float la[2][2], lb[2][2];  // body-local anchors
+    float vpre[2];         // normal relative velocity before the position solve
+    float l0, l1;          // normal lambdas of this substep
+};
+
+// Narrowphase of one candidate pair at the poses of the batch start (DESIGN.md "Contract /
+// batches"): manifold, body-local anchors, pre-solve normal velocities, combined material.
+__device__ __forceinline__ void prepare_pair(const float4& pa, const float4& sa, const float4& va,
+                                             const float4& pb, const float4& sb, const float4& vb,
+                                             const float4* __restrict__ poly, const float4* __restrict__ mats,
+                                             float sm, PairRec& r) {
     Manifold m;
-    manifold(pa, sa, pb, sb, B.poly, m);
-    if (m.count == 0) {
-        C.misc[slot] = make_float2(0.0f, __uint_as_float(0u));
-        return;
-    }
-    const float4 ma = B.mats[shape_material(sa)], mb = B.mats[shape_material(sb)];
-    const float2 wa = B.mass[a], wb = B.mass[b];
-    const float4 va = B.vel[a], vb = B.vel[b];
-    const float mu_s = 0.5f * (ma.y + mb.y);
-    const float mu_d = 0.5f * (ma.z + mb.z);
-    const float rest = fmaxf(ma.x, mb.x);
-    const float nx = m.nx, ny = m.ny;
-    const float ima = wa.x, iia = wa.y, imb = wb.x, iib = wb.y;
-    float la[2][2], lb[2][2], d[2], cna[2], cnb[2], vpre[2];
-    la[1][0] = la[1][1] = lb[1][0] = lb[1][1] = 0.0f;
-    d[1] = 0.0f; cna[1] = 0.0f; cnb[1] = 0.0f; vpre[1] = 0.0f;
+    manifold(pa, sa, pb, sb, poly, sm, m);
+    r.count = m.count;
+    r.l0 = 0.0f; r.l1 = 0.0f;
+    r.nx = 0.0f; r.ny = 0.0f; r.mu_s = 0.0f; r.mu_d = 0.0f; r.rest = 0.0f;
+    r.la[0][0] = r.la[0][1] = r.lb[0][0] = r.lb[0][1] = 0.0f;
+    r.la[1][0] = r.la[1][1] = r.lb[1][0] = r.lb[1][1] = 0.0f;
+    r.vpre[0] = r.vpre[1] = 0.0f;
+    if (m.count == 0) return;
+    const float4 ma = mats[shape_material(sa)], mb = mats[shape_material(sb)];
+    r.mu_s = 0.5f * (ma.y + mb.y);
+    r.mu_d = 0.5f * (ma.z + mb.z);
+    r.rest = fmaxf(ma.x, mb.x);
+    r.nx = m.nx; r.ny = m.ny;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (k < m.count) {
             float ax = m.p1x[k] - pa.x, ay = m.p1y[k] - pa.y;
             float bx = m.p2x[k] - pb.x, by = m.p2y[k] - pb.y;
-            la[k][0] = pa.z * ax + pa.w * ay; la[k][1] = pa.z * ay - pa.w * ax;
-            lb[k][0] = pb.z * bx + pb.w * by; lb[k][1] = pb.z * by - pb.w * bx;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (k < m.count) {
+            r.la[k][0] = pa.z * ax + pa.w * ay; r.la[k][1] = pa.z * ay - pa.w * ax;
+            r.lb[k][0] = pb.z * bx + pb.w * by; r.lb[k][1] = pb.z * by - pb.w * bx;
             float rax, ray, rbx, rby;
-            anchor_world(pa, la[k][0], la[k][1], rax, ray);
-            anchor_world(pb, lb[k][0], lb[k][1], rbx, rby);
+            anchor_world(pa, r.la[k][0], r.la[k][1], rax, ray);
+            anchor_world(pb, r.lb[k][0], r.lb[k][1], rbx, rby);
             float vax = va.x - va.z * ray, vay = va.y + va.z * rax;
             float vbx = vb.x - vb.z * rby, vby = vb.y + vb.z * rbx;
-            vpre[k] = (vbx - vax) * nx + (vby - vay) * ny;
+            r.vpre[k] = (vbx - vax) * m.nx + (vby - vay) * m.ny;
+        }
+    }
+}
+
+// Position solve of one prepared pair at the current poses: penetration re-evaluated from the
+// anchors, the manifold's normal constraints solved as a block, poses updated in registers.
+// Returns true when the poses changed.  Mueller et al. 2020 sec. 3.5.
+__device__ __forceinline__ bool solve_pos_rec(PairRec& r, float4& pa, const float2& wa, float4& pb, const float2& wb,
+                                              float max_corr) {
+    if (r.count == 0) return false;
+    const float nx = r.nx, ny = r.ny;
+    const float ima = wa.x, iia = wa.y, imb = wb.x, iib = wb.y;
+    float d[2], cna[2], cnb[2];
+    d[1] = 0.0f; cna[1] = 0.0f; cnb[1] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k < r.count) {
+            float rax, ray, rbx, rby;
+            anchor_world(pa, r.la[k][0], r.la[k][1], rax, ray);
+            anchor_world(pb, r.lb[k][0], r.lb[k][1], rbx, rby);
             d[k] = ((pa.x + rax) - (pb.x + rbx)) * nx + ((pa.y + ray) - (pb.y + rby)) * ny;
             d[k] = fminf(d[k], max_corr);  // bounded depenetration per substep
             cna[k] = rax * ny - ray * nx;
@@ -521,22 +568,17 @@ __device__ __forceinline__ void solve_pos_pair(const BodyArrays& B, const Contac
     float l0 = 0.0f, l1 = 0.0f;
     const float ims = ima + imb;
     const float K00 = (ims + iia * (cna[0] * cna[0])) + iib * (cnb[0] * cnb[0]);
-    if (K00 > 0.0f) {
-        if (m.count == 2) {
-            float K11 = (ims + iia * (cna[1] * cna[1])) + iib * (cnb[1] * cnb[1]);
-            float K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
-            solve_lcp2(K00, K01, K11, d[0], d[1], l0, l1);
-        } else {
-            l0 = fmaxf(d[0], 0.0f) / K00;
-        }
+    if (!(K00 > 0.0f)) return false;
+    if (r.count == 2) {
+        float K11 = (ims + iia * (cna[1] * cna[1])) + iib * (cnb[1] * cnb[1]);
+        float K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
+        solve_lcp2(K00, K01, K11, d[0], d[1], l0, l1);
+    } else {
+        l0 = fmaxf(d[0], 0.0f) / K00;
     }
-    C.hdr[slot] = make_float4(nx, ny, mu_s, mu_d);
-    C.misc[slot] = make_float2(rest, __uint_as_float((uint32_t)m.count));
-    C.anc0[slot] = make_float4(la[0][0], la[0][1], lb[0][0], lb[0][1]);
-    if (m.count == 2) C.anc1[slot] = make_float4(la[1][0], la[1][1], lb[1][0], lb[1][1]);
-    C.lamv[slot] = make_float4(l0, l1, vpre[0], vpre[1]);
+    r.l0 = l0; r.l1 = l1;
     const float lt = l0 + l1;
-    if (!(lt > 0.0f)) return;
+    if (!(lt > 0.0f)) return false;
     if (ima > 0.0f) {
         pa.x = pa.x - (nx * lt) * ima;
         pa.y = pa.y - (ny * lt) * ima;
@@ -547,8 +589,7 @@ __device__ __forceinline__ void solve_pos_pair(const BodyArrays& B, const Contac
         pb.y = pb.y + (ny * lt) * imb;
     }
     if (iib > 0.0f) rotate_by(pb.z, pb.w, iib * (cnb[0] * l0 + cnb[1] * l1));
-    if (ima > 0.0f || iia > 0.0f) B.pose[a] = pa;
-    if (imb > 0.0f || iib > 0.0f) B.pose[b] = pb;
+    return true;
 }
 
 __device__ __forceinline__ void kinv_apply(float K0, float K1, float K01, bool act0, bool act1, int count,
@@ -579,25 +620,17 @@ struct StepParams {
     uint32_t flags;
 };
 
-// Velocity pass of one candidate pair: restitution block, then friction with compensating
-// normal impulses (static friction also shifts the poses).  Mueller et al. 2020 sec. 3.6.
-__device__ __forceinline__ void solve_vel_pair(const BodyArrays& B, const ContactArrays& C, uint32_t slot,
-                                               uint32_t a, uint32_t b, const StepParams& sp) {
-    const float2 misc = C.misc[slot];
-    const int count = (int)__float_as_uint(misc.y);
-    if (count == 0) return;
-    const float4 lamv = C.lamv[slot];
-    const float l0 = lamv.x, l1 = count == 2 ? lamv.y : 0.0f;
+// Velocity pass of one prepared pair: restitution block, then friction with compensating
+// normal impulses (static friction also shifts the poses).  Works on registers; returns bit 0
+// when the velocities changed and bit 1 when the poses changed.  Mueller et al. 2020 sec. 3.6.
+__device__ __forceinline__ int solve_vel_rec(const PairRec& r, float4& pa, float4& va, const float2& wa,
+                                             float4& pb, float4& vb, const float2& wb, const StepParams& sp) {
+    const int count = r.count;
+    if (count == 0) return 0;
+    const float l0 = r.l0, l1 = count == 2 ? r.l1 : 0.0f;
     const float lt = l0 + l1;
-    if (!(lt > 0.0f)) return;
-    const float4 hdr = C.hdr[slot];
-    const float nx = hdr.x, ny = hdr.y, mu_s = hdr.z, mu_d = hdr.w, rest = misc.x;
-    const float4 a0 = C.anc0[slot];
-    float4 a1 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (count == 2) a1 = C.anc1[slot];
-    float4 pa = B.pose[a], pb = B.pose[b];
-    float4 va = B.vel[a], vb = B.vel[b];
-    const float2 wa = B.mass[a], wb = B.mass[b];
+    if (!(lt > 0.0f)) return 0;
+    const float nx = r.nx, ny = r.ny, mu_s = r.mu_s, mu_d = r.mu_d, rest = r.rest;
     const float ima = wa.x, iia = wa.y, imb = wb.x, iib = wb.y;
     const float ims = ima + imb;
     float rax[2], ray[2], rbx[2], rby[2], dv[2], cna[2], cnb[2], K[2];
@@ -607,11 +640,10 @@ __device__ __forceinline__ void solve_vel_pair(const BodyArrays& B, const Contac
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (k < count) {
-            const float4 an = k == 0 ? a0 : a1;
-            const float lam = k == 0 ? lamv.x : lamv.y;
-            const float vpre = k == 0 ? lamv.z : lamv.w;
-            anchor_world(pa, an.x, an.y, rax[k], ray[k]);
-            anchor_world(pb, an.z, an.w, rbx[k], rby[k]);
+            const float lam = k == 0 ? r.l0 : r.l1;
+            const float vpre = r.vpre[k];
+            anchor_world(pa, r.la[k][0], r.la[k][1], rax[k], ray[k]);
+            anchor_world(pb, r.lb[k][0], r.lb[k][1], rbx[k], rby[k]);
             float vax = va.x - va.z * ray[k], vay = va.y + va.z * rax[k];
             float vbx = vb.x - vb.z * rby[k], vby = vb.y + vb.z * rbx[k];
             float vn = (vbx - vax) * nx + (vby - vay) * ny;
@@ -689,9 +721,7 @@ __device__ __forceinline__ void solve_vel_pair(const BodyArrays& B, const Contac
             }
         }
     }
-    const bool dyn_a = ima > 0.0f || iia > 0.0f, dyn_b = imb > 0.0f || iib > 0.0f;
-    if (dyn_a) { B.vel[a] = va; if (shift) B.pose[a] = pa; }
-    if (dyn_b) { B.vel[b] = vb; if (shift) B.pose[b] = pb; }
+    return shift ? 3 : 1;
 }
 
 // distance constraint (Mueller et al. 2020 sec. 3.3, XPBD compliance), lambda restarts at 0

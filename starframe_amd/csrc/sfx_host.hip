@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -16,6 +17,11 @@
 #include "sfx_kernels.h"
 
 using namespace sfx;
+
+#ifndef SFX_TILE_THREADS
+#define SFX_TILE_THREADS 128
+#endif
+constexpr int kTileThreads = SFX_TILE_THREADS;  // workgroup size of the tile solves = pairs on the register path
 
 namespace {
 
@@ -45,6 +51,7 @@ struct sfx_world {
     sfx_config cfg{};
     std::string err;
     hipStream_t stream = nullptr;
+    bool own_stream = true;
     int device = 0;
     // resolved
     float cell = 1.0f, inv_cell = 1.0f;
@@ -58,16 +65,23 @@ struct sfx_world {
     DevBuf<float4> pose, prev, vel, shape, poly, mats, aabb, sorted_aabb;
     DevBuf<float2> mass;
     DevBuf<uint4> filt;
-    // broadphase
-    DevBuf<uint32_t> bucket, cell_start, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, scan_sums;
+    // broadphase.  `zero` is one allocation cleared by a single memset per tick:
+    // [Counters][cell_start: ncell + 1 + pad][tile_cnt: ntiles + 1 + pad][tile_fill: ntiles][tile_flag: ntiles]
+    DevBuf<uint32_t> zero;
+    Counters* ctr = nullptr;
+    uint32_t *cell_start = nullptr, *tile_cnt = nullptr, *tile_fill = nullptr, *tile_flag = nullptr;
+    size_t zero_bytes = 0;
+    DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, scan_sums, active, big_tiles, tile_ncol;
     DevBuf<int2> cellxy, sorted_cell;
-    DevBuf<uint2> pairs, cpairs;
-    uint32_t large_cap = 0;
-    // colouring
+    DevBuf<uint4> rawp, tpair;
+    DevBuf<uint2> fpairs, fsorted;
+    uint32_t large_cap = 0, ntiles = 4, fb_cap = 0, tl = 1;
+    // colouring of global edge lists (joints at upload, the fallback list every tick)
     DevBuf<unsigned long long> used, claim;
     DevBuf<uint32_t> deg, left_list;
     DevBuf<uint8_t> pcolor, prop;
-    DevBuf<Counters> ctr, jctr;
+    DevBuf<Counters> jctr;
+    DevBuf<unsigned long long> dbg;  // -DSFX_TILE_TIMING builds: stage timing of k_tile_pos
     // contact records
     DevBuf<float4> c_hdr, c_anc0, c_anc1, c_lamv;
     DevBuf<float2> c_misc;
@@ -85,6 +99,7 @@ struct sfx_world {
     bool ctr_pending = false, ctr_valid = false;
     Counters stale{};
     uint32_t launches = 0;
+    uint32_t color_grid = 512, big_grid = 64, tile_grid[4] = {1024, 1024, 1024, 1024}, tile_grid_max = 8192;
     bool ticked = false;
     // profiling
     bool profiling = false;
@@ -125,8 +140,9 @@ void resolve_defaults(sfx_config& c) {
     if (c.substeps == 0) c.substeps = 1;
     if (c.color_rounds == 0) c.color_rounds = 12;
     if (c.color_rounds > 60) c.color_rounds = 60;
-    if (c.launch_colors == 0) c.launch_colors = 16;
-    if (c.launch_colors > SFX_MAX_COLORS) c.launch_colors = SFX_MAX_COLORS;
+    c.tile_cells = c.tile_cells >= 8 ? 8u : c.tile_cells >= 4 ? 4u : c.tile_cells >= 2 ? 2u : 1u;
+    if (c.speculative_margin == 0.0f) c.speculative_margin = 0.005f;
+    if (c.speculative_margin < 0.0f) c.speculative_margin = 0.0f;
     if (c.restitution_threshold == 0.0f) c.restitution_threshold = 2.0f;
     if (c.vel_pad_max == 0.0f) c.vel_pad_max = 0.03f;
     if (c.max_depenetration_velocity == 0.0f) c.max_depenetration_velocity = 3.0f;
@@ -180,14 +196,16 @@ void resolve_grid(sfx_world* w) {
     if (gx == 0 || gy == 0) {
         uint32_t side = (uint32_t)std::ceil(std::sqrt(2.0 * (double)(w->n ? w->n : 1)));
         uint32_t l = ceil_log2(side);
-        if (l < 2) l = 2;
         if (l > 12) l = 12;
         gx = gy = l;
     }
-    gx = std::min(std::max(gx, 2u), 12u);
-    gy = std::min(std::max(gy, 2u), 12u);
+    // at least 4 tiles per side, so that the 2x2 tile blocks of one phase never meet on the torus
+    w->tl = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : w->cfg.tile_cells == 2 ? 1u : 0u;
+    gx = std::min(std::max(gx, w->tl + 2u), 12u);
+    gy = std::min(std::max(gy, w->tl + 2u), 12u);
     w->gxl = gx; w->gyl = gy;
     w->ncell = (1u << gx) * (1u << gy);
+    w->ntiles = w->ncell >> (2u * w->tl);
 }
 
 GridParams grid_params(const sfx_world* w) {
@@ -195,6 +213,7 @@ GridParams grid_params(const sfx_world* w) {
     g.inv_cell = w->inv_cell;
     g.small_lim = 0.9f * w->cell;
     g.gxl = w->gxl; g.gyl = w->gyl; g.ncell = w->ncell;
+    g.tl = w->tl; g.ntiles = w->ntiles;
     return g;
 }
 
@@ -272,85 +291,73 @@ int scan_u32(sfx_world* w, uint32_t* data, uint32_t count, uint32_t* copy) {
 
 uint32_t edge_grid(uint32_t cap) { return std::min(std::max(cdiv(cap, kBlock), 1u), 2048u); }
 
-// colour ne edges (device count at n_edges) of `pairs`; result in w->pcolor, counters in ctr
-int color_graph(sfx_world* w, const uint2* pairs, const uint32_t* n_edges, uint32_t cap, Counters* ctr) {
-    const uint32_t n = w->n;
-    HIPCHK(w, hipMemsetAsync(w->used.p, 0, sizeof(unsigned long long) * std::max(n, 1u), w->stream));
-    HIPCHK(w, hipMemsetAsync(w->deg.p, 0, sizeof(uint32_t) * std::max(n, 1u), w->stream));
-    HIPCHK(w, hipMemsetAsync(w->claim.p, 0xFF, sizeof(unsigned long long) * 8 * std::max(n, 1u), w->stream));
-    w->launches += 3;
-    ColorArrays A;
-    A.pairs = pairs; A.filt = w->filt.p; A.used = w->used.p; A.deg = w->deg.p; A.claim = w->claim.p;
-    A.color = w->pcolor.p; A.prop = w->prop.p; A.left_list = w->left_list.p; A.n_edges = n_edges; A.ctr = ctr;
-    const uint32_t grid = edge_grid(cap);
-    { Prof p(w, SFX_K_COLOR, cap);
-      hipLaunchKernelGGL(k_color_init, dim3(grid), dim3(kBlock), 0, w->stream, A); }
-    const uint32_t R = w->cfg.color_rounds;
-    for (uint32_t r = 0; r < R; ++r) {
-        { Prof p(w, SFX_K_COLOR, cap);
-          hipLaunchKernelGGL(k_color_propose, dim3(grid), dim3(kBlock), 0, w->stream, A, r); }
-        { Prof p(w, SFX_K_COLOR, cap);
-          hipLaunchKernelGGL(k_color_resolve, dim3(grid), dim3(kBlock), 0, w->stream, A, r, r + 1 == R ? 1 : 0); }
-    }
-    { Prof p(w, SFX_K_COLOR, 1);
-      hipLaunchKernelGGL(k_color_finish, dim3(1), dim3(kBlock), 0, w->stream, A); }
-    { Prof p(w, SFX_K_COLOR_SORT, cap);
-      hipLaunchKernelGGL(k_color_hist, dim3(grid), dim3(kBlock), 0, w->stream, A); }
-    { Prof p(w, SFX_K_COLOR_SORT, 64);
-      hipLaunchKernelGGL(k_color_scan, dim3(1), dim3(64), 0, w->stream, ctr); }
-    return SFX_OK;
+TileArrays tile_arrays(sfx_world* w) {
+    TileArrays T;
+    T.cell_start = w->cell_start; T.sorted_id = w->sorted_id.p; T.tile_start = w->tile_cnt;
+    T.active = w->active.p; T.tpair = w->tpair.p; T.tile_ncol = w->tile_ncol.p; T.fsorted = w->fsorted.p;
+    T.max_pairs = w->max_pairs; T.fb_cap = w->fb_cap;
+    T.dbg = w->dbg.p;
+    return T;
 }
 
-int zero_tick_counters(sfx_world* w, Counters* ctr) {
-    HIPCHK(w, hipMemsetAsync(ctr, 0, sizeof(Counters), w->stream));
-    w->launches++;
-    return SFX_OK;
+// colour one global edge list with a single workgroup (k_color_global)
+void color_global(sfx_world* w, const uint2* edges, const uint32_t* n_edges, uint32_t cap, int key_by_index,
+                  uint2* sorted, uint32_t* start, uint32_t* n_colors_out, Counters* ctr, int tick_totals) {
+    GlobalColor A;
+    A.edges = edges; A.n_edges = n_edges; A.cap = cap; A.key_by_index = key_by_index;
+    A.filt = w->filt.p; A.used = w->used.p; A.deg = w->deg.p; A.claim = w->claim.p;
+    A.color = w->pcolor.p; A.prop = w->prop.p; A.left_list = w->left_list.p;
+    A.sorted = sorted; A.start = start; A.n_colors_out = n_colors_out;
+    A.rounds = w->cfg.color_rounds; A.ctr = ctr; A.tick_totals = tick_totals;
+    A.tile_start = w->tile_cnt; A.ntiles = w->ntiles; A.max_pairs = w->max_pairs;
+    Prof p(w, SFX_K_COLOR, cap);
+    hipLaunchKernelGGL(k_color_global, dim3(1), dim3(kGlobalColorBlock), 0, w->stream, A);
 }
 
 int broadphase(sfx_world* w, float dt) {
     const uint32_t n = w->n;
     const GridParams g = grid_params(w);
-    int rc = zero_tick_counters(w, w->ctr.p);
-    if (rc) return rc;
-    HIPCHK(w, hipMemsetAsync(w->cell_start.p, 0, sizeof(uint32_t) * (w->ncell + 1), w->stream));
-    w->launches++;
+    { Prof p(w, SFX_K_AABB_COUNT, 0);
+      const uint32_t n16 = (uint32_t)(w->zero_bytes / 16);
+      hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, reinterpret_cast<uint4*>(w->zero.p), n16); }
     const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
     { Prof p(w, SFX_K_AABB_COUNT, n);
       hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p,
-                         w->poly.p, w->cfg.aabb_margin, w->cfg.vel_pad_max, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start.p,
-                         w->large_tmp.p, w->large_cap, w->ctr.p); }
-    rc = scan_u32(w, w->cell_start.p, w->ncell + 1, w->cell_fill.p);
+                         w->poly.p, w->cfg.aabb_margin, w->cfg.vel_pad_max, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start,
+                         w->large_tmp.p, w->large_cap, w->ctr); }
+    int rc = scan_u32(w, w->cell_start, w->ncell + 1, w->cell_fill.p);
     if (rc) return rc;
     { Prof p(w, SFX_K_SCATTER, n);
       hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(kBlock), 0, w->stream, n, w->bucket.p, w->cell_fill.p, w->tmp_id.p); }
     { Prof p(w, SFX_K_SCATTER, n);
-      hipLaunchKernelGGL(k_finalize_slots, dim3(gb), dim3(kBlock), 0, w->stream, n, g, w->cell_start.p, w->tmp_id.p,
+      hipLaunchKernelGGL(k_finalize_slots, dim3(gb), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->tmp_id.p,
                          w->bucket.p, w->aabb.p, w->cellxy.p, w->large_tmp.p, w->large_cap, w->sorted_id.p,
-                         w->sorted_aabb.p, w->sorted_cell.p, w->ctr.p); }
-    // one 8-lane group per slot: (n + 1) slots / 32 per block
+                         w->sorted_aabb.p, w->sorted_cell.p, w->ctr); }
+    PairArrays P;
+    P.slot_cnt = w->slot_cnt.p; P.tile_cnt = w->tile_cnt; P.tile_fill = w->tile_fill; P.tile_flag = w->tile_flag;
+    P.rawp = w->rawp.p; P.fpairs = w->fpairs.p; P.max_pairs = w->max_pairs; P.fb_cap = w->fb_cap;
+    // one 8-lane group per slot: 32 slots per block
     const uint32_t gp = std::min(std::max(cdiv(n + 1, kBlock / kGroup), 1u), 8192u);
     { Prof p(w, SFX_K_PAIR_COUNT, n);
-      hipLaunchKernelGGL(k_pairs<false>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start.p, w->sorted_id.p,
-                         w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, w->slot_cnt.p, w->pairs.p, w->max_pairs,
-                         w->ctr.p, w->large_cap); }
-    rc = scan_u32(w, w->slot_cnt.p, n + 1, nullptr);
+      hipLaunchKernelGGL(k_pairs<false>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
+                         w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }
+    { Prof p(w, SFX_K_TILE_LIST, w->ntiles);
+      hipLaunchKernelGGL(k_tile_list, dim3(cdiv(w->ntiles, kBlock)), dim3(kBlock), 0, w->stream, g, w->cell_start,
+                         w->tile_cnt, w->tile_flag, w->active.p, w->big_tiles.p, w->ctr); }
+    rc = scan_u32(w, w->tile_cnt, w->ntiles + 1, nullptr);
     if (rc) return rc;
     { Prof p(w, SFX_K_PAIR_FILL, n);
-      hipLaunchKernelGGL(k_pairs<true>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start.p, w->sorted_id.p,
-                         w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, w->slot_cnt.p, w->pairs.p, w->max_pairs,
-                         w->ctr.p, w->large_cap); }
-    { Prof p(w, SFX_K_PAIR_FILL, 1);
-      hipLaunchKernelGGL(k_pairs_finish, dim3(1), dim3(64), 0, w->stream, n, w->slot_cnt.p, w->max_pairs, w->ctr.p); }
-    rc = color_graph(w, w->pairs.p, &w->ctr.p->n_pairs, w->max_pairs, w->ctr.p);
-    if (rc) return rc;
-    {
-        ColorArrays A;
-        A.pairs = w->pairs.p; A.filt = w->filt.p; A.used = w->used.p; A.deg = w->deg.p; A.claim = w->claim.p;
-        A.color = w->pcolor.p; A.prop = w->prop.p; A.left_list = w->left_list.p; A.n_edges = &w->ctr.p->n_pairs;
-        A.ctr = w->ctr.p;
-        Prof p(w, SFX_K_COLOR_SORT, w->max_pairs);
-        hipLaunchKernelGGL(k_color_scatter, dim3(edge_grid(w->max_pairs)), dim3(kBlock), 0, w->stream, A, w->cpairs.p);
-    }
+      hipLaunchKernelGGL(k_pairs<true>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
+                         w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }
+    { Prof p(w, SFX_K_COLOR, w->max_pairs);
+      hipLaunchKernelGGL((k_tile_color<kSmallB, kSmallP, 128>), dim3(w->color_grid, 4), dim3(128), 0, w->stream, g,
+                         w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
+                         w->tile_ncol.p, w->max_pairs, w->cfg.color_rounds, w->ctr); }
+    { Prof p(w, SFX_K_COLOR, w->max_pairs);
+      hipLaunchKernelGGL((k_tile_color<kMaxB, kMaxP, 256>), dim3(w->big_grid, 1), dim3(256), 0, w->stream, g,
+                         w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->big_tiles.p, w->rawp.p, w->tpair.p,
+                         w->tile_ncol.p, w->max_pairs, w->cfg.color_rounds, w->ctr); }
+    color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
     return SFX_OK;
 }
@@ -361,6 +368,14 @@ void poll_counters(sfx_world* w) {
         w->stale = *w->h_ctr;
         w->ctr_valid = true;
         w->ctr_pending = false;
+        uint32_t tot = 0;
+        for (int ph = 0; ph < 4; ++ph) {
+            const uint32_t a = w->stale.n_active[ph];
+            w->tile_grid[ph] = std::min(std::max(a + a / 8u + 4u, 1u), w->tile_grid_max);
+            tot = std::max(tot, a);
+        }
+        w->color_grid = std::min(std::max(tot + tot / 8u + 4u, 1u), 8192u);
+        w->big_grid = std::min(std::max(w->stale.n_big + w->stale.n_big / 8u + 4u, 1u), 1024u);
     }
 }
 
@@ -411,7 +426,16 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
     w->cfg = *cfg;
     resolve_defaults(w->cfg);
     w->device = cfg->device;
-    if ((e = hipSetDevice(w->device)) != hipSuccess || (e = hipStreamCreate(&w->stream)) != hipSuccess ||
+    // SFX_NULL_STREAM=1 runs the world on the device's default stream (profilers that cannot
+    // follow a second queue)
+    if (const char* gm = getenv("SFX_TILE_GRID_MAX")) {  // tuning knob: cap on the workgroups of a tile-solve launch
+        w->tile_grid_max = std::max(1, atoi(gm));
+        for (auto& tg : w->tile_grid) tg = std::min(tg, w->tile_grid_max);
+    }
+    const char* ns = getenv("SFX_NULL_STREAM");
+    w->own_stream = !(ns && ns[0] == '1');
+    if ((e = hipSetDevice(w->device)) != hipSuccess ||
+        (w->own_stream && (e = hipStreamCreate(&w->stream)) != hipSuccess) ||
         (e = hipEventCreate(&w->ev_ctr)) != hipSuccess || (e = hipEventCreate(&w->t_begin)) != hipSuccess ||
         (e = hipEventCreate(&w->t_end)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&w->h_ctr), sizeof(Counters))) != hipSuccess) {
@@ -419,7 +443,7 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
         sfx_destroy(w);
         return SFX_ERR_DEVICE;
     }
-    if (w->ctr.alloc(1) || w->jctr.alloc(1) || w->scan_sums.alloc(4096) || w->left_list.alloc(kLeftCap) ||
+    if (w->jctr.alloc(1) || w->scan_sums.alloc(4096) || w->left_list.alloc(kLeftCap) ||
         w->j_count_dev.alloc(1)) {
         fail(nullptr, SFX_ERR_NOMEM, "hipMalloc failed");
         sfx_destroy(w);
@@ -432,23 +456,25 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
 void sfx_destroy(sfx_world* w) {
     if (!w) return;
     (void)hipSetDevice(w->device);
-    if (w->stream) (void)hipStreamSynchronize(w->stream);
+    (void)hipStreamSynchronize(w->stream);
     for (auto& e : w->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : w->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     w->pose.release(); w->prev.release(); w->vel.release(); w->shape.release(); w->poly.release();
     w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release();
-    w->bucket.release(); w->cell_start.release(); w->cell_fill.release(); w->tmp_id.release();
+    w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
+    w->active.release(); w->big_tiles.release(); w->tile_ncol.release(); w->rawp.release(); w->tpair.release();
+    w->fpairs.release(); w->fsorted.release();
     w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->scan_sums.release();
-    w->cellxy.release(); w->sorted_cell.release(); w->pairs.release(); w->cpairs.release();
+    w->cellxy.release(); w->sorted_cell.release();
     w->used.release(); w->claim.release(); w->deg.release(); w->left_list.release();
-    w->pcolor.release(); w->prop.release(); w->ctr.release(); w->jctr.release();
+    w->pcolor.release(); w->prop.release(); w->jctr.release(); w->dbg.release();
     w->c_hdr.release(); w->c_anc0.release(); w->c_anc1.release(); w->c_lamv.release(); w->c_misc.release();
     w->j_bodies.release(); w->j_anchors.release(); w->j_params.release(); w->j_count_dev.release();
     if (w->h_ctr) (void)hipHostFree(w->h_ctr);
     if (w->ev_ctr) (void)hipEventDestroy(w->ev_ctr);
     if (w->t_begin) (void)hipEventDestroy(w->t_begin);
     if (w->t_end) (void)hipEventDestroy(w->t_end);
-    if (w->stream) (void)hipStreamDestroy(w->stream);
+    if (w->stream && w->own_stream) (void)hipStreamDestroy(w->stream);
     delete w;
 }
 
@@ -484,8 +510,8 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
         ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
         ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
         ALLOC(w, w->bucket, c); ALLOC(w, w->tmp_id, c); ALLOC(w, w->sorted_id, c); ALLOC(w, w->large_tmp, c);
-        ALLOC(w, w->slot_cnt, (size_t)n + 1 + kScanItems); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
-        ALLOC(w, w->used, c); ALLOC(w, w->deg, c); ALLOC(w, w->claim, c * 8);
+        ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
+        ALLOC(w, w->used, c); ALLOC(w, w->deg, c); ALLOC(w, w->claim, c * kClaim);
         w->large_cap = n;
     }
     std::vector<float4> hp(std::max(n, 1u)), hv(std::max(n, 1u));
@@ -565,12 +591,30 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     resolve_grid(w);
     w->max_pairs = w->cfg.max_pairs ? w->cfg.max_pairs : 12u * n;
     if (w->max_pairs < 1024u) w->max_pairs = 1024u;
-    const size_t mp = std::max<size_t>(w->max_pairs, w->m) + kScanItems;
-    ALLOC(w, w->cell_start, (size_t)w->ncell + 1 + kScanItems); ALLOC(w, w->cell_fill, (size_t)w->ncell + 1 + kScanItems);
-    ALLOC(w, w->pairs, mp); ALLOC(w, w->cpairs, mp); ALLOC(w, w->pcolor, mp); ALLOC(w, w->prop, mp);
+    // fallback list: pairs with a large dynamic collider and pairs of tiles over capacity
+    w->fb_cap = std::max(65536u, w->max_pairs / 8u);
+    const size_t pad = kScanItems;
+    const size_t words = sizeof(Counters) / 4 + ((size_t)w->ncell + 1 + pad) + ((size_t)w->ntiles + 1 + pad) +
+                         2 * (size_t)w->ntiles;
+    const size_t words16 = (words + 3) & ~(size_t)3;  // cleared by k_zero in 16-byte units
+    ALLOC(w, w->zero, words16);
+    w->zero_bytes = words16 * 4;
+    w->ctr = reinterpret_cast<Counters*>(w->zero.p);
+    w->cell_start = w->zero.p + sizeof(Counters) / 4;
+    w->tile_cnt = w->cell_start + ((size_t)w->ncell + 1 + pad);
+    w->tile_fill = w->tile_cnt + ((size_t)w->ntiles + 1 + pad);
+    w->tile_flag = w->tile_fill + w->ntiles;
+    ALLOC(w, w->cell_fill, (size_t)w->ncell + 1 + pad);
+    ALLOC(w, w->active, w->ntiles); ALLOC(w, w->big_tiles, w->ntiles); ALLOC(w, w->tile_ncol, w->ntiles);
+    ALLOC(w, w->rawp, w->max_pairs); ALLOC(w, w->tpair, w->max_pairs);
+    ALLOC(w, w->fpairs, w->fb_cap); ALLOC(w, w->fsorted, w->fb_cap);
+    const size_t mc = std::max<size_t>(w->fb_cap, w->m);
+    ALLOC(w, w->pcolor, mc); ALLOC(w, w->prop, mc);
+    const size_t mp = (size_t)w->max_pairs + w->fb_cap;  // record slots: tile pairs, then the fallback list
     ALLOC(w, w->c_hdr, mp); ALLOC(w, w->c_misc, mp); ALLOC(w, w->c_anc0, mp); ALLOC(w, w->c_anc1, mp); ALLOC(w, w->c_lamv, mp);
     HIPCHK(w, hipMemset(w->c_misc.p, 0, sizeof(float2) * mp));
-    HIPCHK(w, hipMemset(w->ctr.p, 0, sizeof(Counters)));
+    HIPCHK(w, hipMemset(w->zero.p, 0, w->zero_bytes));
+    w->ctr_valid = false; w->ctr_pending = false;
     w->ticked = false;
     return rebuild_filt(w);
 }
@@ -600,7 +644,8 @@ int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constrai
     HIPCHK(w, hipMemcpy(d_ab.p, ab.data(), sizeof(uint2) * m, hipMemcpyHostToDevice));
     HIPCHK(w, hipMemcpy(w->j_count_dev.p, &m, sizeof(uint32_t), hipMemcpyHostToDevice));
     HIPCHK(w, hipMemsetAsync(w->jctr.p, 0, sizeof(Counters), w->stream));
-    int rc = color_graph(w, d_ab.p, w->j_count_dev.p, m, w->jctr.p);
+    int rc = SFX_OK;
+    color_global(w, d_ab.p, w->j_count_dev.p, m, 1, nullptr, nullptr, nullptr, w->jctr.p, 0);
     std::vector<uint8_t> colors(m);
     Counters jc{};
     if (rc == SFX_OK) {
@@ -619,6 +664,7 @@ int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constrai
     for (uint32_t q = 0; q < nc; ++q) w->joint_color_start[q + 1] += w->joint_color_start[q];
     std::vector<uint32_t> fill(w->joint_color_start.begin(), w->joint_color_start.end() - 1);
     for (uint32_t k = 0; k < m; ++k) {
+        if (colors[k] >= nc) continue;  // cannot happen unless the colouring overflowed (rejected above)
         const uint32_t dst = fill[colors[k]]++;
         w->joint_perm[dst] = k;
         w->joint_color_sorted[dst] = colors[k];
@@ -675,17 +721,10 @@ int sfx_step(sfx_world* w, float frame_dt) {
     const ContactArrays C = contact_arrays(w);
     JointArrays J;
     J.bodies = w->j_bodies.p; J.anchors = w->j_anchors.p; J.params = w->j_params.p;
-    // colours that get their own launch: all that held >= 1024 pairs one tick ago (stale
-    // counters, read back asynchronously); the rest share the single-workgroup tail kernel
-    uint32_t K = w->cfg.launch_colors;
-    uint32_t solve_grid = std::min(std::max(cdiv(std::max(n, 1u), kBlock), 1u), 2048u);
-    if (w->ctr_valid) {
-        uint32_t k = 0, biggest = 0;
-        while (k < w->stale.n_colors && k < K && w->stale.color_count[k] >= 1024u) ++k;
-        K = std::max(k, 1u);
-        for (uint32_t c2 = 0; c2 < SFX_MAX_COLORS; ++c2) biggest = std::max(biggest, w->stale.color_count[c2]);
-        solve_grid = std::min(std::max(cdiv(biggest + biggest / 4 + 256, kBlock), 1u), 2048u);
-    }
+    // grids follow the active tile counts of an earlier tick (stale counters, read back
+    // asynchronously); the kernels loop over the tile lists, so any grid size is correct
+    const TileArrays T = tile_arrays(w);
+    const GridParams g = grid_params(w);
     const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
     const uint32_t njc = (uint32_t)w->joint_color_start.size() - 1;
     for (uint32_t s = 0; s < w->cfg.substeps; ++s) {
@@ -697,24 +736,22 @@ int sfx_step(sfx_world* w, float frame_dt) {
             Prof p(w, SFX_K_SOLVE_JOINTS, cnt);
             hipLaunchKernelGGL(k_solve_joints, dim3(cdiv(cnt, kBlock)), dim3(kBlock), 0, w->stream, start, cnt, B, J, sp.inv_h2);
         }
-        for (uint32_t c2 = 0; c2 < K; ++c2) {
-            Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.color_count[c2] : 0);
-            hipLaunchKernelGGL(k_solve_pos, dim3(solve_grid), dim3(kBlock), 0, w->stream, c2, w->ctr.p, w->cpairs.p, B, C, sp.max_corr);
+        for (uint32_t ph = 0; ph < 4; ++ph) {
+            Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_tile_pairs / 4 : 0);
+            hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph,
+                               ph == 3 ? 1 : 0, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
         }
-        { Prof p(w, SFX_K_SOLVE_POS_TAIL, 0);
-          hipLaunchKernelGGL(k_solve_pos_tail, dim3(1), dim3(kBlock), 0, w->stream, K, w->ctr.p, w->cpairs.p, B, C, sp.max_corr); }
         { Prof p(w, SFX_K_DERIVE_VEL, n);
           hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
-        for (uint32_t c2 = 0; c2 < K; ++c2) {
-            Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.color_count[c2] : 0);
-            hipLaunchKernelGGL(k_solve_vel, dim3(solve_grid), dim3(kBlock), 0, w->stream, c2, w->ctr.p, w->cpairs.p, B, C, sp);
+        for (uint32_t ph = 0; ph < 4; ++ph) {
+            Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_tile_pairs / 4 : 0);
+            hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph,
+                               ph == 3 ? 1 : 0, g, T, w->ctr, B, C, sp);
         }
-        { Prof p(w, SFX_K_SOLVE_VEL_TAIL, 0);
-          hipLaunchKernelGGL(k_solve_vel_tail, dim3(1), dim3(kBlock), 0, w->stream, K, w->ctr.p, w->cpairs.p, B, C, sp); }
     }
     HIPCHK(w, hipGetLastError());
     if (!w->ctr_pending) {
-        HIPCHK(w, hipMemcpyAsync(w->h_ctr, w->ctr.p, sizeof(Counters), hipMemcpyDeviceToHost, w->stream));
+        HIPCHK(w, hipMemcpyAsync(w->h_ctr, w->ctr, sizeof(Counters), hipMemcpyDeviceToHost, w->stream));
         HIPCHK(w, hipEventRecord(w->ev_ctr, w->stream));
         w->ctr_pending = true;
     }
@@ -729,7 +766,7 @@ int sfx_sync(sfx_world* w) {
     HIPCHK(w, hipStreamSynchronize(w->stream));
     poll_counters(w);
     if (w->ctr_valid && w->stale.overflow)
-        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list)",
+        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list)",
                     w->stale.overflow);
     return SFX_OK;
 }
@@ -770,50 +807,82 @@ int sfx_debug_aabbs(sfx_world* w, float* out) {
     return SFX_OK;
 }
 
-static int fetch_pairs(sfx_world* w, const uint2* dev, std::vector<uint2>& out, Counters& c) {
+// all candidate pairs of the last broadphase: tile-owned pairs (with owner tile and colour),
+// then the fallback list
+struct HostPair { uint32_t a, b, tile; uint8_t color; };
+
+static int fetch_pairs(sfx_world* w, std::vector<HostPair>& out, Counters& c) {
     int rc = ready(w);
     if (rc) return rc;
     if (!w->ticked) return fail(w, SFX_ERR_INVALID, "no broadphase has run");
     HIPCHK(w, hipSetDevice(w->device));
-    rc = sync_counters(w, &c, w->ctr.p);
+    rc = sync_counters(w, &c, w->ctr);
     if (rc) return rc;
-    out.resize(c.n_pairs);
-    if (c.n_pairs) HIPCHK(w, hipMemcpy(out.data(), dev, sizeof(uint2) * c.n_pairs, hipMemcpyDeviceToHost));
+    out.clear();
+    const uint32_t ntp = c.n_tile_pairs, nfb = c.n_fb;
+    std::vector<uint4> tp(ntp);
+    std::vector<uint32_t> ts(w->ntiles + 1);
+    if (ntp) HIPCHK(w, hipMemcpy(tp.data(), w->tpair.p, sizeof(uint4) * ntp, hipMemcpyDeviceToHost));
+    HIPCHK(w, hipMemcpy(ts.data(), w->tile_cnt, sizeof(uint32_t) * (w->ntiles + 1), hipMemcpyDeviceToHost));
+    out.reserve((size_t)ntp + nfb);
+    for (uint32_t t = 0; t < w->ntiles; ++t)
+        for (uint32_t k = std::min(ts[t], ntp); k < std::min(ts[t + 1], ntp); ++k)
+            out.push_back({tp[k].x, tp[k].y, t, (uint8_t)std::min(tp[k].w, 255u)});
+    if (nfb) {
+        // the raw list holds every fallback pair; colours come from the colour-major copy
+        std::vector<uint2> fp(nfb), fs(c.fb_start[SFX_MAX_COLORS]);
+        HIPCHK(w, hipMemcpy(fp.data(), w->fpairs.p, sizeof(uint2) * nfb, hipMemcpyDeviceToHost));
+        if (!fs.empty()) HIPCHK(w, hipMemcpy(fs.data(), w->fsorted.p, sizeof(uint2) * fs.size(), hipMemcpyDeviceToHost));
+        std::vector<std::pair<uint64_t, uint8_t>> col;
+        col.reserve(fs.size());
+        for (uint32_t q = 0; q < SFX_MAX_COLORS; ++q)
+            for (uint32_t k = c.fb_start[q]; k < c.fb_start[q + 1]; ++k)
+                col.emplace_back(((uint64_t)fs[k].x << 32) | fs[k].y, (uint8_t)q);
+        std::sort(col.begin(), col.end());
+        for (uint32_t k = 0; k < nfb; ++k) {
+            const uint64_t key = ((uint64_t)fp[k].x << 32) | fp[k].y;
+            auto it = std::lower_bound(col.begin(), col.end(), std::make_pair(key, (uint8_t)0));
+            const uint8_t cc = (it != col.end() && it->first == key) ? it->second : (uint8_t)SFX_NO_COLOR;
+            out.push_back({fp[k].x, fp[k].y, SFX_FALLBACK_TILE, cc});
+        }
+    }
     return SFX_OK;
 }
 
 int sfx_debug_pairs(sfx_world* w, uint64_t* keys, size_t cap, size_t* n) {
-    std::vector<uint2> p;
+    std::vector<HostPair> p;
     Counters c;
-    int rc = fetch_pairs(w, w ? w->pairs.p : nullptr, p, c);
+    int rc = fetch_pairs(w, p, c);
     if (rc) return rc;
     std::vector<uint64_t> k(p.size());
-    for (size_t i = 0; i < p.size(); ++i) k[i] = ((uint64_t)p[i].x << 32) | p[i].y;
+    for (size_t i = 0; i < p.size(); ++i) k[i] = ((uint64_t)p[i].a << 32) | p[i].b;
     std::sort(k.begin(), k.end());
     if (n) *n = k.size();
     if (keys) memcpy(keys, k.data(), sizeof(uint64_t) * std::min(cap, k.size()));
     return SFX_OK;
 }
 
-int sfx_debug_pair_colors(sfx_world* w, uint64_t* keys, uint8_t* colors, size_t cap, size_t* n) {
-    std::vector<uint2> p;
+int sfx_debug_pair_colors(sfx_world* w, uint64_t* keys, uint8_t* colors, uint32_t* tiles, size_t cap, size_t* n) {
+    std::vector<HostPair> p;
     Counters c;
-    int rc = fetch_pairs(w, w ? w->cpairs.p : nullptr, p, c);
+    int rc = fetch_pairs(w, p, c);
     if (rc) return rc;
-    if (n) *n = std::min<size_t>(p.size(), c.color_start[SFX_MAX_COLORS]);
-    for (uint32_t col = 0; col < SFX_MAX_COLORS; ++col)
-        for (uint32_t k = c.color_start[col]; k < c.color_start[col + 1] && k < p.size() && k < cap; ++k) {
-            if (keys) keys[k] = ((uint64_t)p[k].x << 32) | p[k].y;
-            if (colors) colors[k] = (uint8_t)col;
-        }
+    if (n) *n = p.size();
+    for (size_t k = 0; k < p.size() && k < cap; ++k) {
+        if (keys) keys[k] = ((uint64_t)p[k].a << 32) | p[k].b;
+        if (colors) colors[k] = p[k].color;
+        if (tiles) tiles[k] = p[k].tile;
+    }
     return SFX_OK;
 }
 
 int sfx_debug_contacts(sfx_world* w, sfx_contact* out, size_t cap, size_t* n) {
-    std::vector<uint2> p;
+    std::vector<HostPair> hp;
     Counters c;
-    int rc = fetch_pairs(w, w ? w->pairs.p : nullptr, p, c);
+    int rc = fetch_pairs(w, hp, c);
     if (rc) return rc;
+    std::vector<uint2> p(hp.size());
+    for (size_t i = 0; i < hp.size(); ++i) p[i] = make_uint2(hp[i].a, hp[i].b);
     std::sort(p.begin(), p.end(), [](const uint2& a, const uint2& b) { return a.x != b.x ? a.x < b.x : a.y < b.y; });
     if (n) *n = p.size();
     const uint32_t np = (uint32_t)std::min(cap, p.size());
@@ -823,7 +892,8 @@ int sfx_debug_contacts(sfx_world* w, sfx_contact* out, size_t cap, size_t* n) {
     ALLOC(w, dp, np); ALLOC(w, dc, np);
     hipError_t e = hipMemcpy(dp.p, p.data(), sizeof(uint2) * np, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_contacts_debug, dim3(cdiv(np, kBlock)), dim3(kBlock), 0, w->stream, np, dp.p, body_arrays(w), dc.p);
+        hipLaunchKernelGGL(k_contacts_debug, dim3(cdiv(np, kBlock)), dim3(kBlock), 0, w->stream, np, dp.p, body_arrays(w),
+                           w->cfg.speculative_margin, dc.p);
         e = hipStreamSynchronize(w->stream);
     }
     if (e == hipSuccess) e = hipMemcpy(out, dc.p, sizeof(sfx_contact) * np, hipMemcpyDeviceToHost);
@@ -856,16 +926,18 @@ int sfx_stats(sfx_world* w, sfx_frame_stats* out) {
     const uint32_t grid = std::min(std::max(cdiv(std::max(w->n, 1u), kBlock), 1u), 1024u);
     hipLaunchKernelGGL(k_stats_bodies, dim3(grid), dim3(kBlock), 0, w->stream, w->n, w->vel.p, w->mass.p, w->jctr.p);
     if (w->have_mats)
-        hipLaunchKernelGGL(k_stats_pairs, dim3(edge_grid(w->max_pairs)), dim3(kBlock), 0, w->stream, w->ctr.p, w->jctr.p,
-                           w->cpairs.p, body_arrays(w), contact_arrays(w));
+        hipLaunchKernelGGL(k_stats_pairs, dim3(edge_grid(w->max_pairs)), dim3(kBlock), 0, w->stream, w->ctr, w->jctr.p,
+                           tile_arrays(w), body_arrays(w), contact_arrays(w), w->cfg.speculative_margin);
     Counters c{}, s{};
     int rc = sync_counters(w, &s, w->jctr.p);
     if (rc) return rc;
-    rc = sync_counters(w, &c, w->ctr.p);
+    rc = sync_counters(w, &c, w->ctr);
     if (rc) return rc;
     w->launches = saved;
     out->n_small = c.n_small; out->n_large = c.n_large; out->n_pairs = c.n_pairs; out->n_colors = c.n_colors;
     out->n_leftover = c.n_leftover; out->overflow = c.overflow;
+    out->n_tiles = c.n_active[0] + c.n_active[1] + c.n_active[2] + c.n_active[3];
+    out->n_fallback = c.n_fb; out->max_tile_pairs = c.max_tile_pairs; out->max_tile_bodies = c.max_tile_bodies;
     out->n_contacts = s.n_contacts;
     out->n_manifolds = s.n_manifolds;
     out->n_manifolds2 = s.n_manifolds2;
@@ -891,10 +963,22 @@ int sfx_kernel_times(sfx_world* w, sfx_kernel_time* out, int reset) {
     return SFX_OK;
 }
 
+#ifdef SFX_TILE_TIMING
+// development hook: stage timing of k_tile_pos in 10 ns units: [load, narrowphase, colour loop, whole tile, tiles, colours]
+int sfx_debug_tile_timing(sfx_world* w, unsigned long long* out, int reset) {
+    if (!w) return SFX_ERR_INVALID;
+    if (!w->dbg.p) { if (w->dbg.alloc(8)) return SFX_ERR_NOMEM; (void)hipMemset(w->dbg.p, 0, 64); }
+    (void)hipStreamSynchronize(w->stream);
+    if (out) (void)hipMemcpy(out, w->dbg.p, 64, hipMemcpyDeviceToHost);
+    if (reset) (void)hipMemset(w->dbg.p, 0, 64);
+    return SFX_OK;
+}
+#endif
+
 const char* sfx_kernel_class_name(int cls) {
     static const char* names[SFX_K_CLASSES] = {
-        "aabb_count", "scan", "scatter", "pair_count", "pair_fill", "color", "color_sort", "integrate",
-        "solve_joints", "solve_pos", "solve_pos_tail", "derive_vel", "solve_vel", "solve_vel_tail", "stats", "halo"};
+        "aabb_count", "scan", "scatter", "pair_count", "pair_fill", "tile_list", "color", "integrate",
+        "solve_joints", "solve_pos", "derive_vel", "solve_vel", "stats", "halo"};
     return (cls >= 0 && cls < SFX_K_CLASSES) ? names[cls] : "?";
 }
 

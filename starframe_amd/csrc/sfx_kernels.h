@@ -3,12 +3,13 @@
 // K1  k_integrate          substep integration over the body records (streaming)
 // K2  k_aabb_count         world AABB + home cell + per-cell histogram (atomics)
 // K3b k_scan_*             exclusive prefix scan, block scan in LDS with wave shuffles
-// K3c k_scatter / k_finalize_slots   counting sort into cell order, ascending id per cell
-// K3d k_pairs<FILL>        candidate pairs, wave ballot compaction, deterministic order
-// K5  k_color_*            edge colouring of the candidate-pair graph
-// K6  k_solve_pos*         fused narrowphase + XPBD manifold block solve, one launch/colour
+// K3c k_scatter / k_finalize_slots   counting sort into tile-major cell order, ascending id per cell
+// K3d k_pairs<FILL>        candidate pairs, wave ballot compaction, binned by owner tile
+// K5  k_tile_list / k_tile_color / k_color_global   solver tiles + edge colouring (LDS / one workgroup)
+// K6  k_tile_pos           per tile and phase: bodies of the 2x2 tile block in LDS, narrowphase of
+//                          the tile's pairs, XPBD manifold block solves colour by colour
 // K7  k_derive             velocities from pose deltas
-// K8  k_solve_vel*         restitution + friction per manifold, one launch per colour
+// K8  k_tile_vel           restitution + friction per manifold, same tiling
 //
 // All of it is HBM/latency-bound gather-scatter work: no MFMA anywhere.
 #pragma once
@@ -18,38 +19,67 @@
 namespace sfx {
 
 constexpr int kBlock = 256;
+constexpr uint32_t kMaxP = SFX_TILE_MAX_PAIRS;      // pairs a tile may own
+constexpr uint32_t kMaxB = SFX_TILE_MAX_BODIES;     // grid-sorted colliders in a 2x2 tile block
+constexpr uint32_t kSmallB = 128, kSmallP = 256;    // tiles up to this size are coloured by the small-LDS kernel
+constexpr int kClaim = 4;                           // claim slots per body in the colouring
+constexpr uint32_t kExt = 0xFFFFu;                  // local index of a body outside the block (large static)
 constexpr int kScanItems = 16;                      // items per thread in the block scan
 constexpr int kScanTile = kBlock * kScanItems;      // 4096 items per block
 constexpr uint32_t kLeftCap = 4096;                 // leftover edges the serial finish takes
-constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u;
+constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u, kOvfFallback = 16u;
 
-// device-resident counters of one tick (one allocation, zeroed per tick where noted)
+// device-resident counters of one tick (one allocation, zeroed at the start of every tick)
 struct Counters {
-    uint32_t n_small;       // written by the cell scan
-    uint32_t n_large;       // zeroed per tick
-    uint32_t n_pairs;       // written after the pair scan (clamped to capacity)
-    uint32_t overflow;      // zeroed per tick, kOvf* bits
-    uint32_t n_colors;
-    uint32_t n_leftover;    // zeroed per tick
+    uint32_t n_small;       // written by k_finalize_slots
+    uint32_t n_large;
+    uint32_t n_pairs;       // tile pairs + fallback pairs (clamped to the capacities)
+    uint32_t overflow;      // kOvf* bits
+    uint32_t n_colors;      // most colours of any tile / the fallback list
+    uint32_t n_leftover;
     uint32_t n_contacts;    // stats kernel
     uint32_t max_depth_bits;
     float ke;
     uint32_t n_manifolds, n_manifolds2;
-    uint32_t pad[5];
-    uint32_t color_count[SFX_MAX_COLORS];      // zeroed per tick
-    uint32_t color_start[SFX_MAX_COLORS + 1];
-    uint32_t color_fill[SFX_MAX_COLORS];       // zeroed per tick
+    uint32_t n_fb;          // pairs appended to the fallback list (may exceed its capacity)
+    uint32_t n_fb_colors;
+    uint32_t n_tile_pairs;  // pairs owned by tiles (clamped to max_pairs)
+    uint32_t max_tile_pairs, max_tile_bodies;
+    uint32_t n_active[4];   // tiles that own pairs, per phase
+    uint32_t ticket;        // last-workgroup detection of the phase-3 kernels
+    uint32_t n_over_tiles;  // tiles that handed their pairs to the fallback list
+    uint32_t n_big;         // active tiles beyond the small colouring kernel's capacity
+    uint32_t pad[1];
+    uint32_t color_count[SFX_MAX_COLORS];
+    uint32_t fb_start[SFX_MAX_COLORS + 1];  // colour-major offsets into the sorted fallback list
 };
 
 struct GridParams {
     float inv_cell;
     float small_lim;   // 0.9 * cell
-    uint32_t gxl, gyl; // log2 grid dims
+    uint32_t gxl, gyl; // log2 grid dims (cells)
     uint32_t ncell;
+    uint32_t tl;       // log2 tile edge (cells)
+    uint32_t ntiles;
 };
 
+// wrapped tile index of true tile coordinates
+__device__ __forceinline__ uint32_t tile_of(int32_t tx, int32_t ty, const GridParams& g) {
+    const uint32_t lx = g.gxl - g.tl, ly = g.gyl - g.tl;
+    return (((uint32_t)ty & ((1u << ly) - 1u)) << lx) | ((uint32_t)tx & ((1u << lx) - 1u));
+}
+
+// bucket of a true cell: tile-major, so that a tile's cells -- and with them its colliders in
+// the sorted order -- are contiguous
 __device__ __forceinline__ uint32_t bucket_of(int32_t cx, int32_t cy, const GridParams& g) {
-    return (((uint32_t)cy & ((1u << g.gyl) - 1u)) << g.gxl) | ((uint32_t)cx & ((1u << g.gxl) - 1u));
+    const uint32_t tm = (1u << g.tl) - 1u;
+    return (tile_of(cx >> g.tl, cy >> g.tl, g) << (2u * g.tl)) | (((uint32_t)cy & tm) << g.tl) | ((uint32_t)cx & tm);
+}
+
+// clears the per-tick block (counters, cell and tile histograms) with 16-byte stores
+__global__ __launch_bounds__(kBlock) void k_zero(uint4* __restrict__ p, uint32_t n16) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
 // ---------------------------------------------------------------- K1 / K7 streaming
@@ -280,22 +310,36 @@ __global__ __launch_bounds__(kBlock) void k_finalize_slots(uint32_t n, GridParam
 // ---------------------------------------------------------------- K3d candidate pairs
 // Eight lanes share one slot (eight slots per 64-lane wave): the candidates of a slot -- the
 // entries of its own cell behind it, the four forward neighbour cells, then every large
-// collider -- are spread over the eight lanes, tested, and the survivors compacted with one
-// wave-wide __ballot + popcount per step, so a slot's pairs land contiguously and in
-// candidate order.  Two passes (count, then fill behind an exclusive scan of the per-slot
-// counts) give every pair a fixed place: the list order is a pure function of the slot
-// order, with no atomics and no capacity races.
+// collider -- are spread over the eight lanes, tested, and the survivors compacted with
+// wave-wide __ballot + popcount, so a slot's pairs land contiguously.
+//
+// Every pair goes to one of three streams (DESIGN.md "Contract / tiles"):
+//   0  owned by the slot's own tile T      (both small, or small + large non-dynamic)
+//   1  owned by the tile left of T         (the neighbour cell (-1, +1) lies in that tile)
+//   2  the fallback list                   (a large dynamic collider is involved)
+// The count pass adds the per-slot stream sizes to the tiles' pair counts; after
+// k_tile_list + a scan of those counts the fill pass reserves room per slot and stream with
+// one atomic each and writes (id a, id b, slot a, slot b).  Pairs of tiles flagged as over
+// capacity are re-routed to the fallback list.
 constexpr int kGroup = 8;                 // lanes per slot
 constexpr int kSlotsPerWave = 64 / kGroup;
+
+struct PairArrays {
+    uint32_t* slot_cnt;      // [3 * (n + 1)] per slot: stream sizes (count pass out, fill pass in)
+    uint32_t* tile_cnt;      // count pass: pairs per tile (atomics); fill pass: scanned = tile start
+    uint32_t* tile_fill;     // fill pass: per tile cursor
+    const uint32_t* tile_flag;  // != 0: tile hands its pairs to the fallback list
+    uint4* rawp;             // tile-ordered pairs (id a, id b, slot a, slot b)
+    uint2* fpairs;           // fallback list (id a, id b)
+    uint32_t max_pairs, fb_cap;
+};
 
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, const uint32_t* __restrict__ cell_start,
                                                    const uint32_t* __restrict__ sorted_id,
                                                    const float4* __restrict__ sorted_aabb,
                                                    const int2* __restrict__ sorted_cell, const uint4* __restrict__ filt,
-                                                   uint32_t* __restrict__ slot_cnt /* count: out, fill: scanned in */,
-                                                   uint2* __restrict__ pairs, uint32_t max_pairs,
-                                                   const Counters* __restrict__ ctr, uint32_t large_cap) {
+                                                   PairArrays P, Counters* __restrict__ ctr, uint32_t large_cap) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & (kGroup - 1);          // lane inside the group
     const int gshift = lane & ~(kGroup - 1);     // first lane of the group
@@ -305,8 +349,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
     const uint32_t nl = min(ctr->n_large, large_cap);
     const uint32_t nact = ns + nl;
     const uint64_t below = (1ull << gl) - 1ull;  // group-local lanes before this one
-    // slots [0, n] are covered so that the count array is fully written (n + 1 entries scanned)
-    for (uint32_t p0 = wave * kSlotsPerWave; p0 <= n; p0 += nwaves * kSlotsPerWave) {
+    for (uint32_t p0 = wave * kSlotsPerWave; p0 < nact; p0 += nwaves * kSlotsPerWave) {
         const uint32_t p = p0 + (uint32_t)(lane / kGroup);
         const bool live = p < nact;
         uint32_t i = 0;
@@ -314,14 +357,33 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
         uint4 fi = make_uint4(0, 0, 0, 0);
         int2 c = make_int2(0, 0);
         if (live) { i = sorted_id[p]; Ai = sorted_aabb[p]; fi = filt[i]; c = sorted_cell[p]; }
-        const uint32_t base = (FILL && live) ? slot_cnt[p] : 0u;
-        uint32_t cnt = 0;
+        const int32_t txp = c.x >> g.tl, typ = c.y >> g.tl;
+        const uint32_t T0 = tile_of(txp, typ, g), T1 = tile_of(txp - 1, typ, g);
+        // stream bases (fill pass): lane 0 of the group reserves, the group reads them by shuffle
+        uint32_t base[3] = {0u, 0u, 0u};
+        bool to_fb[3] = {false, false, true};
+        if (FILL) {
+            uint32_t b0 = 0, b1 = 0, b2 = 0, f0 = 0, f1 = 0;
+            if (live && gl == 0) {
+                const uint32_t c0 = P.slot_cnt[3 * p], c1 = P.slot_cnt[3 * p + 1], c2 = P.slot_cnt[3 * p + 2];
+                f0 = (c0 && P.tile_flag[T0]) ? 1u : 0u;
+                f1 = (c1 && P.tile_flag[T1]) ? 1u : 0u;
+                const uint32_t nfb = c2 + (f0 ? c0 : 0u) + (f1 ? c1 : 0u);
+                if (nfb) b2 = atomicAdd(&ctr->n_fb, nfb);
+                if (c0) b0 = f0 ? b2 + c2 : P.tile_cnt[T0] + atomicAdd(&P.tile_fill[T0], c0);
+                if (c1) b1 = f1 ? b2 + c2 + (f0 ? c0 : 0u) : P.tile_cnt[T1] + atomicAdd(&P.tile_fill[T1], c1);
+            }
+            base[0] = __shfl(b0, gshift, 64); base[1] = __shfl(b1, gshift, 64); base[2] = __shfl(b2, gshift, 64);
+            to_fb[0] = __shfl(f0, gshift, 64) != 0u; to_fb[1] = __shfl(f1, gshift, 64) != 0u;
+        }
+        uint32_t cnt[3] = {0u, 0u, 0u};
         // six candidate ranges per slot, walked in lockstep by the eight groups of the wave
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             uint32_t qs = 0, qe = 0;
             int32_t ncx = 0, ncy = 0;
             bool check_cell = true;
+            int stream = 0;
             if (live && p < ns) {
                 if (r == 0) {
                     ncx = c.x; ncy = c.y;
@@ -332,270 +394,789 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                     ncx = c.x + dx; ncy = c.y + dy;
                     const uint32_t bk = bucket_of(ncx, ncy, g);
                     qs = cell_start[bk]; qe = cell_start[bk + 1];
+                    stream = ((ncx >> g.tl) < txp) ? 1 : 0;
                 } else {
                     qs = ns; qe = nact; check_cell = false;
                 }
             } else if (live && r == 5) {
-                qs = p + 1; qe = nact; check_cell = false;   // large slot: later larges only
+                qs = p + 1; qe = nact; check_cell = false; stream = 2;  // large slot: later larges only
             }
             for (uint32_t q0 = qs; __any(q0 < qe); q0 += kGroup) {
                 const uint32_t q = q0 + (uint32_t)gl;
                 bool hit = false;
                 uint32_t j = 0;
+                int st = stream;
                 if (q < qe) {
                     bool ok = true;
                     if (check_cell) { const int2 cq = sorted_cell[q]; ok = (cq.x == ncx && cq.y == ncy); }
                     if (ok && aabb_overlap(Ai, sorted_aabb[q])) {
                         j = sorted_id[q];
-                        hit = pair_filter(fi, filt[j]);
+                        const uint4 fj = filt[j];
+                        hit = pair_filter(fi, fj);
+                        if (r == 5 && p < ns && fj.w != 0u) st = 2;  // small against a large dynamic collider
                     }
                 }
-                const uint64_t bal = (__ballot(hit) >> gshift) & ((1ull << kGroup) - 1ull);
-                if (FILL && hit) {
-                    const uint32_t dst = base + cnt + (uint32_t)__popcll(bal & below);
-                    if (dst < max_pairs) pairs[dst] = make_uint2(min(i, j), max(i, j));
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3) {
+                    const bool mine = hit && st == s3;
+                    const uint64_t bal = (__ballot(mine) >> gshift) & ((1ull << kGroup) - 1ull);
+                    if (FILL && mine) {
+                        const uint32_t dst = base[s3] + cnt[s3] + (uint32_t)__popcll(bal & below);
+                        const bool swap = j < i;
+                        if (to_fb[s3]) {
+                            if (dst < P.fb_cap) P.fpairs[dst] = make_uint2(swap ? j : i, swap ? i : j);
+                        } else if (dst < P.max_pairs) {
+                            P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, swap ? p : q);
+                        }
+                    }
+                    cnt[s3] += (uint32_t)__popcll(bal);
                 }
-                cnt += (uint32_t)__popcll(bal);
             }
         }
-        if (!FILL && gl == 0 && p <= n) slot_cnt[p] = cnt;
+        if (!FILL && live && gl == 0) {
+            P.slot_cnt[3 * p] = cnt[0]; P.slot_cnt[3 * p + 1] = cnt[1]; P.slot_cnt[3 * p + 2] = cnt[2];
+            if (cnt[0]) atomicAdd(&P.tile_cnt[T0], cnt[0]);
+            if (cnt[1]) atomicAdd(&P.tile_cnt[T1], cnt[1]);
+        }
     }
 }
 
-// after the scan of the slot counts: publish the pair count, flag capacity overflow
-__global__ void k_pairs_finish(uint32_t n, const uint32_t* __restrict__ slot_off, uint32_t max_pairs,
-                               Counters* __restrict__ ctr) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        uint32_t total = slot_off[n];
-        if (total > max_pairs) { atomicOr(&ctr->overflow, kOvfPairs); total = max_pairs; }
-        ctr->n_pairs = total;
+// ---------------------------------------------------------------- K5 solver tiles
+// slot ranges of the four tiles of the block anchored at wrapped tile t, in the order
+// (0,0) (1,0) (0,1) (1,1); off[k] = local index of the first body of tile k, off[4] = bodies
+struct BlockRanges { uint32_t ts[4], te[4], off[5]; };
+
+__device__ __forceinline__ void block_ranges(uint32_t t, const GridParams& g, const uint32_t* __restrict__ cell_start,
+                                             BlockRanges& R) {
+    const uint32_t lx = g.gxl - g.tl;
+    const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
+    uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t tk = tile_of(tx + (k & 1), ty + (k >> 1), g);
+        R.ts[k] = cell_start[tk << (2u * g.tl)];
+        R.te[k] = cell_start[(tk + 1u) << (2u * g.tl)];
+        R.off[k] = run;
+        run += R.te[k] - R.ts[k];
+    }
+    R.off[4] = run;
+}
+
+__device__ __forceinline__ uint32_t block_local(const BlockRanges& R, uint32_t slot) {
+    uint32_t l = kExt;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (slot >= R.ts[k] && slot < R.te[k]) l = R.off[k] + (slot - R.ts[k]);
+    return l;
+}
+
+__device__ __forceinline__ uint32_t block_slot(const BlockRanges& R, uint32_t l) {
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (l >= R.off[k] && l < R.off[k + 1]) s = R.ts[k] + (l - R.off[k]);
+    return s;
+}
+
+// One thread per tile, after the count pass: tiles over capacity are flagged (their pair count
+// is zeroed so that the scan skips them), the others are listed per phase.
+__global__ __launch_bounds__(kBlock) void k_tile_list(GridParams g, const uint32_t* __restrict__ cell_start,
+                                                       uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_flag,
+                                                       uint32_t* __restrict__ active, uint32_t* __restrict__ big,
+                                                       Counters* __restrict__ ctr) {
+    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= g.ntiles) return;
+    const uint32_t cnt = tile_cnt[t];
+    if (!cnt) return;
+    BlockRanges R;
+    block_ranges(t, g, cell_start, R);
+    if (cnt > kMaxP || R.off[4] > kMaxB) {
+        tile_flag[t] = 1u;
+        tile_cnt[t] = 0u;
+        atomicAdd(&ctr->n_over_tiles, 1u);
+        return;
+    }
+    const uint32_t lx = g.gxl - g.tl;
+    const uint32_t ph = (t & 1u) | (((t >> lx) & 1u) << 1);
+    const uint32_t k = atomicAdd(&ctr->n_active[ph], 1u);
+    active[ph * (g.ntiles >> 2) + k] = t;
+    if (cnt > kSmallP || R.off[4] > kSmallB) big[atomicAdd(&ctr->n_big, 1u)] = t;
+    atomicMax(&ctr->max_tile_pairs, cnt);
+    atomicMax(&ctr->max_tile_bodies, R.off[4]);
+}
+
+// pair range of tile t after the scan, clamped to the pair capacity
+__device__ __forceinline__ void tile_pair_range(uint32_t t, const uint32_t* __restrict__ tile_start, uint32_t max_pairs,
+                                                uint32_t& start, uint32_t& np) {
+    const uint32_t s = min(tile_start[t], max_pairs), e = min(tile_start[t + 1], max_pairs);
+    start = s; np = e - s;
+}
+
+// Edge colouring of every active tile's pair graph, one workgroup per tile, all state in LDS
+// (DESIGN.md "Contract / colouring").  Writes the tile's pairs colour-major as
+// (id a, id b, local a | local b << 16, colour | ext << 8) and the tile's colour count.
+// Two instances: <kSmallB, kSmallP> walks the per-phase tile lists (blockIdx.y = phase) and skips
+// the few tiles beyond its LDS arrays; <kMaxB, kMaxP> walks the list of exactly those tiles.
+template <uint32_t MB, uint32_t MP, int NTC>
+__global__ __launch_bounds__(NTC) void k_tile_color(GridParams g, const uint32_t* __restrict__ cell_start,
+                                                     const uint32_t* __restrict__ sorted_id,
+                                                     const uint4* __restrict__ filt,
+                                                     const uint32_t* __restrict__ tile_start,
+                                                     const uint32_t* __restrict__ list, const uint4* __restrict__ rawp,
+                                                     uint4* __restrict__ tpair, uint32_t* __restrict__ tile_ncol,
+                                                     uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr) {
+    constexpr bool kBig = MB > kSmallB;
+    constexpr uint32_t kBlock = NTC;  // shadows the file-level constant inside this kernel
+    __shared__ unsigned long long s_used[MB];
+    __shared__ unsigned long long s_claim[MB * kClaim];
+    __shared__ uint32_t s_deg[MB];
+    __shared__ uint8_t s_dyn[MB];
+    __shared__ uint32_t s_a[MP], s_b[MP];
+    __shared__ uint16_t s_la[MP], s_lb[MP], s_left[MP], s_srt[MP];
+    __shared__ uint8_t s_col[MP], s_prop[MP];
+    __shared__ uint32_t s_hist[SFX_MAX_COLORS], s_base[SFX_MAX_COLORS];
+    __shared__ uint32_t s_nleft, s_ovf;
+    const uint32_t ph = blockIdx.y;
+    const uint32_t nact = kBig ? ctr->n_big : ctr->n_active[ph];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t it = blockIdx.x; it < nact; it += gridDim.x) {
+        const uint32_t t = kBig ? list[it] : list[ph * (g.ntiles >> 2) + it];
+        BlockRanges R;
+        block_ranges(t, g, cell_start, R);
+        uint32_t start, np;
+        tile_pair_range(t, tile_start, max_pairs, start, np);
+        if (!kBig && (np > kSmallP || R.off[4] > kSmallB)) continue;  // the big instance takes it
+        const uint32_t nb = min(R.off[4], MB);
+        np = min(np, MP);
+        for (uint32_t l = tid; l < nb; l += kBlock) {
+            const uint32_t gid = sorted_id[block_slot(R, l)];
+            s_dyn[l] = (uint8_t)(filt[gid].w != 0u);
+            s_used[l] = 0ull;
+            s_deg[l] = 0u;
+#pragma unroll
+            for (int k = 0; k < kClaim; ++k) s_claim[l * kClaim + k] = ~0ull;
+        }
+        if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
+        if (tid == 0) { s_nleft = 0u; s_ovf = 0u; }
+        for (uint32_t e = tid; e < np; e += kBlock) {
+            const uint4 rp = rawp[start + e];
+            s_a[e] = rp.x; s_b[e] = rp.y;
+            s_la[e] = (uint16_t)block_local(R, rp.z);
+            s_lb[e] = (uint16_t)block_local(R, rp.w);
+            s_col[e] = SFX_NO_COLOR;
+        }
+        __syncthreads();
+#define TDYN(l) ((l) != kExt && s_dyn[(l)])
+        for (uint32_t e = tid; e < np; e += kBlock) {
+            const uint32_t la = s_la[e], lb = s_lb[e];
+            if (TDYN(la)) atomicAdd(&s_deg[la], 1u);
+            if (TDYN(lb)) atomicAdd(&s_deg[lb], 1u);
+        }
+        __syncthreads();
+        for (uint32_t r = 0; r < rounds; ++r) {
+            int open_edges = 0;
+            for (uint32_t e = tid; e < np; e += kBlock) open_edges |= (s_col[e] == SFX_NO_COLOR) ? 1 : 0;
+            if (!__syncthreads_or(open_edges)) break;  // everything coloured: later rounds would do nothing
+            for (uint32_t e = tid; e < np; e += kBlock) {  // propose
+                if (s_col[e] != SFX_NO_COLOR) continue;
+                const uint32_t la = s_la[e], lb = s_lb[e];
+                const bool da = TDYN(la), db = TDYN(lb);
+                const unsigned long long freem = ~((da ? s_used[la] : 0ull) | (db ? s_used[lb] : 0ull));
+                if (freem == 0ull) { s_prop[e] = SFX_NO_COLOR; s_ovf = 1u; continue; }
+                uint32_t dg = 1;
+                if (da) dg = max(dg, s_deg[la]);
+                if (db) dg = max(dg, s_deg[lb]);
+                dg = min(dg, 8u);
+                dg = min(dg, (uint32_t)__popcll(freem));
+                const uint32_t h = edge_hash(s_a[e], s_b[e], r);
+                const uint32_t k = mix32(h ^ 0xA5A5A5A5u) % dg;
+                const uint32_t c = kth_set_bit(freem, k);
+                s_prop[e] = (uint8_t)c;
+                const unsigned long long p = edge_prio(s_a[e], s_b[e], r, h);
+                if (da) atomicMin(&s_claim[la * kClaim + (c & (kClaim - 1u))], p);
+                if (db) atomicMin(&s_claim[lb * kClaim + (c & (kClaim - 1u))], p);
+            }
+            __syncthreads();
+            for (uint32_t e = tid; e < np; e += kBlock) {  // resolve
+                if (s_col[e] != SFX_NO_COLOR) continue;
+                const uint32_t c = s_prop[e];
+                if (c == SFX_NO_COLOR) continue;
+                const uint32_t la = s_la[e], lb = s_lb[e];
+                const bool da = TDYN(la), db = TDYN(lb);
+                const uint32_t h = edge_hash(s_a[e], s_b[e], r);
+                const unsigned long long p = edge_prio(s_a[e], s_b[e], r, h);
+                const bool win = (!da || s_claim[la * kClaim + (c & (kClaim - 1u))] == p) && (!db || s_claim[lb * kClaim + (c & (kClaim - 1u))] == p);
+                if (win) {
+                    s_col[e] = (uint8_t)c;
+                    if (da) { atomicOr(&s_used[la], 1ull << c); atomicSub(&s_deg[la], 1u); }
+                    if (db) { atomicOr(&s_used[lb], 1ull << c); atomicSub(&s_deg[lb], 1u); }
+                }
+            }
+            __syncthreads();
+        }
+        // serial first-fit finish over the leftovers, ascending key
+        for (uint32_t e = tid; e < np; e += kBlock)
+            if (s_col[e] == SFX_NO_COLOR) s_left[atomicAdd(&s_nleft, 1u)] = (uint16_t)e;
+        __syncthreads();
+        const uint32_t nleft = s_nleft;
+        if (nleft) {
+            for (uint32_t q = tid; q < nleft; q += kBlock) {
+                const uint32_t e = s_left[q];
+                const unsigned long long key = ((unsigned long long)s_a[e] << 24) | s_b[e];
+                uint32_t rank = 0;
+                for (uint32_t q2 = 0; q2 < nleft; ++q2) {
+                    const uint32_t e2 = s_left[q2];
+                    rank += ((((unsigned long long)s_a[e2] << 24) | s_b[e2]) < key) ? 1u : 0u;
+                }
+                s_srt[rank] = (uint16_t)e;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                for (uint32_t q = 0; q < nleft; ++q) {
+                    const uint32_t e = s_srt[q], la = s_la[e], lb = s_lb[e];
+                    const bool da = TDYN(la), db = TDYN(lb);
+                    const unsigned long long freem = ~((da ? s_used[la] : 0ull) | (db ? s_used[lb] : 0ull));
+                    if (freem == 0ull) { s_ovf = 1u; continue; }  // stays uncoloured: dropped from the solve
+                    const uint32_t c = (uint32_t)__builtin_ctzll(freem);
+                    s_col[e] = (uint8_t)c;
+                    if (da) s_used[la] |= 1ull << c;
+                    if (db) s_used[lb] |= 1ull << c;
+                }
+                atomicAdd(&ctr->n_leftover, nleft);
+            }
+            __syncthreads();
+        }
+#undef TDYN
+        // colour-major order inside the tile (uncoloured pairs last)
+        for (uint32_t e = tid; e < np; e += kBlock) {
+            const uint32_t c = s_col[e];
+            if (c < SFX_MAX_COLORS) atomicAdd(&s_hist[c], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t run = 0, nc = 0;
+            for (uint32_t c = 0; c < SFX_MAX_COLORS; ++c) {
+                s_base[c] = run;
+                if (s_hist[c]) nc = c + 1;
+                run += s_hist[c];
+            }
+            s_nleft = run;  // reused: cursor of the uncoloured tail
+            tile_ncol[t] = nc;
+            atomicMax(&ctr->n_colors, nc);
+            if (s_ovf) atomicOr(&ctr->overflow, kOvfColors);
+        }
+        if (tid < SFX_MAX_COLORS && s_hist[tid]) atomicAdd(&ctr->color_count[tid], s_hist[tid]);
+        __syncthreads();
+        for (uint32_t e = tid; e < np; e += kBlock) {
+            const uint32_t c = s_col[e];
+            const uint32_t dst = (c < SFX_MAX_COLORS) ? atomicAdd(&s_base[c], 1u) : atomicAdd(&s_nleft, 1u);
+            const uint32_t la = s_la[e], lb = s_lb[e];
+            tpair[start + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), c);
+        }
+        __syncthreads();
     }
 }
 
-// ---------------------------------------------------------------- K5 colouring
-// DESIGN.md "Contract / colouring"; the CPU oracle restates the same rounds sequentially.
-struct ColorArrays {
-    const uint2* pairs;            // (a, b), SFX_WORLD_BODY allowed (joints)
+// Edge colouring of one global edge list by ONE workgroup (joints at upload, the fallback list
+// every tick): same rounds as k_tile_color, with the tables in global memory.  Optionally writes
+// the edges colour-major (`sorted`) with the colour offsets (`start`, SFX_MAX_COLORS + 1).
+constexpr int kGlobalColorBlock = 1024;
+
+struct GlobalColor {
+    const uint2* edges;            // (a, b), SFX_WORLD_BODY allowed
+    const uint32_t* n_edges;       // device-side count
+    uint32_t cap;                  // list capacity (count is clamped to it)
+    int key_by_index;              // joints: keyed by edge index, pairs: by (a, b)
     const uint4* filt;             // .w = dynamic
-    unsigned long long* used;      // per body: colours taken
-    uint32_t* deg;                 // per body: uncoloured incident edges
-    unsigned long long* claim;     // per body x 8: lowest priority seen
-    uint8_t* color;                // per edge
-    uint8_t* prop;                 // per edge: proposal of this round
-    uint32_t* left_list;           // uncoloured edges after the last round
-    const uint32_t* n_edges;       // device-side edge count
-    Counters* ctr;
+    unsigned long long* used;      // [n_bodies]
+    uint32_t* deg;                 // [n_bodies]
+    unsigned long long* claim;     // [n_bodies][kClaim]
+    uint8_t* color;                // [cap] out
+    uint8_t* prop;                 // [cap] scratch
+    uint32_t* left_list;           // [kLeftCap] scratch
+    uint2* sorted;                 // optional [cap]
+    uint32_t* start;               // optional [SFX_MAX_COLORS + 1]
+    uint32_t* n_colors_out;        // optional
+    uint32_t rounds;
+    Counters* ctr;                 // overflow / n_leftover / colour stats
+    int tick_totals;               // 1: also publish n_pairs, n_tile_pairs and the overflow bits of the tick
+    const uint32_t* tile_start;    // tick_totals: scanned tile pair counts
+    uint32_t ntiles, max_pairs;
 };
 
-__device__ __forceinline__ bool edge_dyn(const ColorArrays& A, uint32_t body) {
-    return body != SFX_WORLD_BODY && A.filt[body].w != 0u;
-}
-
-__global__ __launch_bounds__(kBlock) void k_color_init(ColorArrays A) {
-    const uint32_t ne = *A.n_edges;
-    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < ne; e += gridDim.x * kBlock) {
-        const uint2 ab = A.pairs[e];
+__global__ __launch_bounds__(kGlobalColorBlock) void k_color_global(GlobalColor A) {
+    __shared__ uint32_t s_hist[SFX_MAX_COLORS], s_base[SFX_MAX_COLORS];
+    __shared__ uint32_t s_nleft;
+    __shared__ uint32_t s_raw[kLeftCap];
+    __shared__ uint32_t s_srt[kLeftCap];
+    const uint32_t tid = threadIdx.x;
+    uint32_t ne = *A.n_edges;
+    if (ne > A.cap) {
+        if (tid == 0) atomicOr(&A.ctr->overflow, kOvfFallback);
+        ne = A.cap;
+    }
+    if (A.tick_totals && tid == 0) {
+        uint32_t total = A.tile_start[A.ntiles];
+        if (total > A.max_pairs) { atomicOr(&A.ctr->overflow, kOvfPairs); total = A.max_pairs; }
+        A.ctr->n_tile_pairs = total;
+        A.ctr->n_pairs = total + ne;
+        A.ctr->n_fb = ne;
+    }
+    if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
+    if (tid == 0) s_nleft = 0u;
+    __syncthreads();
+    if (ne == 0) {
+        if (tid <= SFX_MAX_COLORS && A.start) A.start[tid] = 0u;
+        if (tid == 0 && A.n_colors_out) *A.n_colors_out = 0u;
+        return;
+    }
+#define GDYN(x) ((x) != SFX_WORLD_BODY && A.filt[(x)].w != 0u)
+    for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {
+        const uint2 ab = A.edges[e];
         A.color[e] = SFX_NO_COLOR;
-        if (edge_dyn(A, ab.x)) atomicAdd(&A.deg[ab.x], 1u);
-        if (edge_dyn(A, ab.y)) atomicAdd(&A.deg[ab.y], 1u);
+        if (GDYN(ab.x)) { A.used[ab.x] = 0ull; A.deg[ab.x] = 0u; for (int k = 0; k < kClaim; ++k) A.claim[(size_t)ab.x * kClaim + k] = ~0ull; }
+        if (GDYN(ab.y)) { A.used[ab.y] = 0ull; A.deg[ab.y] = 0u; for (int k = 0; k < kClaim; ++k) A.claim[(size_t)ab.y * kClaim + k] = ~0ull; }
     }
-}
-
-__device__ __forceinline__ unsigned long long edge_prio(uint32_t e, uint32_t r, uint32_t& h) {
-    h = mix32(e * 0x9E3779B1u + r * 0x7F4A7C15u + 0x165667B1u);
-    return ((unsigned long long)(63u - r) << 58) | ((unsigned long long)(h >> 6) << 32) | e;
-}
-
-__global__ __launch_bounds__(kBlock) void k_color_propose(ColorArrays A, uint32_t r) {
-    const uint32_t ne = *A.n_edges;
-    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < ne; e += gridDim.x * kBlock) {
-        if (A.color[e] != SFX_NO_COLOR) continue;
-        const uint2 ab = A.pairs[e];
-        const bool da = edge_dyn(A, ab.x), db = edge_dyn(A, ab.y);
-        const unsigned long long ma = da ? A.used[ab.x] : 0ull, mb = db ? A.used[ab.y] : 0ull;
-        const unsigned long long freem = ~(ma | mb);
-        if (freem == 0ull) { A.prop[e] = SFX_NO_COLOR; atomicOr(&A.ctr->overflow, kOvfColors); continue; }
-        uint32_t dg = 1;
-        if (da) dg = max(dg, A.deg[ab.x]);
-        if (db) dg = max(dg, A.deg[ab.y]);
-        dg = min(dg, 8u);
-        dg = min(dg, (uint32_t)__popcll(freem));
-        uint32_t h;
-        const unsigned long long p = edge_prio(e, r, h);
-        const uint32_t k = mix32(h ^ 0xA5A5A5A5u) % dg;
-        const uint32_t c = kth_set_bit(freem, k);
-        A.prop[e] = (uint8_t)c;
-        if (da) atomicMin(&A.claim[(size_t)ab.x * 8 + (c & 7u)], p);
-        if (db) atomicMin(&A.claim[(size_t)ab.y * 8 + (c & 7u)], p);
+    __syncthreads();
+    for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {
+        const uint2 ab = A.edges[e];
+        if (GDYN(ab.x)) atomicAdd(&A.deg[ab.x], 1u);
+        if (GDYN(ab.y)) atomicAdd(&A.deg[ab.y], 1u);
     }
-}
-
-__global__ __launch_bounds__(kBlock) void k_color_resolve(ColorArrays A, uint32_t r, int last) {
-    const uint32_t ne = *A.n_edges;
-    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < ne; e += gridDim.x * kBlock) {
-        if (A.color[e] != SFX_NO_COLOR) continue;
-        const uint32_t c = A.prop[e];
-        bool win = false;
-        if (c != SFX_NO_COLOR) {
-            const uint2 ab = A.pairs[e];
-            const bool da = edge_dyn(A, ab.x), db = edge_dyn(A, ab.y);
-            uint32_t h;
-            const unsigned long long p = edge_prio(e, r, h);
-            win = (!da || A.claim[(size_t)ab.x * 8 + (c & 7u)] == p) &&
-                  (!db || A.claim[(size_t)ab.y * 8 + (c & 7u)] == p);
+    __syncthreads();
+    for (uint32_t r = 0; r < A.rounds; ++r) {
+        for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {  // propose
+            if (A.color[e] != SFX_NO_COLOR) continue;
+            const uint2 ab = A.edges[e];
+            const bool da = GDYN(ab.x), db = GDYN(ab.y);
+            const unsigned long long freem = ~((da ? A.used[ab.x] : 0ull) | (db ? A.used[ab.y] : 0ull));
+            if (freem == 0ull) { A.prop[e] = SFX_NO_COLOR; atomicOr(&A.ctr->overflow, kOvfColors); continue; }
+            uint32_t dg = 1;
+            if (da) dg = max(dg, A.deg[ab.x]);
+            if (db) dg = max(dg, A.deg[ab.y]);
+            dg = min(dg, 8u);
+            dg = min(dg, (uint32_t)__popcll(freem));
+            const uint32_t ku = A.key_by_index ? (e >> 24) : ab.x, kv = A.key_by_index ? (e & 0xFFFFFFu) : ab.y;
+            const uint32_t h = edge_hash(ku, kv, r);
+            const uint32_t k = mix32(h ^ 0xA5A5A5A5u) % dg;
+            const uint32_t c = kth_set_bit(freem, k);
+            A.prop[e] = (uint8_t)c;
+            const unsigned long long p = edge_prio(ku, kv, r, h);
+            if (da) atomicMin(&A.claim[(size_t)ab.x * kClaim + (c & (kClaim - 1u))], p);
+            if (db) atomicMin(&A.claim[(size_t)ab.y * kClaim + (c & (kClaim - 1u))], p);
+        }
+        __syncthreads();
+        for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {  // resolve
+            if (A.color[e] != SFX_NO_COLOR) continue;
+            const uint32_t c = A.prop[e];
+            if (c == SFX_NO_COLOR) continue;
+            const uint2 ab = A.edges[e];
+            const bool da = GDYN(ab.x), db = GDYN(ab.y);
+            const uint32_t ku = A.key_by_index ? (e >> 24) : ab.x, kv = A.key_by_index ? (e & 0xFFFFFFu) : ab.y;
+            const uint32_t h = edge_hash(ku, kv, r);
+            const unsigned long long p = edge_prio(ku, kv, r, h);
+            const bool win = (!da || A.claim[(size_t)ab.x * kClaim + (c & (kClaim - 1u))] == p) &&
+                             (!db || A.claim[(size_t)ab.y * kClaim + (c & (kClaim - 1u))] == p);
             if (win) {
                 A.color[e] = (uint8_t)c;
                 if (da) { atomicOr(&A.used[ab.x], 1ull << c); atomicSub(&A.deg[ab.x], 1u); }
                 if (db) { atomicOr(&A.used[ab.y], 1ull << c); atomicSub(&A.deg[ab.y], 1u); }
             }
         }
-        if (!win && last) {
-            const uint32_t l = atomicAdd(&A.ctr->n_leftover, 1u);
-            if (l < kLeftCap) A.left_list[l] = e;
+        __syncthreads();
+    }
+    // serial first-fit finish, ascending key
+    for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {
+        if (A.color[e] != SFX_NO_COLOR) continue;
+        const uint32_t l = atomicAdd(&s_nleft, 1u);
+        if (l < kLeftCap) s_raw[l] = e;
+    }
+    __syncthreads();
+    uint32_t nleft = s_nleft;
+    if (nleft) {
+        if (nleft > kLeftCap) {
+            if (tid == 0) atomicOr(&A.ctr->overflow, kOvfLeftover);
+            nleft = kLeftCap;
+        }
+        for (uint32_t q = tid; q < nleft; q += kGlobalColorBlock) {
+            const uint32_t e = s_raw[q];
+            const uint2 ab = A.edges[e];
+            const unsigned long long key = A.key_by_index ? (unsigned long long)e : (((unsigned long long)ab.x << 24) | ab.y);
+            uint32_t rank = 0;
+            for (uint32_t q2 = 0; q2 < nleft; ++q2) {
+                const uint32_t e2 = s_raw[q2];
+                const uint2 ab2 = A.edges[e2];
+                const unsigned long long key2 = A.key_by_index ? (unsigned long long)e2 : (((unsigned long long)ab2.x << 24) | ab2.y);
+                rank += (key2 < key) ? 1u : 0u;
+            }
+            s_srt[rank] = e;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            for (uint32_t q = 0; q < nleft; ++q) {
+                const uint32_t e = s_srt[q];
+                const uint2 ab = A.edges[e];
+                const bool da = GDYN(ab.x), db = GDYN(ab.y);
+                const unsigned long long freem = ~((da ? A.used[ab.x] : 0ull) | (db ? A.used[ab.y] : 0ull));
+                if (freem == 0ull) { atomicOr(&A.ctr->overflow, kOvfColors); continue; }
+                const uint32_t c = (uint32_t)__builtin_ctzll(freem);
+                A.color[e] = (uint8_t)c;
+                if (da) A.used[ab.x] |= 1ull << c;
+                if (db) A.used[ab.y] |= 1ull << c;
+            }
+            atomicAdd(&A.ctr->n_leftover, nleft);
+        }
+        __syncthreads();
+    }
+#undef GDYN
+    for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {
+        const uint32_t c = A.color[e];
+        if (c < SFX_MAX_COLORS) atomicAdd(&s_hist[c], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t run = 0, nc = 0;
+        for (uint32_t c = 0; c < SFX_MAX_COLORS; ++c) {
+            s_base[c] = run;
+            if (A.start) A.start[c] = run;
+            if (s_hist[c]) nc = c + 1;
+            run += s_hist[c];
+        }
+        if (A.start) A.start[SFX_MAX_COLORS] = run;
+        if (A.n_colors_out) *A.n_colors_out = nc;
+        atomicMax(&A.ctr->n_colors, nc);
+    }
+    if (tid < SFX_MAX_COLORS && s_hist[tid]) atomicAdd(&A.ctr->color_count[tid], s_hist[tid]);
+    __syncthreads();
+    if (A.sorted) {
+        for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {
+            const uint32_t c = A.color[e];
+            if (c < SFX_MAX_COLORS) A.sorted[atomicAdd(&s_base[c], 1u)] = A.edges[e];
         }
     }
 }
 
-// serial first-fit finish over the (few) edges the rounds left uncoloured, ascending edge id
-__global__ __launch_bounds__(kBlock) void k_color_finish(ColorArrays A) {
-    __shared__ uint32_t raw[kLeftCap];
-    __shared__ uint32_t srt[kLeftCap];
-    uint32_t nl = A.ctr->n_leftover;
-    if (nl == 0) return;
-    if (nl > kLeftCap) {
-        if (threadIdx.x == 0) atomicOr(&A.ctr->overflow, kOvfLeftover);
-        nl = kLeftCap;
+// ---------------------------------------------------------------- K6 / K8 tile solves
+struct TileArrays {
+    const uint32_t* cell_start;
+    const uint32_t* sorted_id;
+    const uint32_t* tile_start;   // scanned pair counts
+    const uint32_t* active;       // per phase lists
+    const uint4* tpair;           // colour-major per tile
+    const uint32_t* tile_ncol;
+    const uint2* fsorted;         // fallback list, colour-major
+    uint32_t max_pairs;           // record slot of fallback pair k = max_pairs + k
+    uint32_t fb_cap;
+    unsigned long long* dbg;      // stage timing (builds with -DSFX_TILE_TIMING only), else unused
+};
+
+#ifdef SFX_TILE_TIMING
+#define SFX_TT(var) const unsigned long long var = wall_clock64()
+#define SFX_TT_ADD(slot, a, b) if (threadIdx.x == 0 && T.dbg) atomicAdd(&T.dbg[slot], (b) - (a))
+#else
+#define SFX_TT(var)
+#define SFX_TT_ADD(slot, a, b)
+#endif
+
+__device__ __forceinline__ void store_record(const ContactArrays& C, uint32_t slot, const PairRec& r) {
+    C.misc[slot] = make_float2(r.rest, __uint_as_float((uint32_t)r.count));
+    if (r.count == 0) return;
+    C.hdr[slot] = make_float4(r.nx, r.ny, r.mu_s, r.mu_d);
+    C.anc0[slot] = make_float4(r.la[0][0], r.la[0][1], r.lb[0][0], r.lb[0][1]);
+    if (r.count == 2) C.anc1[slot] = make_float4(r.la[1][0], r.la[1][1], r.lb[1][0], r.lb[1][1]);
+}
+
+__device__ __forceinline__ void load_record(const ContactArrays& C, uint32_t slot, PairRec& r) {
+    const float2 misc = C.misc[slot];
+    r.count = (int)__float_as_uint(misc.y);
+    r.rest = misc.x;
+    r.nx = r.ny = r.mu_s = r.mu_d = 0.0f;
+    r.la[0][0] = r.la[0][1] = r.lb[0][0] = r.lb[0][1] = 0.0f;
+    r.la[1][0] = r.la[1][1] = r.lb[1][0] = r.lb[1][1] = 0.0f;
+    r.vpre[0] = r.vpre[1] = 0.0f; r.l0 = r.l1 = 0.0f;
+    if (r.count == 0) return;
+    const float4 lamv = C.lamv[slot];
+    r.l0 = lamv.x; r.l1 = lamv.y; r.vpre[0] = lamv.z; r.vpre[1] = lamv.w;
+    const float4 hdr = C.hdr[slot];
+    r.nx = hdr.x; r.ny = hdr.y; r.mu_s = hdr.z; r.mu_d = hdr.w;
+    const float4 a0 = C.anc0[slot];
+    r.la[0][0] = a0.x; r.la[0][1] = a0.y; r.lb[0][0] = a0.z; r.lb[0][1] = a0.w;
+    if (r.count == 2) {
+        const float4 a1 = C.anc1[slot];
+        r.la[1][0] = a1.x; r.la[1][1] = a1.y; r.lb[1][0] = a1.z; r.lb[1][1] = a1.w;
     }
-    for (uint32_t t = threadIdx.x; t < nl; t += kBlock) raw[t] = A.left_list[t];
+}
+
+// The fallback list, solved by one whole workgroup directly on global memory after the last
+// phase: narrowphase of every fallback pair, then the XPBD solves colour by colour.
+__device__ __forceinline__ void fallback_pos(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
+                                             const ContactArrays& C, float max_corr, float sm) {
+    const uint32_t nfb = min(ctr->n_fb, T.fb_cap);
+    if (nfb == 0) return;
+    const uint32_t total = ctr->fb_start[SFX_MAX_COLORS];
+    for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
+        const uint2 ab = T.fsorted[k];
+        PairRec r;
+        prepare_pair(B.pose[ab.x], B.shape[ab.x], B.vel[ab.x], B.pose[ab.y], B.shape[ab.y], B.vel[ab.y], B.poly, B.mats, sm, r);
+        store_record(C, T.max_pairs + k, r);
+        if (r.count) C.lamv[T.max_pairs + k] = make_float4(0.0f, 0.0f, r.vpre[0], r.vpre[1]);
+    }
     __syncthreads();
-    for (uint32_t t = threadIdx.x; t < nl; t += kBlock) {
-        const uint32_t mine = raw[t];
-        uint32_t rank = 0;
-        for (uint32_t q = 0; q < nl; ++q) rank += (raw[q] < mine) ? 1u : 0u;
-        srt[rank] = mine;
+    const uint32_t nc = ctr->n_fb_colors;
+    for (uint32_t c = 0; c < nc; ++c) {
+        const uint32_t s = ctr->fb_start[c], e = ctr->fb_start[c + 1];
+        for (uint32_t k = s + threadIdx.x; k < e; k += blockDim.x) {
+            const uint2 ab = T.fsorted[k];
+            PairRec r;
+            load_record(C, T.max_pairs + k, r);
+            if (r.count == 0) continue;
+            float4 pa = B.pose[ab.x], pb = B.pose[ab.y];
+            const float2 wa = B.mass[ab.x], wb = B.mass[ab.y];
+            const bool moved = solve_pos_rec(r, pa, wa, pb, wb, max_corr);
+            C.lamv[T.max_pairs + k] = make_float4(r.l0, r.l1, r.vpre[0], r.vpre[1]);
+            if (moved) {
+                if (wa.x > 0.0f || wa.y > 0.0f) B.pose[ab.x] = pa;
+                if (wb.x > 0.0f || wb.y > 0.0f) B.pose[ab.y] = pb;
+            }
+        }
+        __syncthreads();
     }
+}
+
+__device__ __forceinline__ void fallback_vel(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
+                                             const ContactArrays& C, const StepParams& sp) {
+    const uint32_t nfb = min(ctr->n_fb, T.fb_cap);
+    if (nfb == 0) return;
+    const uint32_t nc = ctr->n_fb_colors;
+    for (uint32_t c = 0; c < nc; ++c) {
+        const uint32_t s = ctr->fb_start[c], e = ctr->fb_start[c + 1];
+        for (uint32_t k = s + threadIdx.x; k < e; k += blockDim.x) {
+            const uint2 ab = T.fsorted[k];
+            PairRec r;
+            load_record(C, T.max_pairs + k, r);
+            if (r.count == 0) continue;
+            float4 pa = B.pose[ab.x], pb = B.pose[ab.y];
+            float4 va = B.vel[ab.x], vb = B.vel[ab.y];
+            const float2 wa = B.mass[ab.x], wb = B.mass[ab.y];
+            const int ch = solve_vel_rec(r, pa, va, wa, pb, vb, wb, sp);
+            if (ch) {
+                if (wa.x > 0.0f || wa.y > 0.0f) { B.vel[ab.x] = va; if (ch & 2) B.pose[ab.x] = pa; }
+                if (wb.x > 0.0f || wb.y > 0.0f) { B.vel[ab.y] = vb; if (ch & 2) B.pose[ab.y] = pb; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// true for exactly one workgroup of the grid: the one that finishes last.  Everything the
+// others wrote before is visible to it afterwards.
+__device__ __forceinline__ bool last_workgroup(Counters* __restrict__ ctr) {
+    __shared__ uint32_t s_last;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (uint32_t t = 0; t < nl; ++t) {
-            const uint32_t e = srt[t];
-            const uint2 ab = A.pairs[e];
-            const bool da = edge_dyn(A, ab.x), db = edge_dyn(A, ab.y);
-            const unsigned long long freem = ~((da ? A.used[ab.x] : 0ull) | (db ? A.used[ab.y] : 0ull));
-            if (freem == 0ull) { atomicOr(&A.ctr->overflow, kOvfColors); continue; }  // dropped from the solve
-            const uint32_t c = (uint32_t)__builtin_ctzll(freem);
-            A.color[e] = (uint8_t)c;
-            if (da) A.used[ab.x] |= 1ull << c;
-            if (db) A.used[ab.y] |= 1ull << c;
-        }
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_color_hist(ColorArrays A) {
-    __shared__ uint32_t hist[SFX_MAX_COLORS];
-    if (threadIdx.x < SFX_MAX_COLORS) hist[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t ne = *A.n_edges;
-    for (uint32_t e = blockIdx.x * kBlock + threadIdx.x; e < ne; e += gridDim.x * kBlock) {
-        const uint32_t c = A.color[e];
-        if (c < SFX_MAX_COLORS) atomicAdd(&hist[c], 1u);
+        __threadfence();
+        const uint32_t tk = atomicAdd(&ctr->ticket, 1u);
+        s_last = (tk + 1u == gridDim.x) ? 1u : 0u;
+        if (s_last) { ctr->ticket = 0u; __threadfence(); }
     }
     __syncthreads();
-    if (threadIdx.x < SFX_MAX_COLORS && hist[threadIdx.x]) atomicAdd(&A.ctr->color_count[threadIdx.x], hist[threadIdx.x]);
+    const bool last = s_last != 0u;
+    if (last) __threadfence();
+    return last;
 }
 
-__global__ void k_color_scan(Counters* __restrict__ ctr) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t run = 0, nc = 0;
-    for (uint32_t c = 0; c < SFX_MAX_COLORS; ++c) {
-        ctr->color_start[c] = run;
-        const uint32_t k = ctr->color_count[c];
-        if (k) nc = c + 1;
-        run += k;
-    }
-    ctr->color_start[SFX_MAX_COLORS] = run;
-    ctr->n_colors = nc;
+// One end of a tile pair: inside the block (LDS index) or a large non-dynamic collider outside
+// it (kExt), which is read from global memory and never written.
+struct PairEnds {
+    uint32_t a, b;     // body ids
+    uint32_t la, lb;   // local indices or kExt
+    uint32_t col;
+};
+
+__device__ __forceinline__ PairEnds pair_ends(const uint4& pr) {
+    PairEnds e;
+    e.a = pr.x; e.b = pr.y; e.la = pr.z & 0xFFFFu; e.lb = pr.z >> 16; e.col = pr.w;
+    return e;
 }
 
-// colour-major reorder.  A block reserves one contiguous run per colour (LDS histogram, one
-// global atomic per colour and block), so pairs that were neighbours in the spatially sorted
-// list stay neighbours inside their colour: the per-colour gathers keep their L2 locality.
-__global__ __launch_bounds__(kBlock) void k_color_scatter(ColorArrays A, uint2* __restrict__ cpairs) {
-    __shared__ uint32_t cnt[SFX_MAX_COLORS];
-    __shared__ uint32_t base[SFX_MAX_COLORS];
-    const uint32_t ne = *A.n_edges;
-    const uint32_t ntiles = (ne + kBlock - 1) / kBlock;
-    for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        if (threadIdx.x < SFX_MAX_COLORS) cnt[threadIdx.x] = 0u;
-        __syncthreads();
-        const uint32_t e = tile * kBlock + threadIdx.x;
-        uint32_t c = SFX_NO_COLOR, rank = 0;
-        uint2 ab = make_uint2(0, 0);
-        if (e < ne) {
-            c = A.color[e];
-            ab = A.pairs[e];
-            if (c < SFX_MAX_COLORS) rank = atomicAdd(&cnt[c], 1u);
+// Position solve of one phase.  A workgroup takes one tile at a time: the poses of the tile's
+// 2x2 block go to LDS, the narrowphase of the tile's pairs runs at those poses, then the tile's
+// colours are solved one after the other with a workgroup barrier in between, and the block's
+// dynamic bodies are written back.  Tiles of one phase have disjoint blocks.
+// Tiles with at most NT pairs keep one pair record per thread in registers; bigger ones (rare)
+// keep the records in the contact arrays and walk the pairs in strides of NT.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback, GridParams g, TileArrays T,
+                                                  Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
+                                                  float max_corr, float sm) {
+    __shared__ float4 s_pose[kMaxB];
+    __shared__ float2 s_mass[kMaxB];
+    __shared__ uint32_t s_gid[kMaxB];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nact = ctr->n_active[ph];
+    for (uint32_t it = blockIdx.x; it < nact; it += gridDim.x) {
+        SFX_TT(tt0);
+        const uint32_t t = T.active[ph * (g.ntiles >> 2) + it];
+        BlockRanges R;
+        block_ranges(t, g, T.cell_start, R);
+        const uint32_t nb = min(R.off[4], kMaxB);
+        uint32_t start, np;
+        tile_pair_range(t, T.tile_start, T.max_pairs, start, np);
+        np = min(np, kMaxP);
+        const uint32_t ncol = T.tile_ncol[t];
+        for (uint32_t l = tid; l < nb; l += NT) {
+            const uint32_t gid = T.sorted_id[block_slot(R, l)];
+            s_gid[l] = gid;
+            s_pose[l] = B.pose[gid];
+            s_mass[l] = B.mass[gid];
         }
         __syncthreads();
-        if (threadIdx.x < SFX_MAX_COLORS) {
-            const uint32_t k = cnt[threadIdx.x];
-            base[threadIdx.x] = k ? A.ctr->color_start[threadIdx.x] + atomicAdd(&A.ctr->color_fill[threadIdx.x], k) : 0u;
+        SFX_TT(tt1);
+        // narrowphase of pair k at the poses in LDS
+        auto prepare = [&](const PairEnds& e, PairRec& r) {
+            const float4 pa = e.la == kExt ? B.pose[e.a] : s_pose[e.la];
+            const float4 pb = e.lb == kExt ? B.pose[e.b] : s_pose[e.lb];
+            prepare_pair(pa, B.shape[e.a], B.vel[e.a], pb, B.shape[e.b], B.vel[e.b], B.poly, B.mats, sm, r);
+        };
+        auto solve = [&](const PairEnds& e, PairRec& r) {
+            const bool ea = e.la == kExt, eb = e.lb == kExt;
+            float4 pa = ea ? B.pose[e.a] : s_pose[e.la];
+            float4 pb = eb ? B.pose[e.b] : s_pose[e.lb];
+            const float2 wa = ea ? B.mass[e.a] : s_mass[e.la];
+            const float2 wb = eb ? B.mass[e.b] : s_mass[e.lb];
+            if (solve_pos_rec(r, pa, wa, pb, wb, max_corr)) {
+                if (!ea && (wa.x > 0.0f || wa.y > 0.0f)) s_pose[e.la] = pa;
+                if (!eb && (wb.x > 0.0f || wb.y > 0.0f)) s_pose[e.lb] = pb;
+            }
+        };
+        if (np <= (uint32_t)NT) {
+            const bool mine = tid < np;
+            PairEnds e = pair_ends(make_uint4(0, 0, 0, SFX_NO_COLOR));
+            PairRec r;
+            r.count = 0;
+            if (mine) {
+                e = pair_ends(T.tpair[start + tid]);
+                prepare(e, r);
+                store_record(C, start + tid, r);
+            }
+            __syncthreads();
+            SFX_TT(tt2);
+            for (uint32_t c = 0; c < ncol; ++c) {
+                if (e.col == c && r.count) solve(e, r);
+                __syncthreads();
+            }
+            SFX_TT(tt3);
+            SFX_TT_ADD(1, tt1, tt2); SFX_TT_ADD(2, tt2, tt3); SFX_TT_ADD(5, 0ull, (unsigned long long)ncol);
+            if (mine && r.count) C.lamv[start + tid] = make_float4(r.l0, r.l1, r.vpre[0], r.vpre[1]);
+        } else {
+            for (uint32_t k = tid; k < np; k += NT) {
+                const PairEnds e = pair_ends(T.tpair[start + k]);
+                PairRec r;
+                prepare(e, r);
+                store_record(C, start + k, r);
+                if (r.count) C.lamv[start + k] = make_float4(0.0f, 0.0f, r.vpre[0], r.vpre[1]);
+            }
+            __syncthreads();
+            for (uint32_t c = 0; c < ncol; ++c) {
+                for (uint32_t k = tid; k < np; k += NT) {
+                    const PairEnds e = pair_ends(T.tpair[start + k]);
+                    if (e.col != c) continue;
+                    PairRec r;
+                    load_record(C, start + k, r);
+                    if (!r.count) continue;
+                    solve(e, r);
+                    C.lamv[start + k] = make_float4(r.l0, r.l1, r.vpre[0], r.vpre[1]);
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t l = tid; l < nb; l += NT) {
+            const float2 w = s_mass[l];
+            if (w.x > 0.0f || w.y > 0.0f) B.pose[s_gid[l]] = s_pose[l];
         }
         __syncthreads();
-        if (e < ne && c < SFX_MAX_COLORS) cpairs[base[c] + rank] = ab;
+        SFX_TT(tt4);
+        SFX_TT_ADD(0, tt0, tt1); SFX_TT_ADD(3, tt0, tt4); SFX_TT_ADD(4, 0ull, 1ull);
+    }
+    if (with_fallback && last_workgroup(ctr)) fallback_pos(T, ctr, B, C, max_corr, sm);
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph, int with_fallback, GridParams g, TileArrays T,
+                                                  Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
+                                                  StepParams sp) {
+    __shared__ float4 s_pose[kMaxB];
+    __shared__ float4 s_vel[kMaxB];
+    __shared__ float2 s_mass[kMaxB];
+    __shared__ uint32_t s_gid[kMaxB];
+    __shared__ uint32_t s_shift;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t nact = ctr->n_active[ph];
+    for (uint32_t it = blockIdx.x; it < nact; it += gridDim.x) {
+        const uint32_t t = T.active[ph * (g.ntiles >> 2) + it];
+        BlockRanges R;
+        block_ranges(t, g, T.cell_start, R);
+        const uint32_t nb = min(R.off[4], kMaxB);
+        uint32_t start, np;
+        tile_pair_range(t, T.tile_start, T.max_pairs, start, np);
+        np = min(np, kMaxP);
+        const uint32_t ncol = T.tile_ncol[t];
+        if (tid == 0) s_shift = 0u;
+        for (uint32_t l = tid; l < nb; l += NT) {
+            const uint32_t gid = T.sorted_id[block_slot(R, l)];
+            s_gid[l] = gid;
+            s_pose[l] = B.pose[gid];
+            s_vel[l] = B.vel[gid];
+            s_mass[l] = B.mass[gid];
+        }
         __syncthreads();
-    }
-}
-
-// ---------------------------------------------------------------- K6 / K8 solves
-// One launch per colour: inside a colour no dynamic body appears twice, so every thread
-// owns the bodies of its pair.  Colours >= first_tail share one single-workgroup kernel that
-// walks them in order with a workgroup barrier in between (the tail colours are tiny).
-__global__ __launch_bounds__(kBlock) void k_solve_pos(uint32_t color, const Counters* __restrict__ ctr,
-                                                       const uint2* __restrict__ cpairs, BodyArrays B, ContactArrays C,
-                                                       float max_corr) {
-    const uint32_t start = ctr->color_start[color], cnt = ctr->color_count[color];
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < cnt; k += gridDim.x * kBlock) {
-        const uint2 ab = cpairs[start + k];
-        solve_pos_pair(B, C, start + k, ab.x, ab.y, max_corr);
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_solve_pos_tail(uint32_t first, const Counters* __restrict__ ctr,
-                                                          const uint2* __restrict__ cpairs, BodyArrays B, ContactArrays C,
-                                                          float max_corr) {
-    const uint32_t nc = ctr->n_colors;
-    for (uint32_t color = first; color < nc; ++color) {
-        const uint32_t start = ctr->color_start[color], cnt = ctr->color_count[color];
-        for (uint32_t k = threadIdx.x; k < cnt; k += kBlock) {
-            const uint2 ab = cpairs[start + k];
-            solve_pos_pair(B, C, start + k, ab.x, ab.y, max_corr);
+        auto solve = [&](const PairEnds& e, const PairRec& r) {
+            const bool ea = e.la == kExt, eb = e.lb == kExt;
+            float4 pa = ea ? B.pose[e.a] : s_pose[e.la], va = ea ? B.vel[e.a] : s_vel[e.la];
+            float4 pb = eb ? B.pose[e.b] : s_pose[e.lb], vb = eb ? B.vel[e.b] : s_vel[e.lb];
+            const float2 wa = ea ? B.mass[e.a] : s_mass[e.la], wb = eb ? B.mass[e.b] : s_mass[e.lb];
+            const int ch = solve_vel_rec(r, pa, va, wa, pb, vb, wb, sp);
+            if (ch) {
+                if (!ea && (wa.x > 0.0f || wa.y > 0.0f)) { s_vel[e.la] = va; if (ch & 2) s_pose[e.la] = pa; }
+                if (!eb && (wb.x > 0.0f || wb.y > 0.0f)) { s_vel[e.lb] = vb; if (ch & 2) s_pose[e.lb] = pb; }
+                if (ch & 2) s_shift = 1u;
+            }
+        };
+        if (np <= (uint32_t)NT) {
+            PairEnds e = pair_ends(make_uint4(0, 0, 0, SFX_NO_COLOR));
+            PairRec r;
+            r.count = 0;
+            if (tid < np) {
+                e = pair_ends(T.tpair[start + tid]);
+                load_record(C, start + tid, r);
+            }
+            for (uint32_t c = 0; c < ncol; ++c) {
+                if (e.col == c && r.count) solve(e, r);
+                __syncthreads();
+            }
+        } else {
+            for (uint32_t c = 0; c < ncol; ++c) {
+                for (uint32_t k = tid; k < np; k += NT) {
+                    const PairEnds e = pair_ends(T.tpair[start + k]);
+                    if (e.col != c) continue;
+                    PairRec r;
+                    load_record(C, start + k, r);
+                    if (r.count) solve(e, r);
+                }
+                __syncthreads();
+            }
+        }
+        const bool shifted = s_shift != 0u;
+        for (uint32_t l = tid; l < nb; l += NT) {
+            const float2 w = s_mass[l];
+            if (w.x > 0.0f || w.y > 0.0f) {
+                B.vel[s_gid[l]] = s_vel[l];
+                if (shifted) B.pose[s_gid[l]] = s_pose[l];
+            }
         }
         __syncthreads();
     }
-}
-
-__global__ __launch_bounds__(kBlock) void k_solve_vel(uint32_t color, const Counters* __restrict__ ctr,
-                                                       const uint2* __restrict__ cpairs, BodyArrays B, ContactArrays C,
-                                                       StepParams sp) {
-    const uint32_t start = ctr->color_start[color], cnt = ctr->color_count[color];
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < cnt; k += gridDim.x * kBlock) {
-        const uint2 ab = cpairs[start + k];
-        solve_vel_pair(B, C, start + k, ab.x, ab.y, sp);
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_solve_vel_tail(uint32_t first, const Counters* __restrict__ ctr,
-                                                          const uint2* __restrict__ cpairs, BodyArrays B, ContactArrays C,
-                                                          StepParams sp) {
-    const uint32_t nc = ctr->n_colors;
-    for (uint32_t color = first; color < nc; ++color) {
-        const uint32_t start = ctr->color_start[color], cnt = ctr->color_count[color];
-        for (uint32_t k = threadIdx.x; k < cnt; k += kBlock) {
-            const uint2 ab = cpairs[start + k];
-            solve_vel_pair(B, C, start + k, ab.x, ab.y, sp);
-        }
-        __syncthreads();
-    }
+    if (with_fallback && last_workgroup(ctr)) fallback_vel(T, ctr, B, C, sp);
 }
 
 __global__ __launch_bounds__(kBlock) void k_solve_joints(uint32_t start, uint32_t cnt, BodyArrays B, JointArrays J,
@@ -626,23 +1207,31 @@ __global__ __launch_bounds__(kBlock) void k_stats_bodies(uint32_t n, const float
     }
 }
 
-// deepest penetration at the current poses and the number of active contact points of the
-// last substep, over all candidate pairs
+// deepest penetration at the current poses and the manifold / active contact point counts of
+// the last substep, over all candidate pairs (tile pairs, then the fallback list)
 __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restrict__ cin, Counters* __restrict__ ctr,
-                                                         const uint2* __restrict__ cpairs, BodyArrays B, ContactArrays C) {
-    const uint32_t np = cin->color_start[SFX_MAX_COLORS];  // coloured pairs (all, unless colours overflowed)
+                                                         TileArrays T, BodyArrays B, ContactArrays C, float sm) {
+    const uint32_t ntp = cin->n_tile_pairs, nfb = cin->fb_start[SFX_MAX_COLORS];
     uint32_t contacts = 0, mf = 0, mf2 = 0;
     float md = 0.0f;
-    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < np; k += gridDim.x * kBlock) {
-        const uint2 ab = cpairs[k];
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < ntp + nfb; k += gridDim.x * kBlock) {
+        uint32_t a, b, slot;
+        if (k < ntp) {
+            const uint4 pr = T.tpair[k];
+            if (pr.w >= SFX_MAX_COLORS) continue;  // uncoloured: never solved
+            a = pr.x; b = pr.y; slot = k;
+        } else {
+            const uint2 ab = T.fsorted[k - ntp];
+            a = ab.x; b = ab.y; slot = T.max_pairs + (k - ntp);
+        }
         Manifold m;
-        manifold(B.pose[ab.x], B.shape[ab.x], B.pose[ab.y], B.shape[ab.y], B.poly, m);
+        manifold(B.pose[a], B.shape[a], B.pose[b], B.shape[b], B.poly, sm, m);
         for (int q = 0; q < m.count; ++q) md = fmaxf(md, m.depth[q]);
-        const uint32_t cnt = __float_as_uint(C.misc[k].y);
+        const uint32_t cnt = __float_as_uint(C.misc[slot].y);
         if (cnt) {
             mf += 1u;
             mf2 += (cnt == 2) ? 1u : 0u;
-            const float4 lv = C.lamv[k];
+            const float4 lv = C.lamv[slot];
             contacts += (lv.x > 0.0f) ? 1u : 0u;
             contacts += (cnt == 2 && lv.y > 0.0f) ? 1u : 0u;
         }
@@ -654,12 +1243,12 @@ __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restri
 }
 
 __global__ __launch_bounds__(kBlock) void k_contacts_debug(uint32_t np, const uint2* __restrict__ pairs, BodyArrays B,
-                                                            sfx_contact* __restrict__ out) {
+                                                            float sm, sfx_contact* __restrict__ out) {
     const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
     if (k >= np) return;
     const uint2 ab = pairs[k];
     Manifold m;
-    manifold(B.pose[ab.x], B.shape[ab.x], B.pose[ab.y], B.shape[ab.y], B.poly, m);
+    manifold(B.pose[ab.x], B.shape[ab.x], B.pose[ab.y], B.shape[ab.y], B.poly, sm, m);
     sfx_contact c;
     c.body_a = ab.x; c.body_b = ab.y; c.count = (uint32_t)m.count;
     c.normal[0] = m.count ? m.nx : 0.0f; c.normal[1] = m.count ? m.ny : 0.0f;

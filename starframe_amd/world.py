@@ -142,10 +142,11 @@ class World(WorldBase):
         cap = max(int(self.stats().n_pairs), 1)
         keys = np.empty(cap, np.uint64)
         col = np.empty(cap, np.uint8)
+        tiles = np.empty(cap, np.uint32)
         n = C.c_size_t()
-        self._check(self.lib.sfx_debug_pair_colors(self.handle, vptr(keys), vptr(col), cap, C.byref(n)))
+        self._check(self.lib.sfx_debug_pair_colors(self.handle, vptr(keys), vptr(col), vptr(tiles), cap, C.byref(n)))
         k = min(n.value, cap)
-        return keys[:k], col[:k]
+        return keys[:k], col[:k], tiles[:k]
 
     def contacts(self):
         cap = max(int(self.stats().n_pairs), 1)

@@ -32,9 +32,10 @@ def make(name, s):
     out = scene_arrays(s)
     out["aabbs"] = w.aabbs()
     out["pairs"] = w.pairs()
-    k, c = w.pair_colors()
+    k, c, t = w.pair_colors()
     o = np.argsort(k, kind="stable")
     out["pair_colors"] = c[o]
+    out["pair_tiles"] = t[o]
     out["contacts"] = w.contacts()
     perm, col = w.joint_order()
     out["joint_perm"], out["joint_colors"] = perm, col

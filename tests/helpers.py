@@ -20,21 +20,49 @@ def ulp_diff(a, b):
     return int(np.max(np.abs(a - b))) if a.size else 0
 
 
-def colors_by_key(keys, colors):
+def colors_by_key(keys, colors, tiles=None):
+    """(keys, colours[, owner tiles]) sorted by pair key."""
     order = np.argsort(keys, kind="stable")
-    return keys[order], colors[order]
+    if tiles is None:
+        return keys[order], colors[order]
+    return keys[order], colors[order], tiles[order]
 
 
-def coloring_valid(keys, colors, dynamic):
-    """No dynamic body appears twice within one colour; every pair coloured."""
+def coloring_valid(keys, colors, dynamic, tiles=None):
+    """No dynamic body appears twice within one colour of one batch (tile / fallback list);
+    every pair coloured."""
     a = (keys >> np.uint64(32)).astype(np.int64)
     b = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
     if np.any(colors >= 64):
         return False
-    for end in (a, b):
-        pass
+    t = np.zeros(len(keys), np.int64) if tiles is None else tiles.astype(np.int64)
     ends = np.concatenate([a, b])
     cols = np.concatenate([colors, colors]).astype(np.int64)
+    tt = np.concatenate([t, t])
     dyn = dynamic[ends]
-    code = ends[dyn] * 64 + cols[dyn]
-    return len(np.unique(code)) == len(code)
+    code = np.stack([tt[dyn], ends[dyn], cols[dyn]], axis=1)
+    return len(np.unique(code, axis=0)) == len(code)
+
+
+def tile_phases_disjoint(keys, tiles, dynamic, grid_log2, tile_cells):
+    """Tiles of one phase (same parity of tile x, y) never share a dynamic body."""
+    a = (keys >> np.uint64(32)).astype(np.int64)
+    b = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    lx = grid_log2[0] - int(tile_cells).bit_length() + 1
+    ok = tiles != 0xFFFFFFFF
+    t = tiles[ok].astype(np.int64)
+    ph = (t & 1) | (((t >> lx) & 1) << 1)
+    for end in (a[ok], b[ok]):
+        d = dynamic[end]
+        code = np.unique(np.stack([ph[d], end[d], t[d]], axis=1), axis=0)
+        # a (phase, body) may appear with one tile only
+        pb = code[:, :2]
+        if len(np.unique(pb, axis=0)) != len(pb):
+            return False
+    # both ends together
+    e2 = np.concatenate([a[ok], b[ok]])
+    t2 = np.concatenate([t, t])
+    p2 = np.concatenate([ph, ph])
+    d = dynamic[e2]
+    code = np.unique(np.stack([p2[d], e2[d], t2[d]], axis=1), axis=0)
+    return len(np.unique(code[:, :2], axis=0)) == len(code)

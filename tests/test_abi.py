@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(libsfx):
     assert sorted(_abi.SFX_SYMBOLS) == syms, "starframe_amd/_abi.py symbol list out of date"
     for s in syms:
         assert hasattr(libsfx, s), f"libsfx.so does not export {s}"
-    assert libsfx.sfx_abi_version() == 1
+    assert libsfx.sfx_abi_version() == 2
 
 
 def test_struct_layouts_match_header():
@@ -68,7 +68,7 @@ def test_default_config(libsfx):
     libsfx.sfx_default_config(C.byref(cfg))
     assert cfg.struct_size == C.sizeof(_abi.SfxConfig)
     assert cfg.substeps == 4 and abs(cfg.gravity[1] + 9.81) < 1e-6
-    assert cfg.color_rounds == 12 and cfg.launch_colors == 16
+    assert cfg.color_rounds == 12 and cfg.tile_cells == 1
 
 
 def test_create_fails_loudly_without_gpu(libsfx):

@@ -37,8 +37,8 @@ def test_oracle_reproduces_golden(path):
     w.broadphase(DT)
     assert np.array_equal(w.aabbs().view(np.uint32), z["aabbs"].view(np.uint32))
     assert np.array_equal(w.pairs(), z["pairs"])
-    k, c = colors_by_key(*w.pair_colors())
-    assert np.array_equal(c, z["pair_colors"])
+    k, c, t = colors_by_key(*w.pair_colors())
+    assert np.array_equal(c, z["pair_colors"]) and np.array_equal(t, z["pair_tiles"])
     assert w.contacts().tobytes() == z["contacts"].tobytes()
     w.step(DT, ORDER_COLORED)
     p, r = w.poses()
@@ -59,8 +59,8 @@ def test_gpu_matches_golden(path):
     g.broadphase(DT)
     assert np.array_equal(g.aabbs().view(np.uint32), z["aabbs"].view(np.uint32))
     assert np.array_equal(g.pairs(), z["pairs"])
-    k, c = colors_by_key(*g.pair_colors())
-    assert np.array_equal(c, z["pair_colors"])
+    k, c, t = colors_by_key(*g.pair_colors())
+    assert np.array_equal(c, z["pair_colors"]) and np.array_equal(t, z["pair_tiles"])
     gc, oc = g.contacts(), z["contacts"]
     assert np.array_equal(gc["count"], oc["count"])
     assert rel_err(gc["normal"], oc["normal"], floor=1.0) <= 1e-5

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from starframe_amd import scenes
-from tests.helpers import coloring_valid, colors_by_key, rel_err, ulp_diff
+from tests.helpers import coloring_valid, colors_by_key, rel_err, tile_phases_disjoint, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -50,15 +50,20 @@ def test_colouring_matches_oracle(n, seed, extent):
     g, o = make_pair(s)
     g.broadphase(DT)
     o.broadphase(DT)
-    gk, gc = colors_by_key(*g.pair_colors())
-    ok, oc = colors_by_key(*o.pair_colors())
+    gk, gc, gt = colors_by_key(*g.pair_colors())
+    ok, oc, ot = colors_by_key(*o.pair_colors())
     dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
-    assert coloring_valid(gk, gc, dyn)
+    rc = o.resolved_config()
+    assert coloring_valid(gk, gc, dyn, gt)
+    assert tile_phases_disjoint(gk, gt, dyn, tuple(rc.grid_log2), rc.tile_cells)
     assert np.array_equal(gk, ok)
+    assert np.array_equal(gt, ot), "owner tiles differ from the restated tiling"
     assert np.array_equal(gc, oc), "pair colours differ from the restated colouring"
     gs, os_ = g.stats(), o.stats()
     assert gs.n_colors == os_.n_colors and gs.n_leftover == os_.n_leftover
     assert list(gs.color_count) == list(os_.color_count)
+    assert (gs.n_tiles, gs.n_fallback, gs.max_tile_pairs, gs.max_tile_bodies) == \
+           (os_.n_tiles, os_.n_fallback, os_.max_tile_pairs, os_.max_tile_bodies)
 
 
 @pytest.mark.parametrize("n,seed,extent", SOUPS)
@@ -96,6 +101,52 @@ def test_single_tick_positions(n, seed, extent):
     assert rel_err(gv, ov, floor=1.0) <= 1e-4
     assert rel_err(gw, ow, floor=10.0) <= 1e-4
     print("ulp pos", ulp_diff(gp, op), "rot", ulp_diff(gr, orr))
+
+
+@pytest.mark.parametrize("kw", [dict(tile_cells=2), dict(tile_cells=4), dict(tile_cells=8), dict(cell_size=0.2), dict(color_rounds=1)],
+                         ids=["tile2", "tile4", "tile8", "large_dynamic_fallback", "serial_colour_finish"])
+def test_tiling_variants_match_oracle(kw):
+    """Other tile sizes, a cell size that pushes big dynamic bodies onto the fallback list, and a
+    colouring that leans on the serial finish: tiles, colours and one tick still match."""
+    from oracle.oracle import ORDER_COLORED
+
+    s = scenes.random_soup(1500, seed=9, extent=7.0)
+    g, o = make_pair(s, **kw)
+    g.broadphase(DT)
+    o.broadphase(DT)
+    gk, gc, gt = colors_by_key(*g.pair_colors())
+    ok, oc, ot = colors_by_key(*o.pair_colors())
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot) and np.array_equal(gc, oc)
+    if "cell_size" in kw:
+        assert g.stats().n_fallback > 0
+    g.step(DT)
+    o.step(DT, ORDER_COLORED)
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= TOL
+    assert rel_err(g.poses()[1], o.poses()[1], floor=1.0) <= TOL
+    assert rel_err(g.velocities()[0], o.velocities()[0], floor=1.0) <= 1e-4
+
+
+def test_overfull_tiles_fall_back_and_match():
+    from oracle.oracle import ORDER_COLORED
+    from starframe_amd.scenes import SceneBuilder
+
+    b = SceneBuilder("dense")
+    b.static_rect((0.0, -0.5), 10.0, 0.5)
+    b.circle((6.0, 1.0), 1.0)
+    for i in range(40):
+        for j in range(40):
+            b.circle((-2.0 + 0.05 * i, 0.03 + 0.05 * j), 0.026)
+    s = b.build()
+    g, o = make_pair(s)
+    g.broadphase(DT)
+    o.broadphase(DT)
+    gk, gc, gt = colors_by_key(*g.pair_colors())
+    ok, oc, ot = colors_by_key(*o.pair_colors())
+    assert g.stats().n_fallback > 1000 and g.stats().n_fallback == o.stats().n_fallback
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot) and np.array_equal(gc, oc)
+    g.step(DT)
+    o.step(DT, ORDER_COLORED)
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= TOL
 
 
 def test_pyramid_single_tick_and_long_run():
@@ -167,7 +218,7 @@ def test_empty_and_tiny_worlds():
 def test_pair_capacity_overflow_reported():
     from starframe_amd.world import SfxError, World
 
-    s = scenes.random_soup(2000, seed=5, extent=3.0)
+    s = scenes.random_soup(2000, seed=5, extent=8.0)
     w = World.from_scene(s, max_pairs=1024)
     w.step(DT)
     assert w.stats().overflow & 1

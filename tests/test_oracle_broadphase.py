@@ -7,7 +7,7 @@ import pytest
 from oracle.oracle import OracleWorld
 from starframe_amd import scenes
 from starframe_amd.scenes import SceneBuilder
-from tests.helpers import coloring_valid, colors_by_key
+from tests.helpers import coloring_valid, colors_by_key, tile_phases_disjoint
 
 DT = 1.0 / 60.0
 
@@ -74,17 +74,63 @@ def test_colouring_is_valid_and_deterministic(rounds):
     dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
     w = OracleWorld.from_scene(s, color_rounds=rounds)
     w.broadphase(DT)
-    k1, c1 = w.pair_colors()
-    assert coloring_valid(k1, c1, dyn)
+    k1, c1, t1 = w.pair_colors()
+    assert coloring_valid(k1, c1, dyn, t1)
+    rc = w.resolved_config()
+    assert tile_phases_disjoint(k1, t1, dyn, tuple(rc.grid_log2), rc.tile_cells)
     st = w.stats()
     assert st.n_colors <= 40
     assert sum(st.color_count) == st.n_pairs
+    assert st.n_tiles > 4 and st.n_fallback == int((t1 == 0xFFFFFFFF).sum())
     if rounds == 1:
         assert st.n_leftover > 0  # the serial finish did real work
     w2 = OracleWorld.from_scene(s, color_rounds=rounds)
     w2.broadphase(DT)
-    k2, c2 = w2.pair_colors()
-    assert np.array_equal(k1, k2) and np.array_equal(c1, c2)
+    k2, c2, t2 = w2.pair_colors()
+    assert np.array_equal(k1, k2) and np.array_equal(c1, c2) and np.array_equal(t1, t2)
+
+
+@pytest.mark.parametrize("tile_cells,cell", [(1, 0.0), (2, 0.0), (4, 0.0), (8, 0.0), (1, 0.2)])
+def test_tile_ownership_keeps_phases_disjoint(tile_cells, cell):
+    """Every tile size, and a cell size that makes big dynamic bodies 'large' (fallback list):
+    tiles of one phase never share a dynamic body, colours are valid per tile."""
+    s = scenes.random_soup(1500, seed=9, extent=7.0)
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    w = OracleWorld.from_scene(s, tile_cells=tile_cells, cell_size=cell)
+    w.broadphase(DT)
+    k, c, t = w.pair_colors()
+    rc = w.resolved_config()
+    assert rc.tile_cells == tile_cells
+    assert coloring_valid(k, c, dyn, t)
+    assert tile_phases_disjoint(k, t, dyn, tuple(rc.grid_log2), rc.tile_cells)
+    st = w.stats()
+    assert st.max_tile_pairs <= 2048 and st.max_tile_bodies <= 512
+    if cell:
+        assert st.n_fallback > 0 and st.n_large > 3
+
+
+def test_overfull_tiles_fall_back():
+    """Many tiny bodies next to one big dynamic one: the cell is sized by the big body, tiles
+    overflow SFX_TILE_MAX_PAIRS / _BODIES and hand their pairs to the fallback list."""
+    from starframe_amd.scenes import SceneBuilder
+
+    b = SceneBuilder("dense")
+    b.static_rect((0.0, -0.5), 10.0, 0.5)
+    b.circle((6.0, 1.0), 1.0)
+    for i in range(40):
+        for j in range(40):
+            b.circle((-2.0 + 0.05 * i, 0.03 + 0.05 * j), 0.026)
+    s = b.build()
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    w = OracleWorld.from_scene(s)
+    w.broadphase(DT)
+    k, c, t = w.pair_colors()
+    st = w.stats()
+    assert st.n_fallback > 1000
+    assert coloring_valid(k, c, dyn, t)
+    for _ in range(5):
+        w.step(DT)
+    assert np.isfinite(w.poses()[0]).all()
 
 
 def test_chain_joint_colouring_two_colours_possible():
@@ -109,3 +155,4 @@ def test_auto_grid_and_cell_resolution():
     assert rc.cell_size > 0.4
     assert rc.grid_log2[0] == rc.grid_log2[1] == 5
     assert rc.max_pairs == 12 * s.n
+    assert rc.tile_cells == 1
