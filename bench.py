@@ -12,9 +12,10 @@ N = 1 : the headline config (BASELINE.json configs[2]): 100k mixed circle/rect/c
 N > 1 : weak scaling, one process per GPU: see `multi_gpu_workload`.
 
 The JSON line also carries
-  roofline     : the dominant kernel (k_solve_pos: fused narrowphase + XPBD block solve, one
-                 launch per colour), algorithmic bytes per launch / mean launch time from HIP
-                 events recorded by libsfx on its own stream, against the 8 TB/s HBM peak;
+  roofline     : the dominant kernel (k_tile_pos: narrowphase + XPBD manifold block solves of one
+                 phase of solver tiles, bodies in LDS), algorithmic bytes per launch / mean launch
+                 time from HIP events recorded by libsfx on its own stream, against the 8 TB/s
+                 HBM peak;
   cpu_baseline : this repository's single-threaded CPU restatement (oracle/, kind "port")
                  timed on this host on a bounded number of frames of the same settled scene.
                  It is NOT starframe's Rust tick, which was unavailable.
@@ -51,18 +52,12 @@ def settle(scene, device, frames=600, damping=3.3):
     return scene.with_state(pos, rot, name=scene.name + "_settled")
 
 
-def solve_pos_bytes(st, launch_colors):
-    """Algorithmic (compulsory) bytes of the k_solve_pos launches of ONE substep.
-    DESIGN.md "Roofline accounting": per candidate pair 8 B pair + 2 x (16 B pose + 16 B shape)
-    read + 8 B count written; per touching pair additionally 2 x (8 B mass + 16 B velocity)
-    read, 48 B record + 2 x 16 B pose written; 16 B more for a second contact point."""
-    counts = list(st.color_count)
-    in_launch = sum(counts[:launch_colors])
-    frac = in_launch / max(st.n_pairs, 1)
-    pairs = in_launch
-    manifolds = st.n_manifolds * frac
-    manifolds2 = st.n_manifolds2 * frac
-    return pairs * 80.0 + manifolds * 128.0 + manifolds2 * 16.0
+def solve_pos_bytes(st):
+    """Algorithmic (compulsory) bytes of the four k_tile_pos launches of ONE substep.
+    DESIGN.md "Kernels": per candidate pair 16 B pair record + 2 x (16 B pose + 16 B shape) read
+    + 8 B count written; per touching pair additionally 2 x (8 B mass + 16 B velocity) read,
+    48 B record + 16 B lambdas + 2 x 16 B pose written; 16 B more for a second contact point."""
+    return st.n_pairs * 88.0 + st.n_manifolds * 144.0 + st.n_manifolds2 * 16.0
 
 
 def tick_bytes_per_body_substep(st, n_dyn, substeps):
@@ -70,8 +65,8 @@ def tick_bytes_per_body_substep(st, n_dyn, substeps):
     p, m, m2 = st.n_pairs / n_dyn, st.n_manifolds / n_dyn, st.n_manifolds2 / n_dyn
     integrate = 16 + 16 + 8 + 16 + 16 + 16          # pose, vel, mass read; prev, pose, vel written
     derive = 16 + 16 + 8 + 16
-    pos = p * 80 + m * 128 + m2 * 16
-    vel = p * 16 + m * (64 + 2 * (16 + 16 + 8) + 2 * 16) + m2 * 16
+    pos = p * 88 + m * 144 + m2 * 16
+    vel = p * (16 + 8) + m * (64 + 2 * (16 + 16 + 8) + 2 * 16) + m2 * 16
     broad = (16 + 16 + 16 + 16 + 4 + 8 + 4 + 4 + 28 + 16 * 5 + p * (8 + 8 + 2 + 16)) / substeps
     return integrate + derive + pos + vel + broad
 
@@ -177,7 +172,7 @@ def main():
     sp = kt["solve_pos"]
     launches_per_substep = sp["launches"] / (prof_frames * scene.substeps)
     dur_s = 1e-3 * sp["total_ms"] / max(sp["launches"], 1)
-    bytes_per_launch = solve_pos_bytes(st2, int(round(launches_per_substep))) / max(launches_per_substep, 1)
+    bytes_per_launch = solve_pos_bytes(st2) / max(launches_per_substep, 1)
     achieved = bytes_per_launch / dur_s / 1e9
     kernel_ms = {k: round(v["total_ms"] / prof_frames, 4) for k, v in kt.items() if v["launches"]}
     value = world * n_dyn * scene.substeps * args.steps / elapsed
@@ -205,11 +200,14 @@ def main():
             "pairs": st.n_pairs,
             "manifolds": st.n_manifolds,
             "colors": st.n_colors,
+            "tiles": st.n_tiles,
+            "fallback_pairs": st.n_fallback,
             "launches_per_step": st.launches,
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_solve_pos (fused narrowphase + XPBD manifold block solve, one launch per colour)",
+            "kernel": "k_tile_pos (narrowphase + XPBD manifold block solves of one tile phase, bodies in LDS; "
+                      "4 launches per substep)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -22,4 +22,4 @@ lib.sfx_debug_tile_timing(w.handle, out, 1)
 o = list(out)
 tiles = max(o[4], 1)
 print("per tile (us): load %.2f narrow %.2f colours %.2f total %.2f  tiles/launch %.0f  mean colours %.2f" % (
-    o[0] / tiles / 100, o[1] / tiles / 100, o[2] / tiles / 100, o[3] / tiles / 100, tiles / 160, o[5] / tiles))
+    o[0] / tiles / 100, o[1] / tiles / 100, o[2] / tiles / 100, o[3] / tiles / 100, tiles / 160.0, o[5] / tiles))

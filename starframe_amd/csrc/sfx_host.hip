@@ -18,10 +18,6 @@
 
 using namespace sfx;
 
-#ifndef SFX_TILE_THREADS
-#define SFX_TILE_THREADS 128
-#endif
-constexpr int kTileThreads = SFX_TILE_THREADS;  // workgroup size of the tile solves = pairs on the register path
 
 namespace {
 
@@ -51,7 +47,7 @@ struct sfx_world {
     sfx_config cfg{};
     std::string err;
     hipStream_t stream = nullptr;
-    bool own_stream = true;
+    bool own_stream = true, group_fixed = false;
     int device = 0;
     // resolved
     float cell = 1.0f, inv_cell = 1.0f;
@@ -71,7 +67,8 @@ struct sfx_world {
     Counters* ctr = nullptr;
     uint32_t *cell_start = nullptr, *tile_cnt = nullptr, *tile_fill = nullptr, *tile_flag = nullptr;
     size_t zero_bytes = 0;
-    DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, scan_sums, active, big_tiles, tile_ncol;
+    DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, scan_sums, active, big_tiles;
+    DevBuf<BatchDesc> batches;
     DevBuf<int2> cellxy, sorted_cell;
     DevBuf<uint4> rawp, tpair;
     DevBuf<uint2> fpairs, fsorted;
@@ -99,7 +96,8 @@ struct sfx_world {
     bool ctr_pending = false, ctr_valid = false;
     Counters stale{};
     uint32_t launches = 0;
-    uint32_t color_grid = 512, big_grid = 64, tile_grid[4] = {1024, 1024, 1024, 1024}, tile_grid_max = 8192;
+    uint32_t color_grid = 1024, big_grid = 64, tile_grid[4] = {1024, 1024, 1024, 1024}, tile_grid_max = 8192;
+    uint32_t group = 4;  // tiles a colouring workgroup cuts into batches (from the pair density of an earlier tick)
     bool ticked = false;
     // profiling
     bool profiling = false;
@@ -294,7 +292,7 @@ uint32_t edge_grid(uint32_t cap) { return std::min(std::max(cdiv(cap, kBlock), 1
 TileArrays tile_arrays(sfx_world* w) {
     TileArrays T;
     T.cell_start = w->cell_start; T.sorted_id = w->sorted_id.p; T.tile_start = w->tile_cnt;
-    T.active = w->active.p; T.tpair = w->tpair.p; T.tile_ncol = w->tile_ncol.p; T.fsorted = w->fsorted.p;
+    T.active = w->active.p; T.big = w->big_tiles.p; T.batches = w->batches.p; T.tpair = w->tpair.p; T.fsorted = w->fsorted.p;
     T.max_pairs = w->max_pairs; T.fb_cap = w->fb_cap;
     T.dbg = w->dbg.p;
     return T;
@@ -350,13 +348,13 @@ int broadphase(sfx_world* w, float dt) {
       hipLaunchKernelGGL(k_pairs<true>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
                          w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
-      hipLaunchKernelGGL((k_tile_color<kSmallB, kSmallP, 128>), dim3(w->color_grid, 4), dim3(128), 0, w->stream, g,
+      hipLaunchKernelGGL((k_batch_color<kBatchP, false>), dim3(w->color_grid, 4), dim3(kBlock), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
-                         w->tile_ncol.p, w->max_pairs, w->cfg.color_rounds, w->ctr); }
+                         w->batches.p, w->max_pairs, w->cfg.color_rounds, w->ctr); }
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
-      hipLaunchKernelGGL((k_tile_color<kMaxB, kMaxP, 256>), dim3(w->big_grid, 1), dim3(256), 0, w->stream, g,
+      hipLaunchKernelGGL((k_batch_color<kMaxP, true>), dim3(w->big_grid, 1), dim3(kBlock), 0, w->stream, g, 1u,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->big_tiles.p, w->rawp.p, w->tpair.p,
-                         w->tile_ncol.p, w->max_pairs, w->cfg.color_rounds, w->ctr); }
+                         w->batches.p, w->max_pairs, w->cfg.color_rounds, w->ctr); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
     return SFX_OK;
@@ -368,13 +366,19 @@ void poll_counters(sfx_world* w) {
         w->stale = *w->h_ctr;
         w->ctr_valid = true;
         w->ctr_pending = false;
-        uint32_t tot = 0;
-        for (int ph = 0; ph < 4; ++ph) {
-            const uint32_t a = w->stale.n_active[ph];
-            w->tile_grid[ph] = std::min(std::max(a + a / 8u + 4u, 1u), w->tile_grid_max);
-            tot = std::max(tot, a);
+        // tiles per batch so that an average batch fills ~3/4 of the solve workgroup's pair slots
+        const uint32_t ntl = w->stale.n_active[0];
+        if (!w->group_fixed && ntl) {
+            const uint32_t per_tile = std::max(w->stale.n_tile_pairs / ntl, 1u);
+            w->group = std::min(std::max((3u * kBatchP / 4u) / per_tile, 1u), (uint32_t)kMaxGroup);
         }
-        w->color_grid = std::min(std::max(tot + tot / 8u + 4u, 1u), 8192u);
+        uint32_t groups = 0;
+        for (int ph = 0; ph < 4; ++ph) {
+            const uint32_t b = w->stale.n_batches[ph];
+            w->tile_grid[ph] = std::min(std::max(b + b / 8u + 4u, 1u), w->tile_grid_max);
+            groups = std::max(groups, cdiv(w->stale.n_listed[ph], w->group));
+        }
+        w->color_grid = std::min(std::max(groups + groups / 8u + 4u, 1u), 8192u);
         w->big_grid = std::min(std::max(w->stale.n_big + w->stale.n_big / 8u + 4u, 1u), 1024u);
     }
 }
@@ -428,6 +432,10 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
     w->device = cfg->device;
     // SFX_NULL_STREAM=1 runs the world on the device's default stream (profilers that cannot
     // follow a second queue)
+    if (const char* gr = getenv("SFX_GROUP")) {  // tuning knob: tiles per colouring group
+        w->group = std::min(std::max(1, atoi(gr)), kMaxGroup);
+        w->group_fixed = true;
+    }
     if (const char* gm = getenv("SFX_TILE_GRID_MAX")) {  // tuning knob: cap on the workgroups of a tile-solve launch
         w->tile_grid_max = std::max(1, atoi(gm));
         for (auto& tg : w->tile_grid) tg = std::min(tg, w->tile_grid_max);
@@ -462,7 +470,7 @@ void sfx_destroy(sfx_world* w) {
     w->pose.release(); w->prev.release(); w->vel.release(); w->shape.release(); w->poly.release();
     w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release();
     w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
-    w->active.release(); w->big_tiles.release(); w->tile_ncol.release(); w->rawp.release(); w->tpair.release();
+    w->active.release(); w->big_tiles.release(); w->batches.release(); w->rawp.release(); w->tpair.release();
     w->fpairs.release(); w->fsorted.release();
     w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->scan_sums.release();
     w->cellxy.release(); w->sorted_cell.release();
@@ -605,7 +613,7 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     w->tile_fill = w->tile_cnt + ((size_t)w->ntiles + 1 + pad);
     w->tile_flag = w->tile_fill + w->ntiles;
     ALLOC(w, w->cell_fill, (size_t)w->ncell + 1 + pad);
-    ALLOC(w, w->active, w->ntiles); ALLOC(w, w->big_tiles, w->ntiles); ALLOC(w, w->tile_ncol, w->ntiles);
+    ALLOC(w, w->active, w->ntiles); ALLOC(w, w->big_tiles, w->ntiles); ALLOC(w, w->batches, w->ntiles);
     ALLOC(w, w->rawp, w->max_pairs); ALLOC(w, w->tpair, w->max_pairs);
     ALLOC(w, w->fpairs, w->fb_cap); ALLOC(w, w->fsorted, w->fb_cap);
     const size_t mc = std::max<size_t>(w->fb_cap, w->m);
@@ -821,13 +829,9 @@ static int fetch_pairs(sfx_world* w, std::vector<HostPair>& out, Counters& c) {
     out.clear();
     const uint32_t ntp = c.n_tile_pairs, nfb = c.n_fb;
     std::vector<uint4> tp(ntp);
-    std::vector<uint32_t> ts(w->ntiles + 1);
     if (ntp) HIPCHK(w, hipMemcpy(tp.data(), w->tpair.p, sizeof(uint4) * ntp, hipMemcpyDeviceToHost));
-    HIPCHK(w, hipMemcpy(ts.data(), w->tile_cnt, sizeof(uint32_t) * (w->ntiles + 1), hipMemcpyDeviceToHost));
     out.reserve((size_t)ntp + nfb);
-    for (uint32_t t = 0; t < w->ntiles; ++t)
-        for (uint32_t k = std::min(ts[t], ntp); k < std::min(ts[t + 1], ntp); ++k)
-            out.push_back({tp[k].x, tp[k].y, t, (uint8_t)std::min(tp[k].w, 255u)});
+    for (uint32_t k = 0; k < ntp; ++k) out.push_back({tp[k].x, tp[k].y, tp[k].w >> 8, (uint8_t)(tp[k].w & 0xFFu)});
     if (nfb) {
         // the raw list holds every fallback pair; colours come from the colour-major copy
         std::vector<uint2> fp(nfb), fs(c.fb_start[SFX_MAX_COLORS]);
@@ -936,7 +940,7 @@ int sfx_stats(sfx_world* w, sfx_frame_stats* out) {
     w->launches = saved;
     out->n_small = c.n_small; out->n_large = c.n_large; out->n_pairs = c.n_pairs; out->n_colors = c.n_colors;
     out->n_leftover = c.n_leftover; out->overflow = c.overflow;
-    out->n_tiles = c.n_active[0] + c.n_active[1] + c.n_active[2] + c.n_active[3];
+    out->n_tiles = c.n_active[0];
     out->n_fallback = c.n_fb; out->max_tile_pairs = c.max_tile_pairs; out->max_tile_bodies = c.max_tile_bodies;
     out->n_contacts = s.n_contacts;
     out->n_manifolds = s.n_manifolds;

@@ -21,8 +21,13 @@ namespace sfx {
 constexpr int kBlock = 256;
 constexpr uint32_t kMaxP = SFX_TILE_MAX_PAIRS;      // pairs a tile may own
 constexpr uint32_t kMaxB = SFX_TILE_MAX_BODIES;     // grid-sorted colliders in a 2x2 tile block
-constexpr uint32_t kSmallB = 128, kSmallP = 256;    // tiles up to this size are coloured by the small-LDS kernel
 constexpr int kClaim = 4;                           // claim slots per body in the colouring
+#ifndef SFX_TILE_THREADS
+#define SFX_TILE_THREADS 256
+#endif
+constexpr int kTileThreads = SFX_TILE_THREADS;      // workgroup of the tile solves = pairs on the register path
+constexpr uint32_t kBatchP = kTileThreads;          // pairs of a batch of tiles (one bigger tile is a batch of its own)
+constexpr int kMaxGroup = 16;                       // tiles per batch at most
 constexpr uint32_t kExt = 0xFFFFu;                  // local index of a body outside the block (large static)
 constexpr int kScanItems = 16;                      // items per thread in the block scan
 constexpr int kScanTile = kBlock * kScanItems;      // 4096 items per block
@@ -45,14 +50,18 @@ struct Counters {
     uint32_t n_fb_colors;
     uint32_t n_tile_pairs;  // pairs owned by tiles (clamped to max_pairs)
     uint32_t max_tile_pairs, max_tile_bodies;
-    uint32_t n_active[4];   // tiles that own pairs, per phase
+    uint32_t n_active[4];   // [0]: tiles that own pairs (statistic), rest unused
     uint32_t ticket;        // last-workgroup detection of the phase-3 kernels
     uint32_t n_over_tiles;  // tiles that handed their pairs to the fallback list
-    uint32_t n_big;         // active tiles beyond the small colouring kernel's capacity
-    uint32_t pad[1];
+    uint32_t n_big;         // tiles with more than kBatchP pairs: batches of their own
+    uint32_t tp_cursor;     // pairs written to the batch-ordered pair list
+    uint32_t n_batches[4];  // batches per phase
+    uint32_t n_listed[4];   // tiles on the per-phase lists (all but the big ones)
     uint32_t color_count[SFX_MAX_COLORS];
     uint32_t fb_start[SFX_MAX_COLORS + 1];  // colour-major offsets into the sorted fallback list
+    uint32_t pad3[3];
 };
+static_assert(sizeof(Counters) % 16 == 0, "the per-tick block is cleared in 16-byte units");
 
 struct GridParams {
     float inv_cell;
@@ -479,30 +488,55 @@ __device__ __forceinline__ uint32_t block_slot(const BlockRanges& R, uint32_t l)
 }
 
 // One thread per tile, after the count pass: tiles over capacity are flagged (their pair count
-// is zeroed so that the scan skips them), the others are listed per phase.
+// is zeroed so that the scan skips them); tiles with more pairs than a batch holds are listed as
+// "big" (each is a batch of its own), the others per phase.
 __global__ __launch_bounds__(kBlock) void k_tile_list(GridParams g, const uint32_t* __restrict__ cell_start,
                                                        uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_flag,
                                                        uint32_t* __restrict__ active, uint32_t* __restrict__ big,
                                                        Counters* __restrict__ ctr) {
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
-    if (t >= g.ntiles) return;
-    const uint32_t cnt = tile_cnt[t];
-    if (!cnt) return;
-    BlockRanges R;
-    block_ranges(t, g, cell_start, R);
-    if (cnt > kMaxP || R.off[4] > kMaxB) {
-        tile_flag[t] = 1u;
-        tile_cnt[t] = 0u;
-        atomicAdd(&ctr->n_over_tiles, 1u);
-        return;
+    const uint32_t cnt = t < g.ntiles ? tile_cnt[t] : 0u;
+    // 0..3: listed under that phase, 4: big, 5: over capacity, 6: nothing to do
+    uint32_t kind = 6u, nb = 0u;
+    if (cnt) {
+        BlockRanges R;
+        block_ranges(t, g, cell_start, R);
+        nb = R.off[4];
+        const uint32_t lx = g.gxl - g.tl;
+        if (cnt > kMaxP || nb > kMaxB) kind = 5u;
+        else if (cnt > kBatchP) kind = 4u;
+        else kind = (t & 1u) | (((t >> lx) & 1u) << 1);
     }
-    const uint32_t lx = g.gxl - g.tl;
-    const uint32_t ph = (t & 1u) | (((t >> lx) & 1u) << 1);
-    const uint32_t k = atomicAdd(&ctr->n_active[ph], 1u);
-    active[ph * (g.ntiles >> 2) + k] = t;
-    if (cnt > kSmallP || R.off[4] > kSmallB) big[atomicAdd(&ctr->n_big, 1u)] = t;
-    atomicMax(&ctr->max_tile_pairs, cnt);
-    atomicMax(&ctr->max_tile_bodies, R.off[4]);
+    if (!__any(kind != 6u)) return;
+    // one atomic per wave and list: the lanes of a kind take consecutive entries
+    const int lane = threadIdx.x & 63;
+    const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+    for (uint32_t k = 0; k < 6; ++k) {
+        const uint64_t bal = __ballot(kind == k);
+        if (!bal) continue;
+        uint32_t base = 0;
+        const int leader = __builtin_ctzll(bal);
+        if (lane == leader) {
+            const uint32_t c = (uint32_t)__popcll(bal);
+            base = atomicAdd(k < 4 ? &ctr->n_listed[k] : k == 4 ? &ctr->n_big : &ctr->n_over_tiles, c);
+        }
+        base = __shfl(base, leader, 64);
+        if (kind == k) {
+            const uint32_t idx = base + (uint32_t)__popcll(bal & below);
+            if (k < 4) active[k * (g.ntiles >> 2) + idx] = t;
+            else if (k == 4) big[idx] = t;
+            else { tile_flag[t] = 1u; tile_cnt[t] = 0u; }
+        }
+    }
+    // statistics: wave maxima, one atomic each
+    uint32_t mp = (kind < 5u) ? cnt : 0u, mb = (kind < 5u) ? nb : 0u;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        mp = max(mp, (uint32_t)__shfl_xor((int)mp, off, 64));
+        mb = max(mb, (uint32_t)__shfl_xor((int)mb, off, 64));
+    }
+    if (lane == 0 && mp) { atomicMax(&ctr->max_tile_pairs, mp); atomicMax(&ctr->max_tile_bodies, mb); }
 }
 
 // pair range of tile t after the scan, clamped to the pair capacity
@@ -512,168 +546,278 @@ __device__ __forceinline__ void tile_pair_range(uint32_t t, const uint32_t* __re
     start = s; np = e - s;
 }
 
-// Edge colouring of every active tile's pair graph, one workgroup per tile, all state in LDS
-// (DESIGN.md "Contract / colouring").  Writes the tile's pairs colour-major as
-// (id a, id b, local a | local b << 16, colour | ext << 8) and the tile's colour count.
-// Two instances: <kSmallB, kSmallP> walks the per-phase tile lists (blockIdx.y = phase) and skips
-// the few tiles beyond its LDS arrays; <kMaxB, kMaxP> walks the list of exactly those tiles.
-template <uint32_t MB, uint32_t MP, int NTC>
-__global__ __launch_bounds__(NTC) void k_tile_color(GridParams g, const uint32_t* __restrict__ cell_start,
-                                                     const uint32_t* __restrict__ sorted_id,
-                                                     const uint4* __restrict__ filt,
-                                                     const uint32_t* __restrict__ tile_start,
-                                                     const uint32_t* __restrict__ list, const uint4* __restrict__ rawp,
-                                                     uint4* __restrict__ tpair, uint32_t* __restrict__ tile_ncol,
-                                                     uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr) {
-    constexpr bool kBig = MB > kSmallB;
-    constexpr uint32_t kBlock = NTC;  // shadows the file-level constant inside this kernel
+// A batch: up to kMaxGroup tiles of one phase solved together by one workgroup (their blocks
+// are disjoint, so they do not interact; each tile is still coloured on its own, the batch only
+// runs colour c of all its tiles in the same step).  Batching is scheduling only: results do
+// not depend on which tiles share a batch.
+struct BatchDesc {
+    uint32_t first;    // index of the first tile on the phase's list (bit 31: on the big list)
+    uint32_t count;    // tiles
+    uint32_t bstart;   // first pair in tpair / first record slot
+    uint32_t np;       // pairs
+    uint32_t ncol;     // most colours of any of its tiles
+    uint32_t nb;       // bodies of all its blocks
+    uint32_t pad[2];
+};
+
+// body ranges of a batch in LDS: range r = 4 * (tile in batch) + (block tile 0..3)
+struct BatchRanges {
+    uint32_t rs[4 * kMaxGroup];       // first slot
+    uint32_t off[4 * kMaxGroup + 1];  // local index of the range's first body
+};
+
+// all threads of the workgroup; tiles = the batch's tile ids (global memory)
+__device__ __forceinline__ void batch_ranges(const uint32_t* __restrict__ tiles, uint32_t count, const GridParams& g,
+                                             const uint32_t* __restrict__ cell_start, BatchRanges& S) {
+    __syncthreads();
+    if (threadIdx.x < 4u * count) {
+        const uint32_t t = tiles[threadIdx.x >> 2], k = threadIdx.x & 3u;
+        const uint32_t lx = g.gxl - g.tl;
+        const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
+        const uint32_t tk = tile_of(tx + (int32_t)(k & 1u), ty + (int32_t)(k >> 1), g);
+        const uint32_t a = cell_start[tk << (2u * g.tl)], b = cell_start[(tk + 1u) << (2u * g.tl)];
+        S.rs[threadIdx.x] = a;
+        S.off[threadIdx.x + 1] = b - a;  // lengths first, prefix below
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        S.off[0] = 0;
+        for (uint32_t r = 0; r < 4u * count; ++r) { const uint32_t len = S.off[r + 1]; S.off[r + 1] = run + len; run += len; }
+    }
+    __syncthreads();
+}
+
+// slot of local body l (binary search over the range offsets)
+__device__ __forceinline__ uint32_t batch_slot(const BatchRanges& S, uint32_t nr, uint32_t l) {
+    uint32_t lo = 0, hi = nr;  // largest r with off[r] <= l
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (S.off[mid] <= l) lo = mid; else hi = mid;
+    }
+    return S.rs[lo] + (l - S.off[lo]);
+}
+
+// local index of a slot known to belong to tile j of the batch (kExt when outside its block)
+__device__ __forceinline__ uint32_t batch_local(const BatchRanges& S, uint32_t j, uint32_t slot) {
+    uint32_t l = kExt;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        const uint32_t r = 4u * j + k, len = S.off[r + 1] - S.off[r];
+        if (slot >= S.rs[r] && slot - S.rs[r] < len) l = S.off[r] + (slot - S.rs[r]);
+    }
+    return l;
+}
+
+// Forms the batches and edge-colours every tile's pair graph, all state in LDS (DESIGN.md
+// "Contract / colouring").  A workgroup takes `group` consecutive tiles of a phase's list and
+// cuts them greedily into batches of at most kBatchP pairs and kMaxB bodies (BIG: one tile of
+// the big list per batch, up to kMaxP pairs).  Per batch it writes the pairs colour-major as
+// (id a, id b, local a | local b << 16, colour | tile << 8) and a BatchDesc on the phase's table.
+template <uint32_t MP, bool BIG>
+__global__ __launch_bounds__(kBlock) void k_batch_color(GridParams g, uint32_t group, const uint32_t* __restrict__ cell_start,
+                                                         const uint32_t* __restrict__ sorted_id,
+                                                         const uint4* __restrict__ filt,
+                                                         const uint32_t* __restrict__ tile_start,
+                                                         const uint32_t* __restrict__ list, const uint4* __restrict__ rawp,
+                                                         uint4* __restrict__ tpair, BatchDesc* __restrict__ batches,
+                                                         uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr) {
+    constexpr uint32_t MB = kMaxB;
     __shared__ unsigned long long s_used[MB];
     __shared__ unsigned long long s_claim[MB * kClaim];
     __shared__ uint32_t s_deg[MB];
     __shared__ uint8_t s_dyn[MB];
     __shared__ uint32_t s_a[MP], s_b[MP];
     __shared__ uint16_t s_la[MP], s_lb[MP], s_left[MP], s_srt[MP];
-    __shared__ uint8_t s_col[MP], s_prop[MP];
+    __shared__ uint8_t s_col[MP], s_prop[MP], s_tj[MP];
     __shared__ uint32_t s_hist[SFX_MAX_COLORS], s_base[SFX_MAX_COLORS];
-    __shared__ uint32_t s_nleft, s_ovf;
-    const uint32_t ph = blockIdx.y;
-    const uint32_t nact = kBig ? ctr->n_big : ctr->n_active[ph];
+    __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat;
+    __shared__ BatchRanges S;
+    __shared__ uint32_t s_tile[kMaxGroup], s_tnb[kMaxGroup], s_tnp[kMaxGroup], s_tstart[kMaxGroup];
+    __shared__ uint32_t s_bfirst[kMaxGroup + 1], s_poff[kMaxGroup + 1];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t it = blockIdx.x; it < nact; it += gridDim.x) {
-        const uint32_t t = kBig ? list[it] : list[ph * (g.ntiles >> 2) + it];
-        BlockRanges R;
-        block_ranges(t, g, cell_start, R);
-        uint32_t start, np;
-        tile_pair_range(t, tile_start, max_pairs, start, np);
-        if (!kBig && (np > kSmallP || R.off[4] > kSmallB)) continue;  // the big instance takes it
-        const uint32_t nb = min(R.off[4], MB);
-        np = min(np, MP);
-        for (uint32_t l = tid; l < nb; l += kBlock) {
-            const uint32_t gid = sorted_id[block_slot(R, l)];
-            s_dyn[l] = (uint8_t)(filt[gid].w != 0u);
-            s_used[l] = 0ull;
-            s_deg[l] = 0u;
+    const uint32_t ph_list = BIG ? 0u : blockIdx.y;
+    const uint32_t nlist = BIG ? ctr->n_big : ctr->n_listed[ph_list];
+    const uint32_t* lst = BIG ? list : list + ph_list * (g.ntiles >> 2);
+    if (BIG) group = 1u;
+    group = min(max(group, 1u), (uint32_t)kMaxGroup);
+    const uint32_t ngroups = (nlist + group - 1u) / group;
+    for (uint32_t gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
+        const uint32_t e0 = gi * group, cnt = min(group, nlist - e0);
+        __syncthreads();
+        if (tid < cnt) {
+            const uint32_t t = lst[e0 + tid];
+            BlockRanges R;
+            block_ranges(t, g, cell_start, R);
+            uint32_t start, np;
+            tile_pair_range(t, tile_start, max_pairs, start, np);
+            s_tile[tid] = t; s_tnb[tid] = min(R.off[4], kMaxB); s_tnp[tid] = min(np, MP); s_tstart[tid] = start;
+        }
+        __syncthreads();
+        if (tid == 0) {  // greedy cut into batches
+            uint32_t nbat = 0, nb = 0, np = 0;
+            s_bfirst[0] = 0;
+            for (uint32_t j = 0; j < cnt; ++j) {
+                if (j > s_bfirst[nbat] && (nb + s_tnb[j] > kMaxB || np + s_tnp[j] > (BIG ? MP : kBatchP))) {
+                    s_bfirst[++nbat] = j; nb = 0; np = 0;
+                }
+                nb += s_tnb[j]; np += s_tnp[j];
+            }
+            s_bfirst[nbat + 1] = cnt;
+            s_nbat = nbat + 1;
+        }
+        __syncthreads();
+        const uint32_t nbat = s_nbat;
+        for (uint32_t bi = 0; bi < nbat; ++bi) {
+            const uint32_t f = s_bfirst[bi], c = s_bfirst[bi + 1] - f;
+            batch_ranges(lst + e0 + f, c, g, cell_start, S);
+            if (tid == 0) {
+                uint32_t run = 0;
+                for (uint32_t j = 0; j < c; ++j) { s_poff[j] = run; run += s_tnp[f + j]; }
+                s_poff[c] = run;
+                s_nleft = 0u; s_ovf = 0u;
+            }
+            if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
+            __syncthreads();
+            const uint32_t nb = min(S.off[4u * c], MB), np = min(s_poff[c], MP);
+            for (uint32_t l = tid; l < nb; l += kBlock) {
+                const uint32_t gid = sorted_id[batch_slot(S, 4u * c, l)];
+                s_dyn[l] = (uint8_t)(filt[gid].w != 0u);
+                s_used[l] = 0ull;
+                s_deg[l] = 0u;
 #pragma unroll
-            for (int k = 0; k < kClaim; ++k) s_claim[l * kClaim + k] = ~0ull;
-        }
-        if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
-        if (tid == 0) { s_nleft = 0u; s_ovf = 0u; }
-        for (uint32_t e = tid; e < np; e += kBlock) {
-            const uint4 rp = rawp[start + e];
-            s_a[e] = rp.x; s_b[e] = rp.y;
-            s_la[e] = (uint16_t)block_local(R, rp.z);
-            s_lb[e] = (uint16_t)block_local(R, rp.w);
-            s_col[e] = SFX_NO_COLOR;
-        }
-        __syncthreads();
-#define TDYN(l) ((l) != kExt && s_dyn[(l)])
-        for (uint32_t e = tid; e < np; e += kBlock) {
-            const uint32_t la = s_la[e], lb = s_lb[e];
-            if (TDYN(la)) atomicAdd(&s_deg[la], 1u);
-            if (TDYN(lb)) atomicAdd(&s_deg[lb], 1u);
-        }
-        __syncthreads();
-        for (uint32_t r = 0; r < rounds; ++r) {
-            int open_edges = 0;
-            for (uint32_t e = tid; e < np; e += kBlock) open_edges |= (s_col[e] == SFX_NO_COLOR) ? 1 : 0;
-            if (!__syncthreads_or(open_edges)) break;  // everything coloured: later rounds would do nothing
-            for (uint32_t e = tid; e < np; e += kBlock) {  // propose
-                if (s_col[e] != SFX_NO_COLOR) continue;
-                const uint32_t la = s_la[e], lb = s_lb[e];
-                const bool da = TDYN(la), db = TDYN(lb);
-                const unsigned long long freem = ~((da ? s_used[la] : 0ull) | (db ? s_used[lb] : 0ull));
-                if (freem == 0ull) { s_prop[e] = SFX_NO_COLOR; s_ovf = 1u; continue; }
-                uint32_t dg = 1;
-                if (da) dg = max(dg, s_deg[la]);
-                if (db) dg = max(dg, s_deg[lb]);
-                dg = min(dg, 8u);
-                dg = min(dg, (uint32_t)__popcll(freem));
-                const uint32_t h = edge_hash(s_a[e], s_b[e], r);
-                const uint32_t k = mix32(h ^ 0xA5A5A5A5u) % dg;
-                const uint32_t c = kth_set_bit(freem, k);
-                s_prop[e] = (uint8_t)c;
-                const unsigned long long p = edge_prio(s_a[e], s_b[e], r, h);
-                if (da) atomicMin(&s_claim[la * kClaim + (c & (kClaim - 1u))], p);
-                if (db) atomicMin(&s_claim[lb * kClaim + (c & (kClaim - 1u))], p);
+                for (int k = 0; k < kClaim; ++k) s_claim[l * kClaim + k] = ~0ull;
+            }
+            for (uint32_t e = tid; e < np; e += kBlock) {
+                uint32_t j = 0;
+                while (j + 1 < c && s_poff[j + 1] <= e) ++j;
+                const uint4 rp = rawp[s_tstart[f + j] + (e - s_poff[j])];
+                s_a[e] = rp.x; s_b[e] = rp.y;
+                s_la[e] = (uint16_t)batch_local(S, j, rp.z);
+                s_lb[e] = (uint16_t)batch_local(S, j, rp.w);
+                s_tj[e] = (uint8_t)j;
+                s_col[e] = SFX_NO_COLOR;
             }
             __syncthreads();
-            for (uint32_t e = tid; e < np; e += kBlock) {  // resolve
-                if (s_col[e] != SFX_NO_COLOR) continue;
-                const uint32_t c = s_prop[e];
-                if (c == SFX_NO_COLOR) continue;
+#define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
+            for (uint32_t e = tid; e < np; e += kBlock) {
                 const uint32_t la = s_la[e], lb = s_lb[e];
-                const bool da = TDYN(la), db = TDYN(lb);
-                const uint32_t h = edge_hash(s_a[e], s_b[e], r);
-                const unsigned long long p = edge_prio(s_a[e], s_b[e], r, h);
-                const bool win = (!da || s_claim[la * kClaim + (c & (kClaim - 1u))] == p) && (!db || s_claim[lb * kClaim + (c & (kClaim - 1u))] == p);
-                if (win) {
-                    s_col[e] = (uint8_t)c;
-                    if (da) { atomicOr(&s_used[la], 1ull << c); atomicSub(&s_deg[la], 1u); }
-                    if (db) { atomicOr(&s_used[lb], 1ull << c); atomicSub(&s_deg[lb], 1u); }
-                }
+                if (TDYN(la)) atomicAdd(&s_deg[la], 1u);
+                if (TDYN(lb)) atomicAdd(&s_deg[lb], 1u);
             }
             __syncthreads();
-        }
-        // serial first-fit finish over the leftovers, ascending key
-        for (uint32_t e = tid; e < np; e += kBlock)
-            if (s_col[e] == SFX_NO_COLOR) s_left[atomicAdd(&s_nleft, 1u)] = (uint16_t)e;
-        __syncthreads();
-        const uint32_t nleft = s_nleft;
-        if (nleft) {
-            for (uint32_t q = tid; q < nleft; q += kBlock) {
-                const uint32_t e = s_left[q];
-                const unsigned long long key = ((unsigned long long)s_a[e] << 24) | s_b[e];
-                uint32_t rank = 0;
-                for (uint32_t q2 = 0; q2 < nleft; ++q2) {
-                    const uint32_t e2 = s_left[q2];
-                    rank += ((((unsigned long long)s_a[e2] << 24) | s_b[e2]) < key) ? 1u : 0u;
+            for (uint32_t r = 0; r < rounds; ++r) {
+                int open_edges = 0;
+                for (uint32_t e = tid; e < np; e += kBlock) open_edges |= (s_col[e] == SFX_NO_COLOR) ? 1 : 0;
+                if (!__syncthreads_or(open_edges)) break;  // everything coloured: later rounds would do nothing
+                for (uint32_t e = tid; e < np; e += kBlock) {  // propose
+                    if (s_col[e] != SFX_NO_COLOR) continue;
+                    const uint32_t la = s_la[e], lb = s_lb[e];
+                    const bool da = TDYN(la), db = TDYN(lb);
+                    const unsigned long long freem = ~((da ? s_used[la] : 0ull) | (db ? s_used[lb] : 0ull));
+                    if (freem == 0ull) { s_prop[e] = SFX_NO_COLOR; s_ovf = 1u; continue; }
+                    uint32_t dg = 1;
+                    if (da) dg = max(dg, s_deg[la]);
+                    if (db) dg = max(dg, s_deg[lb]);
+                    dg = min(dg, 8u);
+                    dg = min(dg, (uint32_t)__popcll(freem));
+                    const uint32_t h = edge_hash(s_a[e], s_b[e], r);
+                    const uint32_t k = mix32(h ^ 0xA5A5A5A5u) % dg;
+                    const uint32_t cc = kth_set_bit(freem, k);
+                    s_prop[e] = (uint8_t)cc;
+                    const unsigned long long p = edge_prio(s_a[e], s_b[e], r, h);
+                    if (da) atomicMin(&s_claim[la * kClaim + (cc & (kClaim - 1u))], p);
+                    if (db) atomicMin(&s_claim[lb * kClaim + (cc & (kClaim - 1u))], p);
                 }
-                s_srt[rank] = (uint16_t)e;
+                __syncthreads();
+                for (uint32_t e = tid; e < np; e += kBlock) {  // resolve
+                    if (s_col[e] != SFX_NO_COLOR) continue;
+                    const uint32_t cc = s_prop[e];
+                    if (cc == SFX_NO_COLOR) continue;
+                    const uint32_t la = s_la[e], lb = s_lb[e];
+                    const bool da = TDYN(la), db = TDYN(lb);
+                    const uint32_t h = edge_hash(s_a[e], s_b[e], r);
+                    const unsigned long long p = edge_prio(s_a[e], s_b[e], r, h);
+                    const bool win = (!da || s_claim[la * kClaim + (cc & (kClaim - 1u))] == p) &&
+                                     (!db || s_claim[lb * kClaim + (cc & (kClaim - 1u))] == p);
+                    if (win) {
+                        s_col[e] = (uint8_t)cc;
+                        if (da) { atomicOr(&s_used[la], 1ull << cc); atomicSub(&s_deg[la], 1u); }
+                        if (db) { atomicOr(&s_used[lb], 1ull << cc); atomicSub(&s_deg[lb], 1u); }
+                    }
+                }
+                __syncthreads();
+            }
+            // serial first-fit finish over the leftovers, ascending key
+            for (uint32_t e = tid; e < np; e += kBlock)
+                if (s_col[e] == SFX_NO_COLOR) s_left[atomicAdd(&s_nleft, 1u)] = (uint16_t)e;
+            __syncthreads();
+            const uint32_t nleft = s_nleft;
+            if (nleft) {
+                for (uint32_t q = tid; q < nleft; q += kBlock) {
+                    const uint32_t e = s_left[q];
+                    const unsigned long long key = ((unsigned long long)s_a[e] << 24) | s_b[e];
+                    uint32_t rank = 0;
+                    for (uint32_t q2 = 0; q2 < nleft; ++q2) {
+                        const uint32_t e2 = s_left[q2];
+                        rank += ((((unsigned long long)s_a[e2] << 24) | s_b[e2]) < key) ? 1u : 0u;
+                    }
+                    s_srt[rank] = (uint16_t)e;
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    for (uint32_t q = 0; q < nleft; ++q) {
+                        const uint32_t e = s_srt[q], la = s_la[e], lb = s_lb[e];
+                        const bool da = TDYN(la), db = TDYN(lb);
+                        const unsigned long long freem = ~((da ? s_used[la] : 0ull) | (db ? s_used[lb] : 0ull));
+                        if (freem == 0ull) { s_ovf = 1u; continue; }  // stays uncoloured: dropped from the solve
+                        const uint32_t cc = (uint32_t)__builtin_ctzll(freem);
+                        s_col[e] = (uint8_t)cc;
+                        if (da) s_used[la] |= 1ull << cc;
+                        if (db) s_used[lb] |= 1ull << cc;
+                    }
+                    atomicAdd(&ctr->n_leftover, nleft);
+                }
+                __syncthreads();
+            }
+#undef TDYN
+            // colour-major order inside the batch (uncoloured pairs last)
+            for (uint32_t e = tid; e < np; e += kBlock) {
+                const uint32_t cc = s_col[e];
+                if (cc < SFX_MAX_COLORS) atomicAdd(&s_hist[cc], 1u);
             }
             __syncthreads();
             if (tid == 0) {
-                for (uint32_t q = 0; q < nleft; ++q) {
-                    const uint32_t e = s_srt[q], la = s_la[e], lb = s_lb[e];
-                    const bool da = TDYN(la), db = TDYN(lb);
-                    const unsigned long long freem = ~((da ? s_used[la] : 0ull) | (db ? s_used[lb] : 0ull));
-                    if (freem == 0ull) { s_ovf = 1u; continue; }  // stays uncoloured: dropped from the solve
-                    const uint32_t c = (uint32_t)__builtin_ctzll(freem);
-                    s_col[e] = (uint8_t)c;
-                    if (da) s_used[la] |= 1ull << c;
-                    if (db) s_used[lb] |= 1ull << c;
+                uint32_t run = 0, nc = 0;
+                for (uint32_t cc = 0; cc < SFX_MAX_COLORS; ++cc) {
+                    s_base[cc] = run;
+                    if (s_hist[cc]) nc = cc + 1;
+                    run += s_hist[cc];
                 }
-                atomicAdd(&ctr->n_leftover, nleft);
+                s_nleft = run;  // reused: cursor of the uncoloured tail
+                const uint32_t bstart = atomicAdd(&ctr->tp_cursor, np);
+                s_bstart = bstart;
+                const uint32_t t0 = s_tile[f];
+                const uint32_t lx = g.gxl - g.tl;
+                const uint32_t ph = (t0 & 1u) | (((t0 >> lx) & 1u) << 1);
+                BatchDesc d;
+                d.first = BIG ? ((e0 + f) | 0x80000000u) : (e0 + f);
+                d.count = c; d.bstart = bstart; d.np = np; d.ncol = nc; d.nb = nb; d.pad[0] = d.pad[1] = 0u;
+                batches[ph * (g.ntiles >> 2) + atomicAdd(&ctr->n_batches[ph], 1u)] = d;
+                atomicMax(&ctr->n_colors, nc);
+                if (s_ovf) atomicOr(&ctr->overflow, kOvfColors);
+            }
+            if (tid < SFX_MAX_COLORS && s_hist[tid]) atomicAdd(&ctr->color_count[tid], s_hist[tid]);
+            __syncthreads();
+            const uint32_t bstart = s_bstart;
+            for (uint32_t e = tid; e < np; e += kBlock) {
+                const uint32_t cc = s_col[e];
+                const uint32_t dst = (cc < SFX_MAX_COLORS) ? atomicAdd(&s_base[cc], 1u) : atomicAdd(&s_nleft, 1u);
+                const uint32_t la = s_la[e], lb = s_lb[e];
+                tpair[bstart + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), cc | (s_tile[f + s_tj[e]] << 8));
             }
             __syncthreads();
         }
-#undef TDYN
-        // colour-major order inside the tile (uncoloured pairs last)
-        for (uint32_t e = tid; e < np; e += kBlock) {
-            const uint32_t c = s_col[e];
-            if (c < SFX_MAX_COLORS) atomicAdd(&s_hist[c], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t run = 0, nc = 0;
-            for (uint32_t c = 0; c < SFX_MAX_COLORS; ++c) {
-                s_base[c] = run;
-                if (s_hist[c]) nc = c + 1;
-                run += s_hist[c];
-            }
-            s_nleft = run;  // reused: cursor of the uncoloured tail
-            tile_ncol[t] = nc;
-            atomicMax(&ctr->n_colors, nc);
-            if (s_ovf) atomicOr(&ctr->overflow, kOvfColors);
-        }
-        if (tid < SFX_MAX_COLORS && s_hist[tid]) atomicAdd(&ctr->color_count[tid], s_hist[tid]);
-        __syncthreads();
-        for (uint32_t e = tid; e < np; e += kBlock) {
-            const uint32_t c = s_col[e];
-            const uint32_t dst = (c < SFX_MAX_COLORS) ? atomicAdd(&s_base[c], 1u) : atomicAdd(&s_nleft, 1u);
-            const uint32_t la = s_la[e], lb = s_lb[e];
-            tpair[start + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), c);
-        }
-        __syncthreads();
     }
 }
 
@@ -721,6 +865,7 @@ __global__ __launch_bounds__(kGlobalColorBlock) void k_color_global(GlobalColor 
         A.ctr->n_tile_pairs = total;
         A.ctr->n_pairs = total + ne;
         A.ctr->n_fb = ne;
+        A.ctr->n_active[0] = A.ctr->n_listed[0] + A.ctr->n_listed[1] + A.ctr->n_listed[2] + A.ctr->n_listed[3] + A.ctr->n_big;
     }
     if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
     if (tid == 0) s_nleft = 0u;
@@ -861,9 +1006,10 @@ struct TileArrays {
     const uint32_t* cell_start;
     const uint32_t* sorted_id;
     const uint32_t* tile_start;   // scanned pair counts
-    const uint32_t* active;       // per phase lists
-    const uint4* tpair;           // colour-major per tile
-    const uint32_t* tile_ncol;
+    const uint32_t* active;       // per phase tile lists
+    const uint32_t* big;          // tiles that are batches of their own
+    const BatchDesc* batches;     // per phase batch tables
+    const uint4* tpair;           // colour-major per batch
     const uint2* fsorted;         // fallback list, colour-major
     uint32_t max_pairs;           // record slot of fallback pair k = max_pairs + k
     uint32_t fb_cap;
@@ -995,7 +1141,7 @@ struct PairEnds {
 
 __device__ __forceinline__ PairEnds pair_ends(const uint4& pr) {
     PairEnds e;
-    e.a = pr.x; e.b = pr.y; e.la = pr.z & 0xFFFFu; e.lb = pr.z >> 16; e.col = pr.w;
+    e.a = pr.x; e.b = pr.y; e.la = pr.z & 0xFFFFu; e.lb = pr.z >> 16; e.col = pr.w & 0xFFu;
     return e;
 }
 
@@ -1012,20 +1158,18 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback,
     __shared__ float4 s_pose[kMaxB];
     __shared__ float2 s_mass[kMaxB];
     __shared__ uint32_t s_gid[kMaxB];
+    __shared__ BatchRanges S;
     const uint32_t tid = threadIdx.x;
-    const uint32_t nact = ctr->n_active[ph];
-    for (uint32_t it = blockIdx.x; it < nact; it += gridDim.x) {
+    const uint32_t nbat = ctr->n_batches[ph];
+    for (uint32_t it = blockIdx.x; it < nbat; it += gridDim.x) {
         SFX_TT(tt0);
-        const uint32_t t = T.active[ph * (g.ntiles >> 2) + it];
-        BlockRanges R;
-        block_ranges(t, g, T.cell_start, R);
-        const uint32_t nb = min(R.off[4], kMaxB);
-        uint32_t start, np;
-        tile_pair_range(t, T.tile_start, T.max_pairs, start, np);
-        np = min(np, kMaxP);
-        const uint32_t ncol = T.tile_ncol[t];
+        const BatchDesc d = T.batches[ph * (g.ntiles >> 2) + it];
+        const uint32_t* tiles = (d.first & 0x80000000u) ? T.big + (d.first & 0x7FFFFFFFu)
+                                                         : T.active + ph * (g.ntiles >> 2) + d.first;
+        batch_ranges(tiles, d.count, g, T.cell_start, S);
+        const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
         for (uint32_t l = tid; l < nb; l += NT) {
-            const uint32_t gid = T.sorted_id[block_slot(R, l)];
+            const uint32_t gid = T.sorted_id[batch_slot(S, 4u * d.count, l)];
             s_gid[l] = gid;
             s_pose[l] = B.pose[gid];
             s_mass[l] = B.mass[gid];
@@ -1110,20 +1254,18 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph, int with_fallback,
     __shared__ float2 s_mass[kMaxB];
     __shared__ uint32_t s_gid[kMaxB];
     __shared__ uint32_t s_shift;
+    __shared__ BatchRanges S;
     const uint32_t tid = threadIdx.x;
-    const uint32_t nact = ctr->n_active[ph];
-    for (uint32_t it = blockIdx.x; it < nact; it += gridDim.x) {
-        const uint32_t t = T.active[ph * (g.ntiles >> 2) + it];
-        BlockRanges R;
-        block_ranges(t, g, T.cell_start, R);
-        const uint32_t nb = min(R.off[4], kMaxB);
-        uint32_t start, np;
-        tile_pair_range(t, T.tile_start, T.max_pairs, start, np);
-        np = min(np, kMaxP);
-        const uint32_t ncol = T.tile_ncol[t];
+    const uint32_t nbat = ctr->n_batches[ph];
+    for (uint32_t it = blockIdx.x; it < nbat; it += gridDim.x) {
+        const BatchDesc d = T.batches[ph * (g.ntiles >> 2) + it];
+        const uint32_t* tiles = (d.first & 0x80000000u) ? T.big + (d.first & 0x7FFFFFFFu)
+                                                         : T.active + ph * (g.ntiles >> 2) + d.first;
+        batch_ranges(tiles, d.count, g, T.cell_start, S);
+        const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
         if (tid == 0) s_shift = 0u;
         for (uint32_t l = tid; l < nb; l += NT) {
-            const uint32_t gid = T.sorted_id[block_slot(R, l)];
+            const uint32_t gid = T.sorted_id[batch_slot(S, 4u * d.count, l)];
             s_gid[l] = gid;
             s_pose[l] = B.pose[gid];
             s_vel[l] = B.vel[gid];
@@ -1218,7 +1360,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restri
         uint32_t a, b, slot;
         if (k < ntp) {
             const uint4 pr = T.tpair[k];
-            if (pr.w >= SFX_MAX_COLORS) continue;  // uncoloured: never solved
+            if ((pr.w & 0xFFu) >= SFX_MAX_COLORS) continue;  // uncoloured: never solved
             a = pr.x; b = pr.y; slot = k;
         } else {
             const uint2 ab = T.fsorted[k - ntp];
