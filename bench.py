@@ -9,7 +9,10 @@ workload; value = dynamic bodies x substeps x K / seconds, summed over all ranks
 
 N = 1 : the headline config (BASELINE.json configs[2]): 100k mixed circle/rect/capsule pile,
         4 substeps, settled on the GPU before anything is timed.
-N > 1 : weak scaling, one process per GPU: see `multi_gpu_workload`.
+N > 1 : weak scaling, one process per GPU: a pile N times as wide (N x 100k bodies) cut into N
+        slabs on x (starframe_amd/slab.py); every substep the boundary bodies go to the two
+        neighbours with RCCL send/recv (torch.distributed "nccl") straight from the library's
+        device buffers.  value = all bodies x substeps x K / max-over-ranks seconds.
 
 The JSON line also carries
   roofline     : the dominant kernel (k_tile_pos: narrowphase + XPBD manifold block solves of one
@@ -116,27 +119,55 @@ def main():
     ap.add_argument("--bodies", type=int, default=100_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--settle-frames", type=int, default=600)
+    ap.add_argument("--force-slab", action="store_true",
+                    help="rehearse the N > 1 code path (slab driver over torch.distributed nccl) with one rank")
     args = ap.parse_args()
     rank, local_rank, world = dist_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
 
-    dist = None
-    if world > 1:
-        import torch.distributed as dist  # gloo only: rendezvous, barrier, max-reduce on CPU
-
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-
     from starframe_amd import scenes
     from starframe_amd.world import World
 
     device = local_rank
-    scene = scenes.mixed_pile(n=args.bodies)
-    parallelism = "1 GPU" if world == 1 else f"{world} independent replicas (one pile per GPU, no exchange)"
-    scene = settle(scene, device, frames=args.settle_frames)
-    n_dyn = scene.n_dynamic()
-    w = World.from_scene(scene, device=device)
+    dist = None
+    slab = None
+    if world > 1 or args.force_slab:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(device)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+
+        from starframe_amd.slab import DistSlab
+
+        # one pile, `world` times as wide; settled as slabs with damping, then re-cut on the settled state
+        scene = scenes.mixed_pile(n=world * args.bodies, width=world * 1000)
+        pre = DistSlab(scene, World, dist, device_index=device, linear_damping=3.3, angular_damping=1.0)
+        for _ in range(args.settle_frames):
+            pre.step(DT)
+        pos, rot, _, _ = pre.gather()
+        pre.close()
+        scene = scene.with_state(pos, rot, name=scene.name + "_settled")
+        slab = DistSlab(scene, World, dist, device_index=device)
+        w = slab.world
+        n_dyn = scene.n_dynamic()            # all ranks together
+        n_local = slab.plan.n_owned
+        halo = len(slab.plan.send_idx)
+        parallelism = (f"{world} slabs on x, {n_local} owned + {len(slab.plan.recv_idx)} ghost bodies on rank 0, "
+                       f"halo of {halo} bodies x 32 B to <= 2 neighbours per substep over "
+                       f"{'RCCL device buffers' if slab.on_device else 'host staging'}")
+        step = lambda: slab.step(DT)
+    else:
+        scene = scenes.mixed_pile(n=args.bodies)
+        parallelism = "1 GPU"
+        scene = settle(scene, device, frames=args.settle_frames)
+        n_dyn = scene.n_dynamic()
+        w = World.from_scene(scene, device=device)
+        step = lambda: w.step(DT)
 
     def barrier():
         w.sync()
@@ -144,17 +175,17 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        w.step(DT)
+        step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        w.step(DT)
+        step()
     w.sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
@@ -165,7 +196,7 @@ def main():
     w.set_profiling(True)
     w.kernel_times(reset=True)
     for _ in range(prof_frames):
-        w.step(DT)
+        step()
     kt = w.kernel_times()
     w.set_profiling(False)
     st2 = w.stats()
@@ -175,8 +206,9 @@ def main():
     bytes_per_launch = solve_pos_bytes(st2) / max(launches_per_substep, 1)
     achieved = bytes_per_launch / dur_s / 1e9
     kernel_ms = {k: round(v["total_ms"] / prof_frames, 4) for k, v in kt.items() if v["launches"]}
-    value = world * n_dyn * scene.substeps * args.steps / elapsed
-    bpbs = tick_bytes_per_body_substep(st2, n_dyn, scene.substeps)
+    value = n_dyn * scene.substeps * args.steps / elapsed
+    n_rank = slab.plan.n_owned if slab is not None else n_dyn
+    bpbs = tick_bytes_per_body_substep(st2, n_rank, scene.substeps)
 
     out = {
         "metric": "body-substeps/sec (100k-body pile, 4 substeps)",
@@ -194,7 +226,7 @@ def main():
         "config": {
             "workload": f"mixed_pile: {n_dyn} circle/rect/capsule bodies settled in a static container, "
                         f"{scene.substeps} substeps, dt=1/60 (BASELINE.json configs[2])",
-            "bodies_per_gpu": n_dyn,
+            "bodies_per_gpu": n_rank,
             "substeps": scene.substeps,
             "parallelism": parallelism,
             "pairs": st.n_pairs,
@@ -223,6 +255,8 @@ def main():
                     f"over {prof_frames} further ticks after the timed region",
         },
     }
+    if dist is not None:
+        dist.barrier()
     w.close()
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(scene)

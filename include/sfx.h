@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 2u
+#define SFX_ABI_VERSION 3u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -187,6 +187,31 @@ int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constrai
  * stream; sfx_sync / any download waits for it. */
 int sfx_step(sfx_world* w, float frame_dt);
 int sfx_sync(sfx_world* w);
+
+/* ---- the tick in pieces + slab halos (BASELINE.json:5 "slab domain decomposition,
+ * exchanging boundary bodies each substep") ------------------------------------------------
+ * sfx_step == sfx_tick_begin, then `substeps` x sfx_tick_substep.  A slab driver (one world per
+ * GPU, starframe_amd/slab.py) runs the pieces itself and swaps halo bodies between substeps:
+ *   sfx_halo_set      the local bodies this world sends (its own, near a slab boundary) and the
+ *                     ghost bodies it receives (copies of the neighbours' boundary bodies);
+ *   sfx_halo_pack     gathers (pose, velocity) = 8 floats per send body into the send buffer;
+ *   sfx_halo_unpack   scatters the receive buffer over the ghosts' poses and velocities;
+ *   sfx_halo_buffers  the two device buffers (library-owned, sized by sfx_halo_set), which the
+ *                     driver hands to RCCL send/recv on the world's stream;
+ *   sfx_halo_download / _upload   the same through host memory (tests, gloo transport);
+ *   sfx_halo_copy     device-to-device between two worlds of one process (logical slabs).
+ * Everything is enqueued on the world's stream; sfx_set_stream makes that an existing HIP
+ * stream (e.g. the one RCCL work is ordered against). */
+int sfx_tick_begin(sfx_world* w, float frame_dt);   /* broadphase + tiles + colouring */
+int sfx_tick_substep(sfx_world* w);                 /* one substep of the tick begun */
+int sfx_set_stream(sfx_world* w, void* hip_stream); /* NULL = back to the world's own stream */
+int sfx_halo_set(sfx_world* w, const uint32_t* send_idx, uint32_t n_send, const uint32_t* recv_idx, uint32_t n_recv);
+int sfx_halo_pack(sfx_world* w);
+int sfx_halo_unpack(sfx_world* w);
+int sfx_halo_buffers(sfx_world* w, float** send_dev, float** recv_dev);
+int sfx_halo_download(sfx_world* w, float* send_host /* [n_send][8] */);   /* pack + copy, synchronises */
+int sfx_halo_upload(sfx_world* w, const float* recv_host /* [n_recv][8] */); /* copy + unpack */
+int sfx_halo_copy(sfx_world* dst, uint32_t dst_first, sfx_world* src, uint32_t src_first, uint32_t count);
 
 int sfx_download_poses(sfx_world* w, float* pos, float* rot);
 int sfx_download_velocities(sfx_world* w, float* vel, float* angvel);

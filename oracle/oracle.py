@@ -49,6 +49,14 @@ def load():
     lib.sfo_resolved_config.restype = None
     lib.sfo_step.argtypes = [vp, C.c_float, C.c_int]
     lib.sfo_step.restype = C.c_int
+    lib.sfo_tick_begin.argtypes = [vp, C.c_float, C.c_int]
+    lib.sfo_tick_begin.restype = C.c_int
+    lib.sfo_tick_substep.argtypes = [vp]
+    lib.sfo_tick_substep.restype = C.c_int
+    lib.sfo_halo_get.argtypes = [vp, vp, C.c_uint32, P(C.c_float)]
+    lib.sfo_halo_get.restype = C.c_int
+    lib.sfo_halo_put.argtypes = [vp, vp, C.c_uint32, P(C.c_float)]
+    lib.sfo_halo_put.restype = C.c_int
     lib.sfo_broadphase.argtypes = [vp, C.c_float]
     lib.sfo_broadphase.restype = C.c_int
     lib.sfo_aabbs.argtypes = [vp, P(C.c_float)]
@@ -104,6 +112,28 @@ class OracleWorld(WorldBase):
 
     def sync(self):
         pass
+
+    # ---- the tick in pieces + slab halos, same interface as starframe_amd.world.World
+    def tick_begin(self, dt, order=ORDER_COLORED):
+        self._check(self.lib.sfo_tick_begin(self.handle, dt, order))
+
+    def tick_substep(self):
+        self._check(self.lib.sfo_tick_substep(self.handle))
+
+    def halo_set(self, send_idx, recv_idx):
+        self._send_idx = np.ascontiguousarray(send_idx, np.uint32)
+        self._recv_idx = np.ascontiguousarray(recv_idx, np.uint32)
+        self.n_halo_send, self.n_halo_recv = len(self._send_idx), len(self._recv_idx)
+
+    def halo_get(self):
+        out = np.empty((self.n_halo_send, 8), np.float32)
+        self._check(self.lib.sfo_halo_get(self.handle, vptr(self._send_idx), self.n_halo_send, fptr(out)))
+        return out
+
+    def halo_put(self, arr):
+        a = np.ascontiguousarray(arr, np.float32)
+        assert a.shape == (self.n_halo_recv, 8)
+        self._check(self.lib.sfo_halo_put(self.handle, vptr(self._recv_idx), self.n_halo_recv, fptr(a)))
 
     def broadphase(self, dt):
         self._check(self.lib.sfo_broadphase(self.handle, dt))

@@ -77,6 +77,9 @@ struct sfo_world {
     uint32_t* batch_end; /* order[] is cut into batches: batch k = [batch_end[k-1], batch_end[k]) */
     uint32_t n_batches, n_order;
     int order_valid;
+    int tick_open, tick_order;
+    uint32_t tick_nbatch;
+    float tick_h;
     pair_rec* rec;
     uint32_t n_contacts, n_manifolds, n_manifolds2;
     float max_depth;
@@ -1374,12 +1377,14 @@ static void solve_joint(sfo_world* w, const sfx_distance_constraint* j, float in
     if (b != SFX_WORLD_BODY) apply_pos(w, b, rbx, rby, nx * corr, ny * corr, -1.0f);
 }
 
-int sfo_step(sfo_world* w, float frame_dt, int order) {
+/* the tick in pieces, mirroring sfx_tick_begin / sfx_tick_substep (slab drivers swap halo
+ * bodies between substeps) */
+int sfo_tick_begin(sfo_world* w, float frame_dt, int order) {
     if (!w->col || !w->mats) return SFX_ERR_INVALID;
     broadphase_core(w, frame_dt); /* capacity overflow is reported by sfo_stats, the tick goes on */
     uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
-    uint32_t nord = np, nbatch = 1;
     for (uint32_t e = 0; e < np; ++e) w->rec[e].count = 0;
+    w->tick_nbatch = 1;
     if (order == SFO_ORDER_SEQUENTIAL) {
         /* one batch, ascending pair key: what a single-threaded engine does */
         key_idx* ki = (key_idx*)malloc((np ? np : 1) * sizeof(key_idx));
@@ -1390,43 +1395,83 @@ int sfo_step(sfo_world* w, float frame_dt, int order) {
         w->batch_end[0] = np;
     } else {
         build_order(w);
-        nord = w->n_order; nbatch = w->n_batches;
+        w->tick_nbatch = w->n_batches;
     }
-    (void)nord;
-    float h = frame_dt / (float)w->cfg.substeps;
+    w->tick_h = frame_dt / (float)w->cfg.substeps;
+    w->tick_order = order;
+    w->tick_open = 1;
+    return SFX_OK;
+}
+
+int sfo_tick_substep(sfo_world* w) {
+    if (!w->tick_open) return SFX_ERR_INVALID;
+    int order = w->tick_order;
+    uint32_t nbatch = w->tick_nbatch;
+    float h = w->tick_h;
     float inv_h = 1.0f / h;
     float inv_h2 = inv_h * inv_h;
     float max_corr = w->cfg.max_depenetration_velocity * h;
-    for (uint32_t s = 0; s < w->cfg.substeps; ++s) {
-        integrate(w, h);
-        for (uint32_t k = 0; k < w->m; ++k) {
-            uint32_t jk = order == SFO_ORDER_SEQUENTIAL ? k : w->joint_perm[k];
-            if (order != SFO_ORDER_SEQUENTIAL && w->joint_color[jk] == NO_COLOR) continue;
-            solve_joint(w, &w->joints[jk], inv_h2);
+    integrate(w, h);
+    for (uint32_t k = 0; k < w->m; ++k) {
+        uint32_t jk = order == SFO_ORDER_SEQUENTIAL ? k : w->joint_perm[k];
+        if (order != SFO_ORDER_SEQUENTIAL && w->joint_color[jk] == NO_COLOR) continue;
+        solve_joint(w, &w->joints[jk], inv_h2);
+    }
+    for (uint32_t bt = 0, k0 = 0; bt < nbatch; ++bt) {
+        uint32_t k1 = w->batch_end[bt];
+        for (uint32_t k = k0; k < k1; ++k) prepare_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]]);
+        for (uint32_t k = k0; k < k1; ++k) solve_pos_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]], max_corr);
+        k0 = k1;
+    }
+    derive_velocities(w, inv_h);
+    for (uint32_t bt = 0, k0 = 0; bt < nbatch; ++bt) {
+        uint32_t k1 = w->batch_end[bt];
+        for (uint32_t k = k0; k < k1; ++k) {
+            uint32_t e = w->order[k];
+            if (w->rec[e].count) solve_vel_pair(w, w->pa[e], w->pb[e], &w->rec[e], h, inv_h);
         }
-        for (uint32_t bt = 0, k0 = 0; bt < nbatch; ++bt) {
-            uint32_t k1 = w->batch_end[bt];
-            for (uint32_t k = k0; k < k1; ++k) prepare_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]]);
-            for (uint32_t k = k0; k < k1; ++k) solve_pos_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]], max_corr);
-            k0 = k1;
-        }
-        derive_velocities(w, inv_h);
-        for (uint32_t bt = 0, k0 = 0; bt < nbatch; ++bt) {
-            uint32_t k1 = w->batch_end[bt];
-            for (uint32_t k = k0; k < k1; ++k) {
-                uint32_t e = w->order[k];
-                if (w->rec[e].count) solve_vel_pair(w, w->pa[e], w->pb[e], &w->rec[e], h, inv_h);
-            }
-            k0 = k1;
-        }
+        k0 = k1;
     }
     /* stats of the last substep, measured on the records */
+    uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
     w->n_contacts = 0; w->max_depth = 0.0f; w->n_manifolds = 0; w->n_manifolds2 = 0;
     for (uint32_t e = 0; e < np; ++e) {
         if (w->rec[e].count) w->n_manifolds++;
         if (w->rec[e].count == 2) w->n_manifolds2++;
         for (uint32_t k = 0; k < w->rec[e].count; ++k)
             if (w->rec[e].lam[k] > 0.0f) w->n_contacts++;
+    }
+    return SFX_OK;
+}
+
+int sfo_step(sfo_world* w, float frame_dt, int order) {
+    int rc = sfo_tick_begin(w, frame_dt, order);
+    for (uint32_t s = 0; rc == SFX_OK && s < w->cfg.substeps; ++s) rc = sfo_tick_substep(w);
+    w->tick_open = 0;
+    return rc;
+}
+
+/* (pose, velocity) of the listed bodies as [n][8] = (x, y, cos, sin, vx, vy, omega, 0) */
+int sfo_halo_get(const sfo_world* w, const uint32_t* idx, uint32_t n, float* out) {
+    for (uint32_t k = 0; k < n; ++k) {
+        uint32_t i = idx[k];
+        if (i >= w->n) return SFX_ERR_INVALID;
+        out[8 * k] = w->pos[2 * i]; out[8 * k + 1] = w->pos[2 * i + 1];
+        out[8 * k + 2] = w->rot[2 * i]; out[8 * k + 3] = w->rot[2 * i + 1];
+        out[8 * k + 4] = w->vel[2 * i]; out[8 * k + 5] = w->vel[2 * i + 1];
+        out[8 * k + 6] = w->angvel[i]; out[8 * k + 7] = 0.0f;
+    }
+    return SFX_OK;
+}
+
+int sfo_halo_put(sfo_world* w, const uint32_t* idx, uint32_t n, const float* in) {
+    for (uint32_t k = 0; k < n; ++k) {
+        uint32_t i = idx[k];
+        if (i >= w->n) return SFX_ERR_INVALID;
+        w->pos[2 * i] = in[8 * k]; w->pos[2 * i + 1] = in[8 * k + 1];
+        w->rot[2 * i] = in[8 * k + 2]; w->rot[2 * i + 1] = in[8 * k + 3];
+        w->vel[2 * i] = in[8 * k + 4]; w->vel[2 * i + 1] = in[8 * k + 5];
+        w->angvel[i] = in[8 * k + 6];
     }
     return SFX_OK;
 }

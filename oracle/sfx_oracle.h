@@ -51,6 +51,12 @@ int sfo_upload_constraints(sfo_world* w, uint32_t m, const sfx_distance_constrai
 void sfo_resolved_config(const sfo_world* w, sfx_config* out);
 
 int sfo_step(sfo_world* w, float frame_dt, int order);
+/* the tick in pieces (sfo_step == begin + substeps x substep) and the halo state of listed bodies,
+ * [n][8] = (x, y, cos, sin, vx, vy, omega, 0): what a slab driver swaps between substeps */
+int sfo_tick_begin(sfo_world* w, float frame_dt, int order);
+int sfo_tick_substep(sfo_world* w);
+int sfo_halo_get(const sfo_world* w, const uint32_t* idx, uint32_t n, float* out);
+int sfo_halo_put(sfo_world* w, const uint32_t* idx, uint32_t n, const float* in);
 
 int sfo_download_poses(const sfo_world* w, float* pos, float* rot);
 int sfo_download_velocities(const sfo_world* w, float* vel, float* angvel);

@@ -175,6 +175,8 @@ SFX_SYMBOLS = [
     "sfx_create", "sfx_destroy", "sfx_abi_version", "sfx_default_config",
     "sfx_upload_bodies", "sfx_upload_colliders", "sfx_upload_materials", "sfx_upload_constraints",
     "sfx_step", "sfx_sync", "sfx_download_poses", "sfx_download_velocities",
+    "sfx_tick_begin", "sfx_tick_substep", "sfx_set_stream", "sfx_halo_set", "sfx_halo_pack", "sfx_halo_unpack",
+    "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy",
     "sfx_debug_aabbs", "sfx_debug_pairs", "sfx_debug_pair_colors", "sfx_debug_broadphase",
     "sfx_debug_contacts", "sfx_debug_joint_order",
     "sfx_stats", "sfx_set_profiling", "sfx_kernel_times", "sfx_kernel_class_name",
@@ -227,6 +229,19 @@ def load_libsfx(path=None):
     lib.sfx_step.restype = C.c_int
     lib.sfx_sync.argtypes = [vp]
     lib.sfx_sync.restype = C.c_int
+    lib.sfx_tick_begin.argtypes = [vp, C.c_float]
+    lib.sfx_tick_substep.argtypes = [vp]
+    lib.sfx_set_stream.argtypes = [vp, vp]
+    lib.sfx_halo_set.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
+    lib.sfx_halo_pack.argtypes = [vp]
+    lib.sfx_halo_unpack.argtypes = [vp]
+    lib.sfx_halo_buffers.argtypes = [vp, P(vp), P(vp)]
+    lib.sfx_halo_download.argtypes = [vp, P(C.c_float)]
+    lib.sfx_halo_upload.argtypes = [vp, P(C.c_float)]
+    lib.sfx_halo_copy.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32]
+    for n in ("sfx_tick_begin", "sfx_tick_substep", "sfx_set_stream", "sfx_halo_set", "sfx_halo_pack",
+              "sfx_halo_unpack", "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy"):
+        getattr(lib, n).restype = C.c_int
     lib.sfx_debug_aabbs.argtypes = [vp, P(C.c_float)]
     lib.sfx_debug_pairs.argtypes = [vp, vp, C.c_size_t, P(C.c_size_t)]
     lib.sfx_debug_pair_colors.argtypes = [vp, vp, vp, vp, C.c_size_t, P(C.c_size_t)]

@@ -78,6 +78,15 @@ struct sfx_world {
     DevBuf<uint32_t> deg, left_list;
     DevBuf<uint8_t> pcolor, prop;
     DevBuf<Counters> jctr;
+    // slab halos
+    DevBuf<uint32_t> halo_send_idx, halo_recv_idx;
+    DevBuf<float4> halo_send, halo_recv;
+    uint32_t n_halo_send = 0, n_halo_recv = 0;
+    // tick in pieces
+    StepParams sp{};
+    bool tick_open = false;
+    uint32_t substeps_done = 0;
+    hipStream_t own_stream_handle = nullptr;
     DevBuf<unsigned long long> dbg;  // -DSFX_TILE_TIMING builds: stage timing of k_tile_pos
     // contact records
     DevBuf<float4> c_hdr, c_anc0, c_anc1, c_lamv;
@@ -443,7 +452,7 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
     const char* ns = getenv("SFX_NULL_STREAM");
     w->own_stream = !(ns && ns[0] == '1');
     if ((e = hipSetDevice(w->device)) != hipSuccess ||
-        (w->own_stream && (e = hipStreamCreate(&w->stream)) != hipSuccess) ||
+        (w->own_stream && (e = hipStreamCreate(&w->own_stream_handle)) != hipSuccess) ||
         (e = hipEventCreate(&w->ev_ctr)) != hipSuccess || (e = hipEventCreate(&w->t_begin)) != hipSuccess ||
         (e = hipEventCreate(&w->t_end)) != hipSuccess ||
         (e = hipHostMalloc(reinterpret_cast<void**>(&w->h_ctr), sizeof(Counters))) != hipSuccess) {
@@ -451,6 +460,7 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
         sfx_destroy(w);
         return SFX_ERR_DEVICE;
     }
+    w->stream = w->own_stream_handle;
     if (w->jctr.alloc(1) || w->scan_sums.alloc(4096) || w->left_list.alloc(kLeftCap) ||
         w->j_count_dev.alloc(1)) {
         fail(nullptr, SFX_ERR_NOMEM, "hipMalloc failed");
@@ -476,13 +486,14 @@ void sfx_destroy(sfx_world* w) {
     w->cellxy.release(); w->sorted_cell.release();
     w->used.release(); w->claim.release(); w->deg.release(); w->left_list.release();
     w->pcolor.release(); w->prop.release(); w->jctr.release(); w->dbg.release();
+    w->halo_send_idx.release(); w->halo_recv_idx.release(); w->halo_send.release(); w->halo_recv.release();
     w->c_hdr.release(); w->c_anc0.release(); w->c_anc1.release(); w->c_lamv.release(); w->c_misc.release();
     w->j_bodies.release(); w->j_anchors.release(); w->j_params.release(); w->j_count_dev.release();
     if (w->h_ctr) (void)hipHostFree(w->h_ctr);
     if (w->ev_ctr) (void)hipEventDestroy(w->ev_ctr);
     if (w->t_begin) (void)hipEventDestroy(w->t_begin);
     if (w->t_end) (void)hipEventDestroy(w->t_end);
-    if (w->stream && w->own_stream) (void)hipStreamDestroy(w->stream);
+    if (w->own_stream_handle) (void)hipStreamDestroy(w->own_stream_handle);
     delete w;
 }
 
@@ -704,7 +715,7 @@ int sfx_debug_broadphase(sfx_world* w, float frame_dt) {
     return SFX_OK;
 }
 
-int sfx_step(sfx_world* w, float frame_dt) {
+int sfx_tick_begin(sfx_world* w, float frame_dt) {
     int rc = ready(w);
     if (rc) return rc;
     if (!(frame_dt > 0.0f)) return fail(w, SFX_ERR_INVALID, "frame_dt must be positive");
@@ -713,8 +724,7 @@ int sfx_step(sfx_world* w, float frame_dt) {
     w->launches = 0;
     rc = broadphase(w, frame_dt);
     if (rc) return rc;
-    const uint32_t n = w->n;
-    StepParams sp;
+    StepParams& sp = w->sp;
     sp.h = frame_dt / (float)w->cfg.substeps;
     sp.inv_h = 1.0f / sp.h;
     sp.inv_h2 = sp.inv_h * sp.inv_h;
@@ -725,46 +735,163 @@ int sfx_step(sfx_world* w, float frame_dt) {
     sp.max_corr = w->cfg.max_depenetration_velocity * sp.h;
     sp.damp_lin = 1.0f / (1.0f + sp.h * w->cfg.linear_damping);
     sp.damp_ang = 1.0f / (1.0f + sp.h * w->cfg.angular_damping);
+    w->tick_open = true;
+    w->substeps_done = 0;
+    w->ticked = true;
+    return SFX_OK;
+}
+
+int sfx_tick_substep(sfx_world* w) {
+    if (!w) return SFX_ERR_INVALID;
+    if (!w->tick_open) return fail(w, SFX_ERR_INVALID, "sfx_tick_substep without sfx_tick_begin");
+    HIPCHK(w, hipSetDevice(w->device));
+    const uint32_t n = w->n;
+    const StepParams sp = w->sp;
     const BodyArrays B = body_arrays(w);
     const ContactArrays C = contact_arrays(w);
     JointArrays J;
     J.bodies = w->j_bodies.p; J.anchors = w->j_anchors.p; J.params = w->j_params.p;
-    // grids follow the active tile counts of an earlier tick (stale counters, read back
-    // asynchronously); the kernels loop over the tile lists, so any grid size is correct
+    // grids follow the batch counts of an earlier tick (stale counters, read back
+    // asynchronously); the kernels loop over the batch tables, so any grid size is correct
     const TileArrays T = tile_arrays(w);
     const GridParams g = grid_params(w);
     const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
     const uint32_t njc = (uint32_t)w->joint_color_start.size() - 1;
-    for (uint32_t s = 0; s < w->cfg.substeps; ++s) {
-        { Prof p(w, SFX_K_INTEGRATE, n);
-          hipLaunchKernelGGL(k_integrate, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
-        for (uint32_t jc = 0; jc < njc; ++jc) {
-            const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
-            if (!cnt) continue;
-            Prof p(w, SFX_K_SOLVE_JOINTS, cnt);
-            hipLaunchKernelGGL(k_solve_joints, dim3(cdiv(cnt, kBlock)), dim3(kBlock), 0, w->stream, start, cnt, B, J, sp.inv_h2);
-        }
-        for (uint32_t ph = 0; ph < 4; ++ph) {
-            Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_tile_pairs / 4 : 0);
-            hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph,
-                               ph == 3 ? 1 : 0, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
-        }
-        { Prof p(w, SFX_K_DERIVE_VEL, n);
-          hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
-        for (uint32_t ph = 0; ph < 4; ++ph) {
-            Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_tile_pairs / 4 : 0);
-            hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph,
-                               ph == 3 ? 1 : 0, g, T, w->ctr, B, C, sp);
-        }
+    { Prof p(w, SFX_K_INTEGRATE, n);
+      hipLaunchKernelGGL(k_integrate, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
+    for (uint32_t jc = 0; jc < njc; ++jc) {
+        const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
+        if (!cnt) continue;
+        Prof p(w, SFX_K_SOLVE_JOINTS, cnt);
+        hipLaunchKernelGGL(k_solve_joints, dim3(cdiv(cnt, kBlock)), dim3(kBlock), 0, w->stream, start, cnt, B, J, sp.inv_h2);
+    }
+    for (uint32_t ph = 0; ph < 4; ++ph) {
+        Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_tile_pairs / 4 : 0);
+        hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph,
+                           ph == 3 ? 1 : 0, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
+    }
+    { Prof p(w, SFX_K_DERIVE_VEL, n);
+      hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
+    for (uint32_t ph = 0; ph < 4; ++ph) {
+        Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_tile_pairs / 4 : 0);
+        hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph,
+                           ph == 3 ? 1 : 0, g, T, w->ctr, B, C, sp);
     }
     HIPCHK(w, hipGetLastError());
-    if (!w->ctr_pending) {
-        HIPCHK(w, hipMemcpyAsync(w->h_ctr, w->ctr, sizeof(Counters), hipMemcpyDeviceToHost, w->stream));
-        HIPCHK(w, hipEventRecord(w->ev_ctr, w->stream));
-        w->ctr_pending = true;
+    if (++w->substeps_done >= w->cfg.substeps) {
+        // end of the tick: start the asynchronous read-back of its counters
+        w->tick_open = false;
+        if (!w->ctr_pending) {
+            HIPCHK(w, hipMemcpyAsync(w->h_ctr, w->ctr, sizeof(Counters), hipMemcpyDeviceToHost, w->stream));
+            HIPCHK(w, hipEventRecord(w->ev_ctr, w->stream));
+            w->ctr_pending = true;
+        }
+        if (w->profiling) return collect_profile(w);
     }
-    w->ticked = true;
-    if (w->profiling) return collect_profile(w);
+    return SFX_OK;
+}
+
+int sfx_step(sfx_world* w, float frame_dt) {
+    int rc = sfx_tick_begin(w, frame_dt);
+    for (uint32_t s = 0; rc == SFX_OK && s < w->cfg.substeps; ++s) rc = sfx_tick_substep(w);
+    return rc;
+}
+
+int sfx_set_stream(sfx_world* w, void* hip_stream) {
+    if (!w) return SFX_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : w->own_stream_handle;
+    return SFX_OK;
+}
+
+int sfx_halo_set(sfx_world* w, const uint32_t* send_idx, uint32_t n_send, const uint32_t* recv_idx, uint32_t n_recv) {
+    if (!w || (n_send && !send_idx) || (n_recv && !recv_idx)) return fail(w, SFX_ERR_INVALID, "null argument");
+    if (!w->have_bodies) return fail(w, SFX_ERR_INVALID, "upload bodies before the halo lists");
+    for (uint32_t k = 0; k < n_send; ++k)
+        if (send_idx[k] >= w->n) return fail(w, SFX_ERR_INVALID, "halo send index %u out of range", send_idx[k]);
+    for (uint32_t k = 0; k < n_recv; ++k)
+        if (recv_idx[k] >= w->n) return fail(w, SFX_ERR_INVALID, "halo receive index %u out of range", recv_idx[k]);
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    ALLOC(w, w->halo_send_idx, n_send); ALLOC(w, w->halo_recv_idx, n_recv);
+    ALLOC(w, w->halo_send, 2 * (size_t)n_send); ALLOC(w, w->halo_recv, 2 * (size_t)n_recv);
+    if (n_send) HIPCHK(w, hipMemcpy(w->halo_send_idx.p, send_idx, sizeof(uint32_t) * n_send, hipMemcpyHostToDevice));
+    if (n_recv) HIPCHK(w, hipMemcpy(w->halo_recv_idx.p, recv_idx, sizeof(uint32_t) * n_recv, hipMemcpyHostToDevice));
+    w->n_halo_send = n_send; w->n_halo_recv = n_recv;
+    return SFX_OK;
+}
+
+int sfx_halo_pack(sfx_world* w) {
+    if (!w) return SFX_ERR_INVALID;
+    if (!w->n_halo_send) return SFX_OK;
+    HIPCHK(w, hipSetDevice(w->device));
+    Prof p(w, SFX_K_HALO, w->n_halo_send);
+    hipLaunchKernelGGL(k_halo_pack, dim3(cdiv(w->n_halo_send, kBlock)), dim3(kBlock), 0, w->stream, w->n_halo_send,
+                       w->halo_send_idx.p, w->pose.p, w->vel.p, w->halo_send.p);
+    return SFX_OK;
+}
+
+int sfx_halo_unpack(sfx_world* w) {
+    if (!w) return SFX_ERR_INVALID;
+    if (!w->n_halo_recv) return SFX_OK;
+    HIPCHK(w, hipSetDevice(w->device));
+    Prof p(w, SFX_K_HALO, w->n_halo_recv);
+    hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv(w->n_halo_recv, kBlock)), dim3(kBlock), 0, w->stream, w->n_halo_recv,
+                       w->halo_recv_idx.p, w->halo_recv.p, w->pose.p, w->vel.p);
+    return SFX_OK;
+}
+
+int sfx_halo_buffers(sfx_world* w, float** send_dev, float** recv_dev) {
+    if (!w) return SFX_ERR_INVALID;
+    if (send_dev) *send_dev = reinterpret_cast<float*>(w->halo_send.p);
+    if (recv_dev) *recv_dev = reinterpret_cast<float*>(w->halo_recv.p);
+    return SFX_OK;
+}
+
+int sfx_halo_download(sfx_world* w, float* send_host) {
+    if (!w || (w->n_halo_send && !send_host)) return fail(w, SFX_ERR_INVALID, "null argument");
+    int rc = sfx_halo_pack(w);
+    if (rc) return rc;
+    if (w->n_halo_send)
+        HIPCHK(w, hipMemcpyAsync(send_host, w->halo_send.p, sizeof(float4) * 2 * w->n_halo_send, hipMemcpyDeviceToHost, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return SFX_OK;
+}
+
+int sfx_halo_upload(sfx_world* w, const float* recv_host) {
+    if (!w || (w->n_halo_recv && !recv_host)) return fail(w, SFX_ERR_INVALID, "null argument");
+    if (!w->n_halo_recv) return SFX_OK;
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipMemcpyAsync(w->halo_recv.p, recv_host, sizeof(float4) * 2 * w->n_halo_recv, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));  // recv_host is borrowed for this call only
+    return sfx_halo_unpack(w);
+}
+
+int sfx_halo_copy(sfx_world* dst, uint32_t dst_first, sfx_world* src, uint32_t src_first, uint32_t count) {
+    if (!dst || !src) return SFX_ERR_INVALID;
+    if (dst->device != src->device) return fail(dst, SFX_ERR_UNSUPPORTED, "sfx_halo_copy needs both worlds on one device");
+    if ((uint64_t)dst_first + count > dst->n_halo_recv || (uint64_t)src_first + count > src->n_halo_send)
+        return fail(dst, SFX_ERR_INVALID, "halo copy range out of bounds");
+    if (!count) return SFX_OK;
+    HIPCHK(dst, hipSetDevice(dst->device));
+    // ordered after the source's pack and before the destination's unpack
+    if (src->stream != dst->stream) {
+        hipEvent_t ev;
+        HIPCHK(dst, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(dst, hipEventRecord(ev, src->stream));
+        HIPCHK(dst, hipStreamWaitEvent(dst->stream, ev, 0));
+        HIPCHK(dst, hipEventDestroy(ev));
+    }
+    HIPCHK(dst, hipMemcpyAsync(dst->halo_recv.p + 2 * (size_t)dst_first, src->halo_send.p + 2 * (size_t)src_first,
+                               sizeof(float4) * 2 * count, hipMemcpyDeviceToDevice, dst->stream));
+    if (src->stream != dst->stream) {  // the source must not pack again before this copy has read its buffer
+        hipEvent_t ev;
+        HIPCHK(dst, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(dst, hipEventRecord(ev, dst->stream));
+        HIPCHK(dst, hipStreamWaitEvent(src->stream, ev, 0));
+        HIPCHK(dst, hipEventDestroy(ev));
+    }
     return SFX_OK;
 }
 

@@ -1327,6 +1327,28 @@ __global__ __launch_bounds__(kBlock) void k_solve_joints(uint32_t start, uint32_
     if (k < cnt) solve_joint(B, J, start + k, inv_h2);
 }
 
+// ---------------------------------------------------------------- slab halos
+// (pose, velocity) of the listed bodies <-> a dense [n][2] float4 buffer
+__global__ __launch_bounds__(kBlock) void k_halo_pack(uint32_t n, const uint32_t* __restrict__ idx,
+                                                       const float4* __restrict__ pose, const float4* __restrict__ vel,
+                                                       float4* __restrict__ out) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = idx[k];
+    out[2 * k] = pose[i];
+    out[2 * k + 1] = vel[i];
+}
+
+__global__ __launch_bounds__(kBlock) void k_halo_unpack(uint32_t n, const uint32_t* __restrict__ idx,
+                                                         const float4* __restrict__ in, float4* __restrict__ pose,
+                                                         float4* __restrict__ vel) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= n) return;
+    const uint32_t i = idx[k];
+    pose[i] = in[2 * k];
+    vel[i] = in[2 * k + 1];
+}
+
 // ---------------------------------------------------------------- reporting / parity hooks
 __global__ __launch_bounds__(kBlock) void k_stats_bodies(uint32_t n, const float4* __restrict__ vel,
                                                           const float2* __restrict__ mass, Counters* __restrict__ ctr) {

@@ -1,0 +1,321 @@
+"""Slab domain decomposition of one scene over several worlds (BASELINE.json:5: "large scenes are
+split across the 8 GPUs of one node by slab domain decomposition, exchanging boundary bodies each
+substep with RCCL over xGMI").
+
+The x axis is cut into `nranks` slabs holding equal numbers of dynamic bodies.  A rank's world
+holds the bodies it owns, ghost copies of the neighbours' bodies within `halo` of its two
+boundaries, and the non-dynamic bodies in reach.  Every substep the owners' (pose, velocity) of
+the boundary bodies replace the neighbours' ghosts: 32 bytes per body to at most two peers, so
+the exchange is latency-bound and there is no collective on the data path.
+
+    plan_slabs      pure numpy: who owns what, who ghosts what, in which buffer order
+    LocalSlabs      all slabs in one process (logical slabs on one GPU or on the CPU oracle)
+    DistSlab        one slab per process over torch.distributed: "nccl" (= RCCL) moves the
+                    library's device buffers directly, "gloo" goes through host memory
+
+Both drivers work with any engine that has the World interface (starframe_amd.world.World on an
+MI355X; the CPU oracle's OracleWorld in the CPU tests).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from ._abi import SHAPE_CAPSULE, SHAPE_CIRCLE, SHAPE_POLY, SHAPE_RECT
+
+
+def bounding_radius(scene):
+    """Radius of a circle around the body origin that contains the collider."""
+    c = scene.colliders
+    p = c["p"]
+    r = np.zeros(scene.n, np.float32)
+    t = c["type"]
+    r = np.where(t == SHAPE_CIRCLE, p[:, 2], r)
+    r = np.where(t == SHAPE_RECT, np.sqrt(p[:, 0] ** 2 + p[:, 1] ** 2) + p[:, 2], r)
+    r = np.where(t == SHAPE_CAPSULE, p[:, 0] + p[:, 2], r)
+    if np.any(t == SHAPE_POLY):
+        pv = np.asarray(scene.poly_verts, np.float32).reshape(-1, 2)
+        vr = np.sqrt((pv ** 2).sum(1))
+        for i in np.nonzero(t == SHAPE_POLY)[0]:
+            o, k = int(c["poly_offset"][i]), int(c["poly_count"][i])
+            r[i] = vr[o:o + k].max() + p[i, 2]
+    return r.astype(np.float32)
+
+
+def x_half_extent(scene):
+    """Half width of the collider's AABB at the current rotation (tight for boxes that never turn)."""
+    c = scene.colliders
+    p, t = c["p"], c["type"]
+    co, si = np.abs(scene.rot[:, 0]), np.abs(scene.rot[:, 1])
+    e = bounding_radius(scene)
+    e = np.where(t == SHAPE_RECT, co * p[:, 0] + si * p[:, 1] + p[:, 2], e)
+    e = np.where(t == SHAPE_CAPSULE, co * p[:, 0] + p[:, 2], e)
+    return e.astype(np.float32)
+
+
+@dataclass
+class SlabPlan:
+    rank: int
+    nranks: int
+    lo: float                      # slab = [lo, hi) on x (owner of a dynamic body = slab of its centre)
+    hi: float
+    ids: np.ndarray                # global id of every local body: owned, ghosts (left, right), fixed
+    n_owned: int
+    send_left: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))   # local indices
+    send_right: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))
+    recv_left: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))
+    recv_right: np.ndarray = field(default_factory=lambda: np.zeros(0, np.uint32))
+
+    @property
+    def send_idx(self):
+        return np.concatenate([self.send_left, self.send_right]).astype(np.uint32)
+
+    @property
+    def recv_idx(self):
+        return np.concatenate([self.recv_left, self.recv_right]).astype(np.uint32)
+
+
+def default_halo(scene):
+    """Two bodies touch only if their centres are closer than the sum of their bounding radii;
+    twice the largest dynamic diameter plus the AABB padding also covers the second ring."""
+    dyn = (scene.inv_mass > 0) | (scene.inv_inertia > 0)
+    r = bounding_radius(scene)
+    rmax = float(r[dyn].max()) if dyn.any() else 0.0
+    return 4.0 * rmax + 4.0 * (scene.aabb_margin + 0.03)
+
+
+def plan_slabs(scene, nranks, halo=None):
+    """Cuts `scene` into `nranks` slabs.  Returns (plans, boundaries)."""
+    if scene.constraints is not None and len(scene.constraints):
+        raise ValueError("scenes with distance constraints are not decomposed (chains stay on one GPU)")
+    halo = default_halo(scene) if halo is None else float(halo)
+    x = scene.pos[:, 0].astype(np.float64)
+    dyn = (scene.inv_mass > 0) | (scene.inv_inertia > 0)
+    rad = bounding_radius(scene).astype(np.float64)
+    xext = x_half_extent(scene).astype(np.float64)   # non-dynamic bodies do not turn
+    xd = np.sort(x[dyn])
+    if len(xd) < nranks:
+        raise ValueError("fewer dynamic bodies than slabs")
+    # equal-count cuts, each halfway between two neighbouring bodies
+    cuts = []
+    for k in range(1, nranks):
+        j = (k * len(xd)) // nranks
+        cuts.append(0.5 * (xd[j - 1] + xd[j]))
+    bounds = np.array([-np.inf] + cuts + [np.inf])
+    if nranks > 2 and np.min(np.diff(bounds[1:-1])) <= 2.0 * halo:
+        raise ValueError("slabs thinner than two halo widths: use fewer ranks")
+    owner = np.searchsorted(bounds, x, side="right") - 1
+    owner = np.clip(owner, 0, nranks - 1)
+    gid = np.arange(scene.n)
+    plans = []
+    for r in range(nranks):
+        lo, hi = bounds[r], bounds[r + 1]
+        owned = gid[dyn & (owner == r)]
+        ghost_l = gid[dyn & (owner == r - 1) & (x + rad > lo - halo)] if r > 0 else gid[:0]
+        ghost_r = gid[dyn & (owner == r + 1) & (x - rad < hi + halo)] if r + 1 < nranks else gid[:0]
+        # anything further out must not reach this slab
+        far = dyn & (np.abs(owner - r) > 1) & (x + rad > lo - halo) & (x - rad < hi + halo)
+        if far.any():
+            raise ValueError("a body two slabs away reaches into this slab's halo: use fewer ranks")
+        fixed = gid[~dyn & (x + xext > lo - 2.0 * halo) & (x - xext < hi + 2.0 * halo)]
+        ids = np.concatenate([owned, ghost_l, ghost_r, fixed])
+        plans.append(SlabPlan(r, nranks, float(lo), float(hi), ids, len(owned)))
+    # send lists mirror the neighbours' ghost lists (ascending global id on both sides)
+    for r in range(nranks):
+        p = plans[r]
+        local = {int(g): k for k, g in enumerate(p.ids[:p.n_owned])}
+        no, nl = p.n_owned, 0
+        if r > 0:
+            gl = dyn & (owner == r - 1) & (x + rad > p.lo - halo)
+            nl = int(gl.sum())
+            p.recv_left = np.arange(no, no + nl, dtype=np.uint32)
+            q = plans[r - 1]
+            want = gid[dyn & (owner == r) & (x - rad < q.hi + halo)]          # what r-1 ghosts from r
+            p.send_left = np.array([local[int(g)] for g in want], np.uint32)
+        if r + 1 < nranks:
+            gr = dyn & (owner == r + 1) & (x - rad < p.hi + halo)
+            p.recv_right = np.arange(no + nl, no + nl + int(gr.sum()), dtype=np.uint32)
+            q = plans[r + 1]
+            want = gid[dyn & (owner == r) & (x + rad > q.lo - halo)]          # what r+1 ghosts from r
+            p.send_right = np.array([local[int(g)] for g in want], np.uint32)
+    return plans, bounds
+
+
+def local_scene(scene, plan):
+    s = scene.subset(plan.ids, name=f"{scene.name}_slab{plan.rank}")
+    return s
+
+
+class LocalSlabs:
+    """All slabs of a scene in one process: logical slabs on one GPU (device-to-device halo
+    copies) or on any engine with halo_get / halo_put (host copies)."""
+
+    def __init__(self, scene, nslabs, engine, halo=None, **cfg_kw):
+        self.scene = scene
+        self.plans, self.bounds = plan_slabs(scene, nslabs, halo)
+        self.worlds = [engine.from_scene(local_scene(scene, p), **cfg_kw) for p in self.plans]
+        for w, p in zip(self.worlds, self.plans):
+            w.halo_set(p.send_idx, p.recv_idx)
+        self.device_copies = all(hasattr(w, "halo_copy_from") for w in self.worlds)
+
+    def exchange(self):
+        ws, ps = self.worlds, self.plans
+        if self.device_copies:
+            for w in ws:
+                w.halo_pack()
+            for r, (w, p) in enumerate(zip(ws, ps)):
+                if r > 0:       # left neighbour's "to the right" segment -> my "from the left" segment
+                    w.halo_copy_from(ws[r - 1], 0, len(ps[r - 1].send_left), len(p.recv_left))
+                if r + 1 < len(ws):
+                    w.halo_copy_from(ws[r + 1], len(p.recv_left), 0, len(p.recv_right))
+            for w in ws:
+                w.halo_unpack()
+            return
+        out = [w.halo_get() for w in ws]
+        for r, (w, p) in enumerate(zip(ws, ps)):
+            parts = []
+            if r > 0:
+                parts.append(out[r - 1][len(ps[r - 1].send_left):])
+            if r + 1 < len(ws):
+                parts.append(out[r + 1][:len(ps[r + 1].send_left)])
+            w.halo_put(np.concatenate(parts) if parts else np.zeros((0, 8), np.float32))
+
+    def step(self, dt):
+        for w in self.worlds:
+            w.tick_begin(dt)
+        for _ in range(self.scene.substeps):
+            for w in self.worlds:
+                w.tick_substep()
+            self.exchange()
+
+    def gather(self):
+        """Global (pos, rot, vel, angvel): every body from its owner (fixed bodies from any copy)."""
+        n = self.scene.n
+        pos, rot = np.array(self.scene.pos, np.float32), np.array(self.scene.rot, np.float32)
+        vel, ang = np.array(self.scene.vel, np.float32), np.array(self.scene.angvel, np.float32)
+        for w, p in zip(self.worlds, self.plans):
+            lp, lr = w.poses()
+            lv, la = w.velocities()
+            own = p.ids[:p.n_owned]
+            pos[own], rot[own], vel[own], ang[own] = lp[:p.n_owned], lr[:p.n_owned], lv[:p.n_owned], la[:p.n_owned]
+        assert pos.shape[0] == n
+        return pos, rot, vel, ang
+
+    def close(self):
+        for w in self.worlds:
+            w.close()
+
+
+class _DeviceArray:
+    """Lets torch view a device buffer owned by libsfx (no copy): __cuda_array_interface__."""
+
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {
+            "shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 2, "strides": None,
+        }
+
+
+class DistSlab:
+    """One slab per process.  `dist` is an initialised torch.distributed module / group.
+
+    backend "nccl" (RCCL): the library's send / receive buffers are wrapped as torch tensors and
+    moved peer to peer on the stream the world runs on -- no host copy, no synchronisation.
+    Any other backend ("gloo"): the halo goes through host memory (tests, CPU engines)."""
+
+    def __init__(self, scene, engine, dist, halo=None, device_index=None, **cfg_kw):
+        import torch
+
+        self.torch, self.dist = torch, dist
+        self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+        self.scene = scene
+        plans, self.bounds = plan_slabs(scene, self.nranks, halo)
+        self.plan = plans[self.rank]
+        self.all_plans = plans
+        if device_index is not None:
+            cfg_kw = dict(cfg_kw, device=device_index)
+        self.world = engine.from_scene(local_scene(scene, self.plan), **cfg_kw)
+        self.world.halo_set(self.plan.send_idx, self.plan.recv_idx)
+        self.on_device = dist.get_backend() == "nccl" and hasattr(self.world, "halo_buffer_pointers")
+        p = self.plan
+        self.n_sl, self.n_sr, self.n_rl, self.n_rr = len(p.send_left), len(p.send_right), len(p.recv_left), len(p.recv_right)
+        self.send = self.recv = self.stream = None
+        if self.on_device:
+            try:
+                dev = torch.device("cuda", device_index if device_index is not None else torch.cuda.current_device())
+                torch.cuda.set_device(dev)
+                # one stream carries the world's kernels and orders the RCCL transfers against them
+                self.stream = torch.cuda.Stream(dev)
+                self.world.set_stream(self.stream.cuda_stream)
+                sp, rp = self.world.halo_buffer_pointers()
+                ns, nr = 8 * (self.n_sl + self.n_sr), 8 * (self.n_rl + self.n_rr)
+                self.send = torch.as_tensor(_DeviceArray(sp, ns), device=dev) if ns else torch.empty(0, device=dev)
+                self.recv = torch.as_tensor(_DeviceArray(rp, nr), device=dev) if nr else torch.empty(0, device=dev)
+            except Exception as e:  # the transfer then goes through host memory: slower, same results
+                import warnings
+
+                warnings.warn(f"device halo buffers unavailable ({e!r}); staging the halo through host memory")
+                self.on_device = False
+                self.world.set_stream(0)
+
+    def _ops(self, send, recv):
+        d, r = self.dist, self.rank
+        ops = []
+        if r > 0:
+            if self.n_sl:
+                ops.append(d.P2POp(d.isend, send[: 8 * self.n_sl], r - 1))
+            if self.n_rl:
+                ops.append(d.P2POp(d.irecv, recv[: 8 * self.n_rl], r - 1))
+        if r + 1 < self.nranks:
+            if self.n_sr:
+                ops.append(d.P2POp(d.isend, send[8 * self.n_sl:], r + 1))
+            if self.n_rr:
+                ops.append(d.P2POp(d.irecv, recv[8 * self.n_rl:], r + 1))
+        return ops
+
+    def exchange(self):
+        if self.on_device:
+            self.world.halo_pack()
+            ops = self._ops(self.send, self.recv)
+            if ops:
+                with self.torch.cuda.stream(self.stream):
+                    for w in self.dist.batch_isend_irecv(ops):
+                        w.wait()       # orders the world's stream after the transfer; no host wait with NCCL
+            self.world.halo_unpack()
+            return
+        t = self.torch
+        send = t.from_numpy(self.world.halo_get().reshape(-1))
+        recv = t.empty(8 * (self.n_rl + self.n_rr), dtype=t.float32)
+        ops = self._ops(send, recv)
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        self.world.halo_put(recv.numpy().reshape(-1, 8))
+
+    def step(self, dt):
+        self.world.tick_begin(dt)
+        for _ in range(self.scene.substeps):
+            self.world.tick_substep()
+            self.exchange()
+
+    def sync(self):
+        self.world.sync()
+
+    def owned_state(self):
+        p = self.plan
+        lp, lr = self.world.poses()
+        lv, la = self.world.velocities()
+        k = p.n_owned
+        return p.ids[:k], lp[:k], lr[:k], lv[:k], la[:k]
+
+    def gather(self):
+        """Global state on every rank (host all-gather; for tests and read-back, not per tick)."""
+        ids, lp, lr, lv, la = self.owned_state()
+        parts = [None] * self.nranks
+        self.dist.all_gather_object(parts, (ids, lp, lr, lv, la))
+        pos, rot = np.array(self.scene.pos, np.float32), np.array(self.scene.rot, np.float32)
+        vel, ang = np.array(self.scene.vel, np.float32), np.array(self.scene.angvel, np.float32)
+        for i, a, b, c, d in parts:
+            pos[i], rot[i], vel[i], ang[i] = a, b, c, d
+        return pos, rot, vel, ang
+
+    def close(self):
+        self.world.close()

@@ -27,6 +27,8 @@ class WorldBase:
     handle = None
     n = 0
     m = 0
+    n_halo_send = 0
+    n_halo_recv = 0
 
     def _f(self, name):
         return getattr(self.lib, self.prefix + name)
@@ -121,6 +123,50 @@ class World(WorldBase):
 
     def sync(self):
         self._check(self.lib.sfx_sync(self.handle))
+
+    # ---- the tick in pieces + slab halos (starframe_amd/slab.py drives these)
+    def tick_begin(self, dt):
+        self._check(self.lib.sfx_tick_begin(self.handle, dt))
+
+    def tick_substep(self):
+        self._check(self.lib.sfx_tick_substep(self.handle))
+
+    def set_stream(self, hip_stream):
+        """Run on an existing HIP stream (an int handle, e.g. torch.cuda.current_stream().cuda_stream)."""
+        self._check(self.lib.sfx_set_stream(self.handle, C.c_void_p(hip_stream or None)))
+
+    def halo_set(self, send_idx, recv_idx):
+        s = np.ascontiguousarray(send_idx, np.uint32)
+        r = np.ascontiguousarray(recv_idx, np.uint32)
+        self.n_halo_send, self.n_halo_recv = len(s), len(r)
+        self._check(self.lib.sfx_halo_set(self.handle, vptr(s), len(s), vptr(r), len(r)))
+
+    def halo_get(self):
+        """Host copy of the send bodies' (pose, velocity): [n_send, 8]."""
+        out = np.empty((self.n_halo_send, 8), np.float32)
+        self._check(self.lib.sfx_halo_download(self.handle, fptr(out)))
+        return out
+
+    def halo_put(self, arr):
+        a = np.ascontiguousarray(arr, np.float32)
+        assert a.shape == (self.n_halo_recv, 8)
+        self._check(self.lib.sfx_halo_upload(self.handle, fptr(a)))
+
+    def halo_pack(self):
+        self._check(self.lib.sfx_halo_pack(self.handle))
+
+    def halo_unpack(self):
+        self._check(self.lib.sfx_halo_unpack(self.handle))
+
+    def halo_buffer_pointers(self):
+        """Device addresses of the library-owned send / receive buffers."""
+        s, r = C.c_void_p(), C.c_void_p()
+        self._check(self.lib.sfx_halo_buffers(self.handle, C.byref(s), C.byref(r)))
+        return s.value or 0, r.value or 0
+
+    def halo_copy_from(self, src, dst_first, src_first, count):
+        """Device-to-device: src's send buffer [src_first, +count) -> this world's receive buffer."""
+        self._check(self.lib.sfx_halo_copy(self.handle, dst_first, src.handle, src_first, count))
 
     # ---- parity hooks
     def broadphase(self, dt):

@@ -1,0 +1,62 @@
+"""Worker of tests/test_slab.py (gpu): torch views of libsfx's halo buffers + the one-rank "nccl"
+driver.  torch is imported first so that libsfx binds to the HIP runtime torch already loaded."""
+import os
+import sys
+
+import numpy as np
+import torch  # noqa: F401  (first: see the module docstring)
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from starframe_amd import scenes  # noqa: E402
+from starframe_amd.slab import DistSlab, _DeviceArray  # noqa: E402
+from starframe_amd.world import World  # noqa: E402
+
+DT = 1.0 / 60.0
+
+
+def main():
+    torch.cuda.init()
+    s = scenes.circles_container(n=500, width=50, floor_hw=7.0, wall_hh=6.0)
+    w = World.from_scene(s)
+    stream = torch.cuda.Stream()
+    w.set_stream(stream.cuda_stream)
+    idx = np.arange(10, 40, dtype=np.uint32)
+    w.halo_set(idx, idx[::-1].copy())
+    for _ in range(5):
+        w.step(DT)
+    sp, rp = w.halo_buffer_pointers()
+    send = torch.as_tensor(_DeviceArray(sp, 8 * len(idx)), device="cuda")
+    recv = torch.as_tensor(_DeviceArray(rp, 8 * len(idx)), device="cuda")
+    w.halo_pack()
+    w.sync()
+    host = w.halo_get()
+    assert np.array_equal(send.cpu().numpy().reshape(-1, 8), host), "torch alias does not see the packed halo"
+    pos, rot = w.poses()
+    assert np.array_equal(host[:, 0:2], pos[idx]) and np.array_equal(host[:, 2:4], rot[idx])
+    with torch.cuda.stream(stream):
+        recv.copy_(send)              # a "transfer" on the world's stream
+    w.halo_unpack()                   # body idx[::-1][k] <- state of body idx[k]
+    pos2, _ = w.poses()
+    assert np.array_equal(pos2[idx[::-1]], pos[idx]), "unpack did not read what torch wrote"
+    w.close()
+
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        slab = DistSlab(s, World, dist, device_index=0)
+        ref = World.from_scene(s)
+        assert slab.on_device
+        for _ in range(20):
+            slab.step(DT)
+            ref.step(DT)
+        slab.sync()
+        assert np.array_equal(slab.gather()[0].view(np.uint32), ref.poses()[0].view(np.uint32))
+    finally:
+        dist.destroy_process_group()
+    print("slab gpu worker ok")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,192 @@
+"""Slab domain decomposition: partition logic, logical slabs in one process, two
+ranks over gloo on the CPU, and -- on the GPU -- logical slabs with device-to-device halos.
+
+The CPU tests run the decomposition on the CPU oracle's engine: they check the driver and the
+exchange protocol, not the HIP kernels (those are covered by the gpu-marked tests below)."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from starframe_amd import scenes
+from starframe_amd.slab import LocalSlabs, default_halo, plan_slabs
+
+DT = 1.0 / 60.0
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def small_scene():
+    return scenes.circles_container(n=600, width=60, floor_hw=8.0, wall_hh=8.0)
+
+
+def test_plan_owns_every_dynamic_body_once_and_mirrors_halos():
+    s = scenes.mixed_pile(n=4000, width=200)
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    plans, bounds = plan_slabs(s, 4)
+    owned = np.concatenate([p.ids[:p.n_owned] for p in plans])
+    assert np.array_equal(np.sort(owned), np.nonzero(dyn)[0])
+    counts = [p.n_owned for p in plans]
+    assert max(counts) - min(counts) <= 1
+    halo = default_halo(s)
+    for r, p in enumerate(plans):
+        x = s.pos[p.ids[:p.n_owned], 0]
+        assert np.all(x >= p.lo) and np.all(x < p.hi)
+        if r + 1 < len(plans):
+            q = plans[r + 1]
+            # what r sends right is what r+1 receives from the left, same bodies in the same order
+            assert np.array_equal(p.ids[p.send_right], q.ids[q.recv_left])
+            assert np.array_equal(q.ids[q.send_left], p.ids[p.recv_right])
+            assert len(p.send_right) > 0
+            # every body of r within reach of the boundary is ghosted
+            near = p.ids[:p.n_owned][s.pos[p.ids[:p.n_owned], 0] > p.hi - 0.5 * halo]
+            assert np.isin(near, q.ids[q.recv_left]).all()
+        # fixed bodies are replicated where they are in reach: the floor everywhere, a wall only at its end
+        fixed = np.nonzero(~dyn)[0]
+        assert np.isin(fixed[0], p.ids)
+        assert np.isin(fixed[1], p.ids) == (r == 0) and np.isin(fixed[2], p.ids) == (r == len(plans) - 1)
+    assert len(plans[0].send_left) == 0 and len(plans[-1].send_right) == 0
+
+
+def test_plan_rejects_too_thin_slabs_and_constraints():
+    s = small_scene()
+    with pytest.raises(ValueError):
+        plan_slabs(s, 64)
+    with pytest.raises(ValueError):
+        plan_slabs(scenes.chains(n_chains=4, links=10), 2)
+
+
+def test_free_fall_is_bit_identical_to_the_undecomposed_world():
+    """Before anything touches, every body's arithmetic is independent of the decomposition."""
+    from oracle.oracle import OracleWorld
+
+    s = small_scene()
+    L = LocalSlabs(s, 3, OracleWorld)
+    W = OracleWorld.from_scene(s)
+    for _ in range(3):
+        L.step(DT)
+        W.step(DT)
+    assert W.stats().n_manifolds == 0
+    pos, rot, vel, ang = L.gather()
+    assert np.array_equal(pos.view(np.uint32), W.poses()[0].view(np.uint32))
+    assert np.array_equal(vel.view(np.uint32), W.velocities()[0].view(np.uint32))
+
+
+def test_logical_slabs_match_undecomposed_pile_statistically():
+    from oracle.oracle import OracleWorld
+
+    s = small_scene()
+    L = LocalSlabs(s, 3, OracleWorld)
+    W = OracleWorld.from_scene(s)
+    for _ in range(360):
+        L.step(DT)
+        W.step(DT)
+    pos, rot, vel, ang = L.gather()
+    ref = W.poses()[0]
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    assert np.isfinite(pos).all()
+    assert abs(pos[dyn, 1].mean() - ref[dyn, 1].mean()) < 0.02          # pile height
+    assert abs(pos[dyn, 1].max() - ref[dyn, 1].max()) < 0.15
+    ke = lambda v: float((v[dyn] ** 2).sum())
+    assert ke(vel) < 1.0 and ke(W.velocities()[0]) < 1.0                  # both (nearly) at rest: sum of v^2 over 600 bodies
+    # nothing fell through the seams: every body is inside the container
+    assert pos[dyn, 1].min() > -0.1 and np.abs(pos[dyn, 0]).max() < 8.5
+    depth = max(w.stats().max_depth for w in L.worlds)
+    assert depth < 0.05 and W.stats().max_depth < 0.05
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_two_ranks_over_gloo_equal_logical_slabs(tmp_path):
+    """world_size 2, gloo, CPU: the distributed driver gives bit-for-bit what two logical slabs in
+    one process give (same plan, same exchange order, another transport)."""
+    from oracle.oracle import OracleWorld
+
+    out = str(tmp_path / "dist.npz")
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_worker.py"), out, "40"], env=env))
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    z = np.load(out)
+    s = small_scene()
+    L = LocalSlabs(s, 2, OracleWorld)
+    for _ in range(40):
+        L.step(DT)
+    pos, rot, vel, ang = L.gather()
+    assert np.array_equal(z["pos"].view(np.uint32), pos.view(np.uint32))
+    assert np.array_equal(z["vel"].view(np.uint32), vel.view(np.uint32))
+    assert (L.worlds[0].stats().n_manifolds + L.worlds[1].stats().n_manifolds) > 100
+
+
+@pytest.mark.gpu
+def test_gpu_logical_slabs_match_oracle_slabs_and_undecomposed():
+    """Four logical slabs on one MI355X, halos copied device to device through the C ABI:
+    one tick equals the same decomposition on the oracle within 1e-5; 150 ticks settle to the
+    same pile as the undecomposed GPU world."""
+    from oracle.oracle import OracleWorld
+    from starframe_amd.world import World
+    from tests.helpers import rel_err
+
+    s = scenes.circles_container(n=3000, width=150, floor_hw=20.0, wall_hh=8.0)
+    G = LocalSlabs(s, 4, World)
+    O = LocalSlabs(s, 4, OracleWorld)
+    for _ in range(60):          # fall until the first layers touch
+        G.step(DT)
+    gp, gr, gv, ga = G.gather()
+    s2 = s.with_state(gp, gr, gv, ga)
+    G.close()
+    G = LocalSlabs(s2, 4, World)
+    O = LocalSlabs(s2, 4, OracleWorld)
+    G.step(DT)
+    O.step(DT)
+    assert sum(w.stats().n_manifolds for w in G.worlds) > 500
+    assert rel_err(G.gather()[0], O.gather()[0], floor=1.0) <= 1e-5
+    assert rel_err(G.gather()[2], O.gather()[2], floor=1.0) <= 1e-4
+    W = World.from_scene(s2)
+    W.step(DT)
+    for _ in range(150):
+        G.step(DT)
+        W.step(DT)
+    pos = G.gather()[0]
+    ref = W.poses()[0]
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    assert np.isfinite(pos).all()
+    assert abs(pos[dyn, 1].mean() - ref[dyn, 1].mean()) < 0.02
+    assert pos[dyn, 1].min() > -0.1
+    assert max(w.stats().max_depth for w in G.worlds) < 0.05
+
+
+@pytest.mark.gpu
+def test_gpu_halo_host_path_equals_device_path():
+    from starframe_amd.world import World
+
+    s = scenes.circles_container(n=1000, width=100, floor_hw=14.0, wall_hh=6.0)
+    A = LocalSlabs(s, 2, World)
+    B = LocalSlabs(s, 2, World)
+    B.device_copies = False      # through sfx_halo_download / sfx_halo_upload
+    for _ in range(30):
+        A.step(DT)
+        B.step(DT)
+    assert np.array_equal(A.gather()[0].view(np.uint32), B.gather()[0].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_gpu_torch_views_the_library_halo_buffers_and_single_rank_nccl():
+    """The RCCL transport hands torch tensors that alias libsfx's device buffers to send/recv.
+    Runs in a fresh process that imports torch BEFORE libsfx is loaded (as bench.py does for
+    N > 1): both must share one HIP runtime, and a process that loaded libsfx first cannot
+    initialise torch's afterwards."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "slab_gpu_worker.py")], env=env,
+                       capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "slab gpu worker ok" in r.stdout
