@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 3u
+#define SFX_ABI_VERSION 4u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -54,7 +54,7 @@ typedef enum sfx_shape_type {
 /* solver tiles (DESIGN.md "Contract / tiles"): a tile that owns more candidate pairs, or whose
  * 2x2 tile block holds more grid-sorted colliders, hands its pairs to the fallback list */
 #define SFX_TILE_MAX_PAIRS 2048u
-#define SFX_TILE_MAX_BODIES 512u
+#define SFX_TILE_MAX_BODIES 1024u
 #define SFX_FALLBACK_TILE 0xFFFFFFFFu
 
 /* physics config struct (BASELINE.json:5 "physics config") */
@@ -70,7 +70,10 @@ typedef struct sfx_config {
     uint32_t grid_log2[2];  /* wrapped grid is 2^gx by 2^gy cells; 0 = auto          */
     uint32_t max_pairs;     /* candidate pair capacity; 0 = 12 * bodies              */
     uint32_t color_rounds;  /* parallel colouring rounds before the serial finish; 0 = 12 */
-    uint32_t tile_cells;    /* solver tile edge in grid cells: 1, 2, 4 or 8; 0 = 1        */
+    uint32_t tile_cells;    /* solver tile width in grid cells: 1, 2, 4 or 8; 0 = 1       */
+    uint32_t tile_cells_y;  /* solver tile height in grid cells, a power of two; 0 = as wide;
+                               anything >= the grid height makes full-height strips: then a
+                               sweep has two phases instead of four (wide, shallow scenes)  */
     float restitution_threshold; /* restitution is dropped when |vn_pre| <= this * |g| * h; 0 = 2.0 */
     float max_depenetration_velocity; /* a contact corrects at most this * h of penetration per
                                substep (m/s); 0 = 3.0; negative = unlimited            */

@@ -67,7 +67,7 @@ struct sfo_world {
     uint32_t *pa, *pb; /* emission order */
     int32_t *ccx, *ccy;  /* home cell of every small collider (last broadphase) */
     uint8_t* is_small;   /* sorted into the grid (else: large list or no collider) */
-    uint32_t tl;         /* log2 of the tile edge in cells */
+    uint32_t tlx, tly;   /* log2 of the tile width / height in cells */
     uint8_t* color;      /* colour of the pair inside its batch (tile or fallback list) */
     uint32_t* owner;     /* wrapped owner tile of the pair, SFO_FALLBACK for the fallback list */
     uint32_t n_colors, n_leftover, overflow;
@@ -193,9 +193,13 @@ static void resolve_grid(sfo_world* w) {
         gx = gy = l;
     }
     /* at least 4 tiles per side, so that the 2x2 tile blocks of one phase never meet on the torus */
-    w->tl = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : w->cfg.tile_cells == 2 ? 1u : 0u;
-    if (gx < w->tl + 2) gx = w->tl + 2;
-    if (gy < w->tl + 2) gy = w->tl + 2;
+    w->tlx = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : w->cfg.tile_cells == 2 ? 1u : 0u;
+    if (gx < w->tlx + 2) gx = w->tlx + 2;
+    if (gy < 2) gy = 2;
+    /* tile height: as wide by default; a power of two; the grid height at most (= strips) */
+    w->tly = w->tlx;
+    if (w->cfg.tile_cells_y) { w->tly = 0; while (w->tly < 31 && (2u << w->tly) <= w->cfg.tile_cells_y) w->tly++; }
+    if (w->tly > gy) w->tly = gy;
     if (gx > 12) gx = 12;
     if (gy > 12) gy = 12;
     w->gxl = gx; w->gyl = gy;
@@ -257,7 +261,8 @@ void sfo_resolved_config(const sfo_world* w, sfx_config* out) {
     out->grid_log2[0] = w->gxl;
     out->grid_log2[1] = w->gyl;
     out->max_pairs = w->max_pairs;
-    out->tile_cells = 1u << w->tl;
+    out->tile_cells = 1u << w->tlx;
+    out->tile_cells_y = 1u << w->tly;
 }
 
 /* ------------------------------------------------------------------ colouring
@@ -629,7 +634,7 @@ static void grid_pairs(sfo_world* w) {
 }
 
 /* ------------------------------------------------------------------ tile order
- * [DESIGN] DESIGN.md "Contract / tiles".  Tiles are 2^tl x 2^tl blocks of grid cells (true
+ * [DESIGN] DESIGN.md "Contract / tiles".  Tiles are 2^tlx x 2^tly blocks of grid cells (true
  * cell coordinates, wrapped onto the torus like the cells).  A candidate pair of two small
  * colliders is owned by the tile (min tx, min ty) of its two home tiles; a pair of a small
  * collider and a large non-dynamic one by the small one's tile; everything else, and every
@@ -640,7 +645,7 @@ static void grid_pairs(sfo_world* w) {
  * Each tile's pairs, and the fallback list, are edge-coloured on their own. */
 
 static uint32_t wrapped_tile(const sfo_world* w, int32_t tx, int32_t ty) {
-    uint32_t lx = w->gxl - w->tl, ly = w->gyl - w->tl;
+    uint32_t lx = w->gxl - w->tlx, ly = w->gyl - w->tly;
     return (((uint32_t)ty & ((1u << ly) - 1u)) << lx) | ((uint32_t)tx & ((1u << lx) - 1u));
 }
 
@@ -648,19 +653,19 @@ static int32_t tile_coord(int32_t c, uint32_t tl) { return c >= 0 ? (int32_t)((u
 
 static void build_order(sfo_world* w) {
     uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
-    uint32_t lx = w->gxl - w->tl, ly = w->gyl - w->tl, ntiles = 1u << (lx + ly);
+    uint32_t lx = w->gxl - w->tlx, ly = w->gyl - w->tly, ntiles = 1u << (lx + ly);
     uint32_t* tbodies = (uint32_t*)calloc(ntiles, sizeof(uint32_t));
     uint32_t* tcnt = (uint32_t*)calloc(ntiles, sizeof(uint32_t));
     uint8_t* tover = (uint8_t*)calloc(ntiles, 1);
     uint8_t* dyn = (uint8_t*)malloc(w->n ? w->n : 1);
     for (uint32_t i = 0; i < w->n; ++i) {
         dyn[i] = (uint8_t)is_dynamic(w, i);
-        if (w->is_small[i]) tbodies[wrapped_tile(w, tile_coord(w->ccx[i], w->tl), tile_coord(w->ccy[i], w->tl))]++;
+        if (w->is_small[i]) tbodies[wrapped_tile(w, tile_coord(w->ccx[i], w->tlx), tile_coord(w->ccy[i], w->tly))]++;
     }
     for (uint32_t e = 0; e < np; ++e) {
         uint32_t a = w->pa[e], b = w->pb[e], own = SFO_FALLBACK;
-        int32_t txa = tile_coord(w->ccx[a], w->tl), tya = tile_coord(w->ccy[a], w->tl);
-        int32_t txb = tile_coord(w->ccx[b], w->tl), tyb = tile_coord(w->ccy[b], w->tl);
+        int32_t txa = tile_coord(w->ccx[a], w->tlx), tya = tile_coord(w->ccy[a], w->tly);
+        int32_t txb = tile_coord(w->ccx[b], w->tlx), tyb = tile_coord(w->ccy[b], w->tly);
         if (w->is_small[a] && w->is_small[b]) own = wrapped_tile(w, txa < txb ? txa : txb, tya < tyb ? tya : tyb);
         else if (w->is_small[a] && !dyn[b]) own = wrapped_tile(w, txa, tya);
         else if (w->is_small[b] && !dyn[a]) own = wrapped_tile(w, txb, tyb);
@@ -671,7 +676,7 @@ static void build_order(sfo_world* w) {
     for (uint32_t t = 0; t < ntiles; ++t) {
         if (!tcnt[t]) continue;
         uint32_t tx = t & ((1u << lx) - 1u), ty = t >> lx, nb = 0;
-        for (int dy = 0; dy < 2; ++dy)
+        for (int dy = 0; dy < (ly ? 2 : 1); ++dy) /* one tile row (strips): the block is two tiles, not four */
             for (int dx = 0; dx < 2; ++dx) nb += tbodies[wrapped_tile(w, (int32_t)tx + dx, (int32_t)ty + dy)];
         if (tcnt[t] > SFX_TILE_MAX_PAIRS || nb > SFX_TILE_MAX_BODIES) { tover[t] = 1; continue; }
         if (tcnt[t] > w->max_tile_pairs) w->max_tile_pairs = tcnt[t];

@@ -24,7 +24,7 @@ MAX_POLY_VERTS = 8
 WORLD_BODY = 0xFFFFFFFF
 MAX_COLORS = 64
 TILE_MAX_PAIRS = 2048
-TILE_MAX_BODIES = 512
+TILE_MAX_BODIES = 1024
 FALLBACK_TILE = 0xFFFFFFFF
 
 CFG_USE_GRAPH = 1
@@ -44,6 +44,7 @@ class SfxConfig(C.Structure):
         ("max_pairs", C.c_uint32),
         ("color_rounds", C.c_uint32),
         ("tile_cells", C.c_uint32),
+        ("tile_cells_y", C.c_uint32),
         ("restitution_threshold", C.c_float),
         ("max_depenetration_velocity", C.c_float),
         ("speculative_margin", C.c_float),
@@ -133,6 +134,7 @@ def make_config(
     max_pairs=0,
     color_rounds=0,
     tile_cells=0,
+    tile_cells_y=0,
     restitution_threshold=0.0,
     max_depenetration_velocity=0.0,
     speculative_margin=0.0,
@@ -153,6 +155,7 @@ def make_config(
     cfg.max_pairs = max_pairs
     cfg.color_rounds = color_rounds
     cfg.tile_cells = tile_cells
+    cfg.tile_cells_y = tile_cells_y
     cfg.restitution_threshold = restitution_threshold
     cfg.max_depenetration_velocity = max_depenetration_velocity
     cfg.speculative_margin = speculative_margin

@@ -472,7 +472,8 @@ struct ContactArrays {
     float2* misc;    // (restitution, count as bits)
     float4* anc0;    // point 0: (ra.x, ra.y, rb.x, rb.y) body-local
     float4* anc1;    // point 1
-    float4* lamv;    // (lambda0, lambda1, vn_pre0, vn_pre1)
+    float2* lam;     // (lambda0, lambda1) of this substep
+    float2* vpre;    // (vn_pre0, vn_pre1): normal relative velocities before the position solve
 };
 
 __device__ __forceinline__ void anchor_world(const float4& pose, float lx, float ly, float& rx, float& ry) {

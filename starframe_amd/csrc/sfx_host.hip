@@ -18,6 +18,8 @@
 
 using namespace sfx;
 
+constexpr uint32_t kTargetBatches = 224;  // batches per phase the grouping aims at (< 256 CUs)
+
 
 namespace {
 
@@ -72,7 +74,7 @@ struct sfx_world {
     DevBuf<int2> cellxy, sorted_cell;
     DevBuf<uint4> rawp, tpair;
     DevBuf<uint2> fpairs, fsorted;
-    uint32_t large_cap = 0, ntiles = 4, fb_cap = 0, tl = 1;
+    uint32_t large_cap = 0, ntiles = 4, fb_cap = 0, tlx = 0, tly = 0;
     // colouring of global edge lists (joints at upload, the fallback list every tick)
     DevBuf<unsigned long long> used, claim;
     DevBuf<uint32_t> deg, left_list;
@@ -89,7 +91,8 @@ struct sfx_world {
     hipStream_t own_stream_handle = nullptr;
     DevBuf<unsigned long long> dbg;  // -DSFX_TILE_TIMING builds: stage timing of k_tile_pos
     // contact records
-    DevBuf<float4> c_hdr, c_anc0, c_anc1, c_lamv;
+    DevBuf<float4> c_hdr, c_anc0, c_anc1;
+    DevBuf<float2> c_lam, c_vpre;
     DevBuf<float2> c_misc;
     // joints (colour-sorted)
     DevBuf<uint2> j_bodies;
@@ -207,12 +210,16 @@ void resolve_grid(sfx_world* w) {
         gx = gy = l;
     }
     // at least 4 tiles per side, so that the 2x2 tile blocks of one phase never meet on the torus
-    w->tl = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : w->cfg.tile_cells == 2 ? 1u : 0u;
-    gx = std::min(std::max(gx, w->tl + 2u), 12u);
-    gy = std::min(std::max(gy, w->tl + 2u), 12u);
+    w->tlx = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : w->cfg.tile_cells == 2 ? 1u : 0u;
+    gx = std::min(std::max(gx, w->tlx + 2u), 12u);
+    gy = std::min(std::max(gy, 2u), 12u);
+    // tile height: as wide by default; a power of two; the grid height at most (= strips)
+    w->tly = w->tlx;
+    if (w->cfg.tile_cells_y) { w->tly = 0; while (w->tly < 31 && (2u << w->tly) <= w->cfg.tile_cells_y) w->tly++; }
+    w->tly = std::min(w->tly, gy);
     w->gxl = gx; w->gyl = gy;
     w->ncell = (1u << gx) * (1u << gy);
-    w->ntiles = w->ncell >> (2u * w->tl);
+    w->ntiles = w->ncell >> (w->tlx + w->tly);
 }
 
 GridParams grid_params(const sfx_world* w) {
@@ -220,7 +227,8 @@ GridParams grid_params(const sfx_world* w) {
     g.inv_cell = w->inv_cell;
     g.small_lim = 0.9f * w->cell;
     g.gxl = w->gxl; g.gyl = w->gyl; g.ncell = w->ncell;
-    g.tl = w->tl; g.ntiles = w->ntiles;
+    g.tlx = w->tlx; g.tly = w->tly; g.ntiles = w->ntiles;
+    g.pstride = (w->tly == w->gyl) ? w->ntiles / 2 : w->ntiles / 4;  // strips: phases 0 and 1 hold all tiles
     return g;
 }
 
@@ -274,7 +282,7 @@ BodyArrays body_arrays(sfx_world* w) {
 
 ContactArrays contact_arrays(sfx_world* w) {
     ContactArrays C;
-    C.hdr = w->c_hdr.p; C.misc = w->c_misc.p; C.anc0 = w->c_anc0.p; C.anc1 = w->c_anc1.p; C.lamv = w->c_lamv.p;
+    C.hdr = w->c_hdr.p; C.misc = w->c_misc.p; C.anc0 = w->c_anc0.p; C.anc1 = w->c_anc1.p; C.lam = w->c_lam.p; C.vpre = w->c_vpre.p;
     return C;
 }
 
@@ -357,12 +365,8 @@ int broadphase(sfx_world* w, float dt) {
       hipLaunchKernelGGL(k_pairs<true>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
                          w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
-      hipLaunchKernelGGL((k_batch_color<kBatchP, false>), dim3(w->color_grid, 4), dim3(kBlock), 0, w->stream, g, w->group,
+      hipLaunchKernelGGL((k_batch_color<kBatchP, false>), dim3(w->color_grid, 4), dim3(512), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
-                         w->batches.p, w->max_pairs, w->cfg.color_rounds, w->ctr); }
-    { Prof p(w, SFX_K_COLOR, w->max_pairs);
-      hipLaunchKernelGGL((k_batch_color<kMaxP, true>), dim3(w->big_grid, 1), dim3(kBlock), 0, w->stream, g, 1u,
-                         w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->big_tiles.p, w->rawp.p, w->tpair.p,
                          w->batches.p, w->max_pairs, w->cfg.color_rounds, w->ctr); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
@@ -375,11 +379,15 @@ void poll_counters(sfx_world* w) {
         w->stale = *w->h_ctr;
         w->ctr_valid = true;
         w->ctr_pending = false;
-        // tiles per batch so that an average batch fills ~3/4 of the solve workgroup's pair slots
+        // tiles per batch: about kTargetBatches batches per phase (one workgroup each, all resident at
+        // once), but no batch beyond ~2/3 of the pair and body capacities on average
         const uint32_t ntl = w->stale.n_active[0];
         if (!w->group_fixed && ntl) {
             const uint32_t per_tile = std::max(w->stale.n_tile_pairs / ntl, 1u);
-            w->group = std::min(std::max((3u * kBatchP / 4u) / per_tile, 1u), (uint32_t)kMaxGroup);
+            const uint32_t phases = (w->tly == w->gyl) ? 2u : 4u;
+            const uint32_t want = cdiv(ntl / phases + 1u, kTargetBatches);
+            const uint32_t fit = std::max((2u * kBatchP / 3u) / per_tile, 1u);
+            w->group = std::min(std::min(std::max(want, 1u), fit), (uint32_t)kMaxGroup);
         }
         uint32_t groups = 0;
         for (int ph = 0; ph < 4; ++ph) {
@@ -487,7 +495,7 @@ void sfx_destroy(sfx_world* w) {
     w->used.release(); w->claim.release(); w->deg.release(); w->left_list.release();
     w->pcolor.release(); w->prop.release(); w->jctr.release(); w->dbg.release();
     w->halo_send_idx.release(); w->halo_recv_idx.release(); w->halo_send.release(); w->halo_recv.release();
-    w->c_hdr.release(); w->c_anc0.release(); w->c_anc1.release(); w->c_lamv.release(); w->c_misc.release();
+    w->c_hdr.release(); w->c_anc0.release(); w->c_anc1.release(); w->c_lam.release(); w->c_vpre.release(); w->c_misc.release();
     w->j_bodies.release(); w->j_anchors.release(); w->j_params.release(); w->j_count_dev.release();
     if (w->h_ctr) (void)hipHostFree(w->h_ctr);
     if (w->ev_ctr) (void)hipEventDestroy(w->ev_ctr);
@@ -624,13 +632,13 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     w->tile_fill = w->tile_cnt + ((size_t)w->ntiles + 1 + pad);
     w->tile_flag = w->tile_fill + w->ntiles;
     ALLOC(w, w->cell_fill, (size_t)w->ncell + 1 + pad);
-    ALLOC(w, w->active, w->ntiles); ALLOC(w, w->big_tiles, w->ntiles); ALLOC(w, w->batches, w->ntiles);
+    ALLOC(w, w->active, 2 * (size_t)w->ntiles); ALLOC(w, w->big_tiles, w->ntiles); ALLOC(w, w->batches, 2 * (size_t)w->ntiles);
     ALLOC(w, w->rawp, w->max_pairs); ALLOC(w, w->tpair, w->max_pairs);
     ALLOC(w, w->fpairs, w->fb_cap); ALLOC(w, w->fsorted, w->fb_cap);
     const size_t mc = std::max<size_t>(w->fb_cap, w->m);
     ALLOC(w, w->pcolor, mc); ALLOC(w, w->prop, mc);
     const size_t mp = (size_t)w->max_pairs + w->fb_cap;  // record slots: tile pairs, then the fallback list
-    ALLOC(w, w->c_hdr, mp); ALLOC(w, w->c_misc, mp); ALLOC(w, w->c_anc0, mp); ALLOC(w, w->c_anc1, mp); ALLOC(w, w->c_lamv, mp);
+    ALLOC(w, w->c_hdr, mp); ALLOC(w, w->c_misc, mp); ALLOC(w, w->c_anc0, mp); ALLOC(w, w->c_anc1, mp); ALLOC(w, w->c_lam, mp); ALLOC(w, w->c_vpre, mp);
     HIPCHK(w, hipMemset(w->c_misc.p, 0, sizeof(float2) * mp));
     HIPCHK(w, hipMemset(w->zero.p, 0, w->zero_bytes));
     w->ctr_valid = false; w->ctr_pending = false;
@@ -765,17 +773,19 @@ int sfx_tick_substep(sfx_world* w) {
         Prof p(w, SFX_K_SOLVE_JOINTS, cnt);
         hipLaunchKernelGGL(k_solve_joints, dim3(cdiv(cnt, kBlock)), dim3(kBlock), 0, w->stream, start, cnt, B, J, sp.inv_h2);
     }
-    for (uint32_t ph = 0; ph < 4; ++ph) {
-        Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_tile_pairs / 4 : 0);
+    // full-height strips have one tile row: only the phases 0 and 1 (tile x parity) exist
+    const uint32_t nph = (w->tly == w->gyl) ? 2u : 4u;
+    for (uint32_t ph = 0; ph < nph; ++ph) {
+        Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_tile_pairs / nph : 0);
         hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph,
-                           ph == 3 ? 1 : 0, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
+                           ph + 1 == nph ? 1 : 0, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
     }
     { Prof p(w, SFX_K_DERIVE_VEL, n);
       hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
-    for (uint32_t ph = 0; ph < 4; ++ph) {
-        Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_tile_pairs / 4 : 0);
+    for (uint32_t ph = 0; ph < nph; ++ph) {
+        Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_tile_pairs / nph : 0);
         hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph,
-                           ph == 3 ? 1 : 0, g, T, w->ctr, B, C, sp);
+                           ph + 1 == nph ? 1 : 0, g, T, w->ctr, B, C, sp);
     }
     HIPCHK(w, hipGetLastError());
     if (++w->substeps_done >= w->cfg.substeps) {

@@ -23,10 +23,10 @@ constexpr uint32_t kMaxP = SFX_TILE_MAX_PAIRS;      // pairs a tile may own
 constexpr uint32_t kMaxB = SFX_TILE_MAX_BODIES;     // grid-sorted colliders in a 2x2 tile block
 constexpr int kClaim = 4;                           // claim slots per body in the colouring
 #ifndef SFX_TILE_THREADS
-#define SFX_TILE_THREADS 256
+#define SFX_TILE_THREADS 512
 #endif
 constexpr int kTileThreads = SFX_TILE_THREADS;      // workgroup of the tile solves = pairs on the register path
-constexpr uint32_t kBatchP = kTileThreads;          // pairs of a batch of tiles (one bigger tile is a batch of its own)
+constexpr uint32_t kBatchP = kMaxP;                 // pairs of a batch of tiles
 constexpr int kMaxGroup = 16;                       // tiles per batch at most
 constexpr uint32_t kExt = 0xFFFFu;                  // local index of a body outside the block (large static)
 constexpr int kScanItems = 16;                      // items per thread in the block scan
@@ -68,21 +68,22 @@ struct GridParams {
     float small_lim;   // 0.9 * cell
     uint32_t gxl, gyl; // log2 grid dims (cells)
     uint32_t ncell;
-    uint32_t tl;       // log2 tile edge (cells)
+    uint32_t tlx, tly; // log2 tile width / height (cells); tly == gyl: full-height strips
     uint32_t ntiles;
+    uint32_t pstride;  // entries per phase in the tile lists and batch tables
 };
 
 // wrapped tile index of true tile coordinates
 __device__ __forceinline__ uint32_t tile_of(int32_t tx, int32_t ty, const GridParams& g) {
-    const uint32_t lx = g.gxl - g.tl, ly = g.gyl - g.tl;
+    const uint32_t lx = g.gxl - g.tlx, ly = g.gyl - g.tly;
     return (((uint32_t)ty & ((1u << ly) - 1u)) << lx) | ((uint32_t)tx & ((1u << lx) - 1u));
 }
 
 // bucket of a true cell: tile-major, so that a tile's cells -- and with them its colliders in
 // the sorted order -- are contiguous
 __device__ __forceinline__ uint32_t bucket_of(int32_t cx, int32_t cy, const GridParams& g) {
-    const uint32_t tm = (1u << g.tl) - 1u;
-    return (tile_of(cx >> g.tl, cy >> g.tl, g) << (2u * g.tl)) | (((uint32_t)cy & tm) << g.tl) | ((uint32_t)cx & tm);
+    const uint32_t mx = (1u << g.tlx) - 1u, my = (1u << g.tly) - 1u;
+    return (tile_of(cx >> g.tlx, cy >> g.tly, g) << (g.tlx + g.tly)) | (((uint32_t)cy & my) << g.tlx) | ((uint32_t)cx & mx);
 }
 
 // clears the per-tick block (counters, cell and tile histograms) with 16-byte stores
@@ -343,6 +344,34 @@ struct PairArrays {
     uint32_t max_pairs, fb_cap;
 };
 
+// The eight slot groups of a wave usually belong to one or two tiles (slots are sorted
+// tile-major): the groups that name the same counter index add up, the first of them does one
+// atomic for all, and every group gets its share.  All 64 lanes must call this.  `idx`, `c` are
+// the group's (uniform inside the group); returns the group's base (FILL) or nothing useful.
+template <bool WANT_BASE>
+__device__ __forceinline__ uint32_t wave_group_add(uint32_t* __restrict__ arr, uint32_t idx, uint32_t c, int lane) {
+    const int grp = lane >> 3;
+    uint32_t tot = 0, pre = 0;
+    int leader = grp;
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+        const uint32_t t = __shfl(idx, gq << 3, 64), cc = __shfl(c, gq << 3, 64);
+        if (t == idx) {
+            tot += cc;
+            if (gq < grp) pre += cc;
+            if (gq < leader) leader = gq;
+        }
+    }
+    uint32_t rb = 0;
+    if ((lane & 7) == 0 && leader == grp && tot) {
+        if (WANT_BASE) rb = atomicAdd(&arr[idx], tot);
+        else atomicAdd(&arr[idx], tot);
+    }
+    if (!WANT_BASE) return 0u;
+    rb = __shfl(rb, leader << 3, 64);
+    return rb + pre;
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, const uint32_t* __restrict__ cell_start,
                                                    const uint32_t* __restrict__ sorted_id,
@@ -366,24 +395,26 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
         uint4 fi = make_uint4(0, 0, 0, 0);
         int2 c = make_int2(0, 0);
         if (live) { i = sorted_id[p]; Ai = sorted_aabb[p]; fi = filt[i]; c = sorted_cell[p]; }
-        const int32_t txp = c.x >> g.tl, typ = c.y >> g.tl;
+        const int32_t txp = c.x >> g.tlx, typ = c.y >> g.tly;
         const uint32_t T0 = tile_of(txp, typ, g), T1 = tile_of(txp - 1, typ, g);
         // stream bases (fill pass): lane 0 of the group reserves, the group reads them by shuffle
         uint32_t base[3] = {0u, 0u, 0u};
         bool to_fb[3] = {false, false, true};
         if (FILL) {
-            uint32_t b0 = 0, b1 = 0, b2 = 0, f0 = 0, f1 = 0;
-            if (live && gl == 0) {
-                const uint32_t c0 = P.slot_cnt[3 * p], c1 = P.slot_cnt[3 * p + 1], c2 = P.slot_cnt[3 * p + 2];
-                f0 = (c0 && P.tile_flag[T0]) ? 1u : 0u;
-                f1 = (c1 && P.tile_flag[T1]) ? 1u : 0u;
-                const uint32_t nfb = c2 + (f0 ? c0 : 0u) + (f1 ? c1 : 0u);
-                if (nfb) b2 = atomicAdd(&ctr->n_fb, nfb);
-                if (c0) b0 = f0 ? b2 + c2 : P.tile_cnt[T0] + atomicAdd(&P.tile_fill[T0], c0);
-                if (c1) b1 = f1 ? b2 + c2 + (f0 ? c0 : 0u) : P.tile_cnt[T1] + atomicAdd(&P.tile_fill[T1], c1);
-            }
-            base[0] = __shfl(b0, gshift, 64); base[1] = __shfl(b1, gshift, 64); base[2] = __shfl(b2, gshift, 64);
-            to_fb[0] = __shfl(f0, gshift, 64) != 0u; to_fb[1] = __shfl(f1, gshift, 64) != 0u;
+            // stream sizes from the count pass; pairs of tiles over capacity go to the fallback list
+            uint32_t c0 = 0, c1 = 0, c2 = 0;
+            if (live) { c0 = P.slot_cnt[3 * p]; c1 = P.slot_cnt[3 * p + 1]; c2 = P.slot_cnt[3 * p + 2]; }
+            const bool f0 = c0 && P.tile_flag[T0], f1 = c1 && P.tile_flag[T1];
+            const uint32_t fb_total = c2 + (f0 ? c0 : 0u) + (f1 ? c1 : 0u);
+            // groups that are not live or have nothing for a stream get an index of their own
+            const uint32_t none = 0xFFFFFF00u + (uint32_t)(lane >> 3);
+            const uint32_t r0 = wave_group_add<true>(P.tile_fill, (live && c0 && !f0) ? T0 : none, f0 ? 0u : c0, lane);
+            const uint32_t r1 = wave_group_add<true>(P.tile_fill, (live && c1 && !f1) ? T1 : none, f1 ? 0u : c1, lane);
+            const uint32_t r2 = wave_group_add<true>(&ctr->n_fb, fb_total ? 0u : none, fb_total, lane);
+            base[2] = r2;
+            base[0] = f0 ? r2 + c2 : ((live && c0) ? P.tile_cnt[T0] + r0 : 0u);
+            base[1] = f1 ? r2 + c2 + (f0 ? c0 : 0u) : ((live && c1) ? P.tile_cnt[T1] + r1 : 0u);
+            to_fb[0] = f0; to_fb[1] = f1;
         }
         uint32_t cnt[3] = {0u, 0u, 0u};
         // six candidate ranges per slot, walked in lockstep by the eight groups of the wave
@@ -403,7 +434,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                     ncx = c.x + dx; ncy = c.y + dy;
                     const uint32_t bk = bucket_of(ncx, ncy, g);
                     qs = cell_start[bk]; qe = cell_start[bk + 1];
-                    stream = ((ncx >> g.tl) < txp) ? 1 : 0;
+                    stream = ((ncx >> g.tlx) < txp) ? 1 : 0;
                 } else {
                     qs = ns; qe = nact; check_cell = false;
                 }
@@ -442,10 +473,11 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                 }
             }
         }
-        if (!FILL && live && gl == 0) {
-            P.slot_cnt[3 * p] = cnt[0]; P.slot_cnt[3 * p + 1] = cnt[1]; P.slot_cnt[3 * p + 2] = cnt[2];
-            if (cnt[0]) atomicAdd(&P.tile_cnt[T0], cnt[0]);
-            if (cnt[1]) atomicAdd(&P.tile_cnt[T1], cnt[1]);
+        if (!FILL) {
+            if (live && gl == 0) { P.slot_cnt[3 * p] = cnt[0]; P.slot_cnt[3 * p + 1] = cnt[1]; P.slot_cnt[3 * p + 2] = cnt[2]; }
+            const uint32_t none = 0xFFFFFF00u + (uint32_t)(lane >> 3);
+            (void)wave_group_add<false>(P.tile_cnt, (live && cnt[0]) ? T0 : none, cnt[0], lane);
+            (void)wave_group_add<false>(P.tile_cnt, (live && cnt[1]) ? T1 : none, cnt[1], lane);
         }
     }
 }
@@ -457,14 +489,15 @@ struct BlockRanges { uint32_t ts[4], te[4], off[5]; };
 
 __device__ __forceinline__ void block_ranges(uint32_t t, const GridParams& g, const uint32_t* __restrict__ cell_start,
                                              BlockRanges& R) {
-    const uint32_t lx = g.gxl - g.tl;
+    const uint32_t lx = g.gxl - g.tlx;
     const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
+    const bool one_row = g.tly == g.gyl;  // strips: the block is two tiles, the upper two would repeat them
     uint32_t run = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t tk = tile_of(tx + (k & 1), ty + (k >> 1), g);
-        R.ts[k] = cell_start[tk << (2u * g.tl)];
-        R.te[k] = cell_start[(tk + 1u) << (2u * g.tl)];
+        R.ts[k] = cell_start[tk << (g.tlx + g.tly)];
+        R.te[k] = (one_row && k >= 2) ? R.ts[k] : cell_start[(tk + 1u) << (g.tlx + g.tly)];
         R.off[k] = run;
         run += R.te[k] - R.ts[k];
     }
@@ -502,9 +535,8 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(GridParams g, const uint32
         BlockRanges R;
         block_ranges(t, g, cell_start, R);
         nb = R.off[4];
-        const uint32_t lx = g.gxl - g.tl;
+        const uint32_t lx = g.gxl - g.tlx;
         if (cnt > kMaxP || nb > kMaxB) kind = 5u;
-        else if (cnt > kBatchP) kind = 4u;
         else kind = (t & 1u) | (((t >> lx) & 1u) << 1);
     }
     if (!__any(kind != 6u)) return;
@@ -524,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(GridParams g, const uint32
         base = __shfl(base, leader, 64);
         if (kind == k) {
             const uint32_t idx = base + (uint32_t)__popcll(bal & below);
-            if (k < 4) active[k * (g.ntiles >> 2) + idx] = t;
+            if (k < 4) active[k * g.pstride + idx] = t;
             else if (k == 4) big[idx] = t;
             else { tile_flag[t] = 1u; tile_cnt[t] = 0u; }
         }
@@ -572,10 +604,11 @@ __device__ __forceinline__ void batch_ranges(const uint32_t* __restrict__ tiles,
     __syncthreads();
     if (threadIdx.x < 4u * count) {
         const uint32_t t = tiles[threadIdx.x >> 2], k = threadIdx.x & 3u;
-        const uint32_t lx = g.gxl - g.tl;
+        const uint32_t lx = g.gxl - g.tlx;
         const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
         const uint32_t tk = tile_of(tx + (int32_t)(k & 1u), ty + (int32_t)(k >> 1), g);
-        const uint32_t a = cell_start[tk << (2u * g.tl)], b = cell_start[(tk + 1u) << (2u * g.tl)];
+        const uint32_t a = cell_start[tk << (g.tlx + g.tly)];
+        const uint32_t b = (g.tly == g.gyl && k >= 2u) ? a : cell_start[(tk + 1u) << (g.tlx + g.tly)];
         S.rs[threadIdx.x] = a;
         S.off[threadIdx.x + 1] = b - a;  // lengths first, prefix below
     }
@@ -615,7 +648,7 @@ __device__ __forceinline__ uint32_t batch_local(const BatchRanges& S, uint32_t j
 // the big list per batch, up to kMaxP pairs).  Per batch it writes the pairs colour-major as
 // (id a, id b, local a | local b << 16, colour | tile << 8) and a BatchDesc on the phase's table.
 template <uint32_t MP, bool BIG>
-__global__ __launch_bounds__(kBlock) void k_batch_color(GridParams g, uint32_t group, const uint32_t* __restrict__ cell_start,
+__global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t group, const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ sorted_id,
                                                          const uint4* __restrict__ filt,
                                                          const uint32_t* __restrict__ tile_start,
@@ -623,6 +656,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_color(GridParams g, uint32_t g
                                                          uint4* __restrict__ tpair, BatchDesc* __restrict__ batches,
                                                          uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr) {
     constexpr uint32_t MB = kMaxB;
+    constexpr uint32_t kBlock = 512;  // shadows the file-level constant: this kernel runs 512 threads
     __shared__ unsigned long long s_used[MB];
     __shared__ unsigned long long s_claim[MB * kClaim];
     __shared__ uint32_t s_deg[MB];
@@ -638,7 +672,7 @@ __global__ __launch_bounds__(kBlock) void k_batch_color(GridParams g, uint32_t g
     const uint32_t tid = threadIdx.x;
     const uint32_t ph_list = BIG ? 0u : blockIdx.y;
     const uint32_t nlist = BIG ? ctr->n_big : ctr->n_listed[ph_list];
-    const uint32_t* lst = BIG ? list : list + ph_list * (g.ntiles >> 2);
+    const uint32_t* lst = BIG ? list : list + ph_list * g.pstride;
     if (BIG) group = 1u;
     group = min(max(group, 1u), (uint32_t)kMaxGroup);
     const uint32_t ngroups = (nlist + group - 1u) / group;
@@ -798,12 +832,12 @@ __global__ __launch_bounds__(kBlock) void k_batch_color(GridParams g, uint32_t g
                 const uint32_t bstart = atomicAdd(&ctr->tp_cursor, np);
                 s_bstart = bstart;
                 const uint32_t t0 = s_tile[f];
-                const uint32_t lx = g.gxl - g.tl;
+                const uint32_t lx = g.gxl - g.tlx;
                 const uint32_t ph = (t0 & 1u) | (((t0 >> lx) & 1u) << 1);
                 BatchDesc d;
                 d.first = BIG ? ((e0 + f) | 0x80000000u) : (e0 + f);
                 d.count = c; d.bstart = bstart; d.np = np; d.ncol = nc; d.nb = nb; d.pad[0] = d.pad[1] = 0u;
-                batches[ph * (g.ntiles >> 2) + atomicAdd(&ctr->n_batches[ph], 1u)] = d;
+                batches[ph * g.pstride + atomicAdd(&ctr->n_batches[ph], 1u)] = d;
                 atomicMax(&ctr->n_colors, nc);
                 if (s_ovf) atomicOr(&ctr->overflow, kOvfColors);
             }
@@ -1027,6 +1061,8 @@ struct TileArrays {
 __device__ __forceinline__ void store_record(const ContactArrays& C, uint32_t slot, const PairRec& r) {
     C.misc[slot] = make_float2(r.rest, __uint_as_float((uint32_t)r.count));
     if (r.count == 0) return;
+    C.lam[slot] = make_float2(0.0f, 0.0f);
+    C.vpre[slot] = make_float2(r.vpre[0], r.vpre[1]);
     C.hdr[slot] = make_float4(r.nx, r.ny, r.mu_s, r.mu_d);
     C.anc0[slot] = make_float4(r.la[0][0], r.la[0][1], r.lb[0][0], r.lb[0][1]);
     if (r.count == 2) C.anc1[slot] = make_float4(r.la[1][0], r.la[1][1], r.lb[1][0], r.lb[1][1]);
@@ -1041,8 +1077,8 @@ __device__ __forceinline__ void load_record(const ContactArrays& C, uint32_t slo
     r.la[1][0] = r.la[1][1] = r.lb[1][0] = r.lb[1][1] = 0.0f;
     r.vpre[0] = r.vpre[1] = 0.0f; r.l0 = r.l1 = 0.0f;
     if (r.count == 0) return;
-    const float4 lamv = C.lamv[slot];
-    r.l0 = lamv.x; r.l1 = lamv.y; r.vpre[0] = lamv.z; r.vpre[1] = lamv.w;
+    const float2 lam = C.lam[slot], vp = C.vpre[slot];
+    r.l0 = lam.x; r.l1 = lam.y; r.vpre[0] = vp.x; r.vpre[1] = vp.y;
     const float4 hdr = C.hdr[slot];
     r.nx = hdr.x; r.ny = hdr.y; r.mu_s = hdr.z; r.mu_d = hdr.w;
     const float4 a0 = C.anc0[slot];
@@ -1065,7 +1101,6 @@ __device__ __forceinline__ void fallback_pos(const TileArrays& T, const Counters
         PairRec r;
         prepare_pair(B.pose[ab.x], B.shape[ab.x], B.vel[ab.x], B.pose[ab.y], B.shape[ab.y], B.vel[ab.y], B.poly, B.mats, sm, r);
         store_record(C, T.max_pairs + k, r);
-        if (r.count) C.lamv[T.max_pairs + k] = make_float4(0.0f, 0.0f, r.vpre[0], r.vpre[1]);
     }
     __syncthreads();
     const uint32_t nc = ctr->n_fb_colors;
@@ -1079,7 +1114,7 @@ __device__ __forceinline__ void fallback_pos(const TileArrays& T, const Counters
             float4 pa = B.pose[ab.x], pb = B.pose[ab.y];
             const float2 wa = B.mass[ab.x], wb = B.mass[ab.y];
             const bool moved = solve_pos_rec(r, pa, wa, pb, wb, max_corr);
-            C.lamv[T.max_pairs + k] = make_float4(r.l0, r.l1, r.vpre[0], r.vpre[1]);
+            C.lam[T.max_pairs + k] = make_float2(r.l0, r.l1);
             if (moved) {
                 if (wa.x > 0.0f || wa.y > 0.0f) B.pose[ab.x] = pa;
                 if (wb.x > 0.0f || wb.y > 0.0f) B.pose[ab.y] = pb;
@@ -1145,12 +1180,65 @@ __device__ __forceinline__ PairEnds pair_ends(const uint4& pr) {
     return e;
 }
 
-// Position solve of one phase.  A workgroup takes one tile at a time: the poses of the tile's
-// 2x2 block go to LDS, the narrowphase of the tile's pairs runs at those poses, then the tile's
-// colours are solved one after the other with a workgroup barrier in between, and the block's
-// dynamic bodies are written back.  Tiles of one phase have disjoint blocks.
-// Tiles with at most NT pairs keep one pair record per thread in registers; bigger ones (rare)
-// keep the records in the contact arrays and walk the pairs in strides of NT.
+// One pair of a batch as the colour loops see it: ends + record, fetched from the pair list and
+// the contact arrays one colour ahead of its use.
+struct PairSlot {
+    PairEnds e;
+    PairRec r;
+    bool valid;
+};
+
+template <bool VEL>
+__device__ __forceinline__ void fetch_pair(const TileArrays& T, const ContactArrays& C, uint32_t slot, bool in_range,
+                                           PairSlot& p) {
+    p.valid = false;
+    p.r.count = 0;
+    p.e = pair_ends(make_uint4(0, 0, 0, SFX_NO_COLOR));
+    if (!in_range) return;
+    const float2 misc = C.misc[slot];
+    const int count = (int)__float_as_uint(misc.y);
+    if (count == 0) return;
+    PairRec& r = p.r;
+    r.count = count; r.rest = misc.x;
+    r.l0 = r.l1 = 0.0f; r.vpre[0] = r.vpre[1] = 0.0f;
+    if (VEL) {
+        const float2 lam = C.lam[slot];
+        if (!(lam.x + lam.y > 0.0f)) { r.count = 0; return; }  // nothing was pushed: nothing to do in the velocity pass
+        const float2 vp = C.vpre[slot];
+        r.l0 = lam.x; r.l1 = lam.y; r.vpre[0] = vp.x; r.vpre[1] = vp.y;
+    }
+    p.e = pair_ends(T.tpair[slot]);
+    const float4 hdr = C.hdr[slot];
+    r.nx = hdr.x; r.ny = hdr.y; r.mu_s = hdr.z; r.mu_d = hdr.w;
+    const float4 a0 = C.anc0[slot];
+    r.la[0][0] = a0.x; r.la[0][1] = a0.y; r.lb[0][0] = a0.z; r.lb[0][1] = a0.w;
+    r.la[1][0] = r.la[1][1] = r.lb[1][0] = r.lb[1][1] = 0.0f;
+    if (count == 2) {
+        const float4 a1 = C.anc1[slot];
+        r.la[1][0] = a1.x; r.la[1][1] = a1.y; r.lb[1][0] = a1.z; r.lb[1][1] = a1.w;
+    }
+    p.valid = true;
+}
+
+// runs of equal colour in the colour-sorted pair list of a batch -> s_cs / s_ce (LDS, zeroed)
+template <int NT>
+__device__ __forceinline__ void colour_runs(const uint4* __restrict__ tpair, uint32_t start, uint32_t np,
+                                            uint32_t* s_cs, uint32_t* s_ce) {
+    for (uint32_t k = threadIdx.x; k < np; k += NT) {
+        const uint32_t c = tpair[start + k].w & 0xFFu;
+        if (c >= SFX_MAX_COLORS) continue;
+        if (k == 0 || (tpair[start + k - 1].w & 0xFFu) != c) s_cs[c] = k;
+        if (k + 1 == np || (tpair[start + k + 1].w & 0xFFu) != c) s_ce[c] = k + 1;
+    }
+}
+
+// Position solve of one phase.  A workgroup takes one batch of tiles at a time: the poses of the
+// batch's blocks go to LDS; the narrowphase of the batch's pairs runs at those poses and leaves
+// one record per pair in the contact arrays; then the colours are solved one after the other with
+// a workgroup barrier in between.  The pairs of a colour are a contiguous run of the
+// colour-sorted list and are taken by consecutive lanes; every lane fetches the record of its
+// next colour's pair while it solves the current one.  Finally the blocks' dynamic bodies are
+// written back.  Batches of one phase have disjoint blocks.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback, GridParams g, TileArrays T,
                                                   Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
@@ -1158,14 +1246,14 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback,
     __shared__ float4 s_pose[kMaxB];
     __shared__ float2 s_mass[kMaxB];
     __shared__ uint32_t s_gid[kMaxB];
+    __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
     __shared__ BatchRanges S;
     const uint32_t tid = threadIdx.x;
     const uint32_t nbat = ctr->n_batches[ph];
     for (uint32_t it = blockIdx.x; it < nbat; it += gridDim.x) {
         SFX_TT(tt0);
-        const BatchDesc d = T.batches[ph * (g.ntiles >> 2) + it];
-        const uint32_t* tiles = (d.first & 0x80000000u) ? T.big + (d.first & 0x7FFFFFFFu)
-                                                         : T.active + ph * (g.ntiles >> 2) + d.first;
+        const BatchDesc d = T.batches[ph * g.pstride + it];
+        const uint32_t* tiles = T.active + ph * g.pstride + d.first;
         batch_ranges(tiles, d.count, g, T.cell_start, S);
         const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
         for (uint32_t l = tid; l < nb; l += NT) {
@@ -1174,66 +1262,54 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback,
             s_pose[l] = B.pose[gid];
             s_mass[l] = B.mass[gid];
         }
+        if (tid < SFX_MAX_COLORS) { s_cs[tid] = 0u; s_ce[tid] = 0u; }
         __syncthreads();
         SFX_TT(tt1);
-        // narrowphase of pair k at the poses in LDS
-        auto prepare = [&](const PairEnds& e, PairRec& r) {
+        colour_runs<NT>(T.tpair, start, np, s_cs, s_ce);
+        // narrowphase of every pair at the poses in LDS (a large non-dynamic collider outside the
+        // blocks is read from global memory)
+        for (uint32_t k = tid; k < np; k += NT) {
+            const PairEnds e = pair_ends(T.tpair[start + k]);
             const float4 pa = e.la == kExt ? B.pose[e.a] : s_pose[e.la];
             const float4 pb = e.lb == kExt ? B.pose[e.b] : s_pose[e.lb];
+            PairRec r;
             prepare_pair(pa, B.shape[e.a], B.vel[e.a], pb, B.shape[e.b], B.vel[e.b], B.poly, B.mats, sm, r);
-        };
-        auto solve = [&](const PairEnds& e, PairRec& r) {
+            store_record(C, start + k, r);
+        }
+        __syncthreads();
+        SFX_TT(tt2);
+        auto solve = [&](uint32_t slot, PairSlot& p) {
+            const PairEnds& e = p.e;
             const bool ea = e.la == kExt, eb = e.lb == kExt;
             float4 pa = ea ? B.pose[e.a] : s_pose[e.la];
             float4 pb = eb ? B.pose[e.b] : s_pose[e.lb];
             const float2 wa = ea ? B.mass[e.a] : s_mass[e.la];
             const float2 wb = eb ? B.mass[e.b] : s_mass[e.lb];
-            if (solve_pos_rec(r, pa, wa, pb, wb, max_corr)) {
+            if (solve_pos_rec(p.r, pa, wa, pb, wb, max_corr)) {
                 if (!ea && (wa.x > 0.0f || wa.y > 0.0f)) s_pose[e.la] = pa;
                 if (!eb && (wb.x > 0.0f || wb.y > 0.0f)) s_pose[e.lb] = pb;
             }
+            C.lam[slot] = make_float2(p.r.l0, p.r.l1);
         };
-        if (np <= (uint32_t)NT) {
-            const bool mine = tid < np;
-            PairEnds e = pair_ends(make_uint4(0, 0, 0, SFX_NO_COLOR));
-            PairRec r;
-            r.count = 0;
-            if (mine) {
-                e = pair_ends(T.tpair[start + tid]);
-                prepare(e, r);
-                store_record(C, start + tid, r);
+        PairSlot cur, nxt;
+        fetch_pair<false>(T, C, start + s_cs[0] + tid, ncol > 0 && s_cs[0] + tid < s_ce[0], nxt);
+        for (uint32_t c = 0; c < ncol; ++c) {
+            cur = nxt;
+            const uint32_t k0 = s_cs[c] + tid, ce = s_ce[c];
+            {   // the next colour's pair, in flight while this one is solved
+                const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
+                fetch_pair<false>(T, C, start + s_cs[c1] + tid, c + 1u < ncol && s_cs[c1] + tid < s_ce[c1], nxt);
+            }
+            if (cur.valid) solve(start + k0, cur);
+            for (uint32_t k = k0 + NT; k < ce; k += NT) {  // colour runs longer than the workgroup (rare)
+                PairSlot more;
+                fetch_pair<false>(T, C, start + k, true, more);
+                if (more.valid) solve(start + k, more);
             }
             __syncthreads();
-            SFX_TT(tt2);
-            for (uint32_t c = 0; c < ncol; ++c) {
-                if (e.col == c && r.count) solve(e, r);
-                __syncthreads();
-            }
-            SFX_TT(tt3);
-            SFX_TT_ADD(1, tt1, tt2); SFX_TT_ADD(2, tt2, tt3); SFX_TT_ADD(5, 0ull, (unsigned long long)ncol);
-            if (mine && r.count) C.lamv[start + tid] = make_float4(r.l0, r.l1, r.vpre[0], r.vpre[1]);
-        } else {
-            for (uint32_t k = tid; k < np; k += NT) {
-                const PairEnds e = pair_ends(T.tpair[start + k]);
-                PairRec r;
-                prepare(e, r);
-                store_record(C, start + k, r);
-                if (r.count) C.lamv[start + k] = make_float4(0.0f, 0.0f, r.vpre[0], r.vpre[1]);
-            }
-            __syncthreads();
-            for (uint32_t c = 0; c < ncol; ++c) {
-                for (uint32_t k = tid; k < np; k += NT) {
-                    const PairEnds e = pair_ends(T.tpair[start + k]);
-                    if (e.col != c) continue;
-                    PairRec r;
-                    load_record(C, start + k, r);
-                    if (!r.count) continue;
-                    solve(e, r);
-                    C.lamv[start + k] = make_float4(r.l0, r.l1, r.vpre[0], r.vpre[1]);
-                }
-                __syncthreads();
-            }
         }
+        SFX_TT(tt3);
+        SFX_TT_ADD(1, tt1, tt2); SFX_TT_ADD(2, tt2, tt3); SFX_TT_ADD(5, 0ull, (unsigned long long)ncol);
         for (uint32_t l = tid; l < nb; l += NT) {
             const float2 w = s_mass[l];
             if (w.x > 0.0f || w.y > 0.0f) B.pose[s_gid[l]] = s_pose[l];
@@ -1253,17 +1329,18 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph, int with_fallback,
     __shared__ float4 s_vel[kMaxB];
     __shared__ float2 s_mass[kMaxB];
     __shared__ uint32_t s_gid[kMaxB];
+    __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
     __shared__ uint32_t s_shift;
     __shared__ BatchRanges S;
     const uint32_t tid = threadIdx.x;
     const uint32_t nbat = ctr->n_batches[ph];
     for (uint32_t it = blockIdx.x; it < nbat; it += gridDim.x) {
-        const BatchDesc d = T.batches[ph * (g.ntiles >> 2) + it];
-        const uint32_t* tiles = (d.first & 0x80000000u) ? T.big + (d.first & 0x7FFFFFFFu)
-                                                         : T.active + ph * (g.ntiles >> 2) + d.first;
+        const BatchDesc d = T.batches[ph * g.pstride + it];
+        const uint32_t* tiles = T.active + ph * g.pstride + d.first;
         batch_ranges(tiles, d.count, g, T.cell_start, S);
         const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
         if (tid == 0) s_shift = 0u;
+        if (tid < SFX_MAX_COLORS) { s_cs[tid] = 0u; s_ce[tid] = 0u; }
         for (uint32_t l = tid; l < nb; l += NT) {
             const uint32_t gid = T.sorted_id[batch_slot(S, 4u * d.count, l)];
             s_gid[l] = gid;
@@ -1272,41 +1349,37 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph, int with_fallback,
             s_mass[l] = B.mass[gid];
         }
         __syncthreads();
-        auto solve = [&](const PairEnds& e, const PairRec& r) {
+        colour_runs<NT>(T.tpair, start, np, s_cs, s_ce);
+        __syncthreads();
+        auto solve = [&](const PairSlot& p) {
+            const PairEnds& e = p.e;
             const bool ea = e.la == kExt, eb = e.lb == kExt;
             float4 pa = ea ? B.pose[e.a] : s_pose[e.la], va = ea ? B.vel[e.a] : s_vel[e.la];
             float4 pb = eb ? B.pose[e.b] : s_pose[e.lb], vb = eb ? B.vel[e.b] : s_vel[e.lb];
             const float2 wa = ea ? B.mass[e.a] : s_mass[e.la], wb = eb ? B.mass[e.b] : s_mass[e.lb];
-            const int ch = solve_vel_rec(r, pa, va, wa, pb, vb, wb, sp);
+            const int ch = solve_vel_rec(p.r, pa, va, wa, pb, vb, wb, sp);
             if (ch) {
                 if (!ea && (wa.x > 0.0f || wa.y > 0.0f)) { s_vel[e.la] = va; if (ch & 2) s_pose[e.la] = pa; }
                 if (!eb && (wb.x > 0.0f || wb.y > 0.0f)) { s_vel[e.lb] = vb; if (ch & 2) s_pose[e.lb] = pb; }
                 if (ch & 2) s_shift = 1u;
             }
         };
-        if (np <= (uint32_t)NT) {
-            PairEnds e = pair_ends(make_uint4(0, 0, 0, SFX_NO_COLOR));
-            PairRec r;
-            r.count = 0;
-            if (tid < np) {
-                e = pair_ends(T.tpair[start + tid]);
-                load_record(C, start + tid, r);
+        PairSlot cur, nxt;
+        fetch_pair<true>(T, C, start + s_cs[0] + tid, ncol > 0 && s_cs[0] + tid < s_ce[0], nxt);
+        for (uint32_t c = 0; c < ncol; ++c) {
+            cur = nxt;
+            const uint32_t k0 = s_cs[c] + tid, ce = s_ce[c];
+            {
+                const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
+                fetch_pair<true>(T, C, start + s_cs[c1] + tid, c + 1u < ncol && s_cs[c1] + tid < s_ce[c1], nxt);
             }
-            for (uint32_t c = 0; c < ncol; ++c) {
-                if (e.col == c && r.count) solve(e, r);
-                __syncthreads();
+            if (cur.valid) solve(cur);
+            for (uint32_t k = k0 + NT; k < ce; k += NT) {
+                PairSlot more;
+                fetch_pair<true>(T, C, start + k, true, more);
+                if (more.valid) solve(more);
             }
-        } else {
-            for (uint32_t c = 0; c < ncol; ++c) {
-                for (uint32_t k = tid; k < np; k += NT) {
-                    const PairEnds e = pair_ends(T.tpair[start + k]);
-                    if (e.col != c) continue;
-                    PairRec r;
-                    load_record(C, start + k, r);
-                    if (r.count) solve(e, r);
-                }
-                __syncthreads();
-            }
+            __syncthreads();
         }
         const bool shifted = s_shift != 0u;
         for (uint32_t l = tid; l < nb; l += NT) {
@@ -1395,7 +1468,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restri
         if (cnt) {
             mf += 1u;
             mf2 += (cnt == 2) ? 1u : 0u;
-            const float4 lv = C.lamv[slot];
+            const float2 lv = C.lam[slot];
             contacts += (lv.x > 0.0f) ? 1u : 0u;
             contacts += (cnt == 2 && lv.y > 0.0f) ? 1u : 0u;
         }

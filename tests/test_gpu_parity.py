@@ -103,8 +103,10 @@ def test_single_tick_positions(n, seed, extent):
     print("ulp pos", ulp_diff(gp, op), "rot", ulp_diff(gr, orr))
 
 
-@pytest.mark.parametrize("kw", [dict(tile_cells=2), dict(tile_cells=4), dict(tile_cells=8), dict(cell_size=0.2), dict(color_rounds=1)],
-                         ids=["tile2", "tile4", "tile8", "large_dynamic_fallback", "serial_colour_finish"])
+@pytest.mark.parametrize("kw", [dict(tile_cells=2), dict(tile_cells=4), dict(tile_cells=8), dict(cell_size=0.2), dict(color_rounds=1),
+                                dict(tile_cells_y=4096), dict(tile_cells=2, tile_cells_y=4)],
+                         ids=["tile2", "tile4", "tile8", "large_dynamic_fallback", "serial_colour_finish", "strips",
+                              "tile2x4"])
 def test_tiling_variants_match_oracle(kw):
     """Other tile sizes, a cell size that pushes big dynamic bodies onto the fallback list, and a
     colouring that leans on the serial finish: tiles, colours and one tick still match."""

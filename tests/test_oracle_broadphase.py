@@ -104,9 +104,42 @@ def test_tile_ownership_keeps_phases_disjoint(tile_cells, cell):
     assert coloring_valid(k, c, dyn, t)
     assert tile_phases_disjoint(k, t, dyn, tuple(rc.grid_log2), rc.tile_cells)
     st = w.stats()
-    assert st.max_tile_pairs <= 2048 and st.max_tile_bodies <= 512
+    assert st.max_tile_pairs <= 2048 and st.max_tile_bodies <= 1024
     if cell:
         assert st.n_fallback > 0 and st.n_large > 3
+
+
+def test_strip_tiles_have_two_phases():
+    """tile_cells_y >= grid height: full-height strips, only phases 0 and 1 (tile x parity)."""
+    s = scenes.random_soup(1500, seed=9, extent=7.0)
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    w = OracleWorld.from_scene(s, tile_cells_y=4096)
+    w.broadphase(DT)
+    rc = w.resolved_config()
+    assert rc.tile_cells == 1 and rc.tile_cells_y == 1 << rc.grid_log2[1]
+    k, c, t = w.pair_colors()
+    ok = t != 0xFFFFFFFF
+    assert ok.sum() > 1000
+    assert t[ok].max() < (1 << rc.grid_log2[0])            # one tile row
+    assert coloring_valid(k, c, dyn, t)
+    # tiles of one parity never share a dynamic body
+    a = (k >> np.uint64(32)).astype(np.int64)[ok]
+    b = (k & np.uint64(0xFFFFFFFF)).astype(np.int64)[ok]
+    tt = t[ok].astype(np.int64)
+    seen = {}
+    for body, tile in zip(np.concatenate([a, b]), np.concatenate([tt, tt])):
+        if dyn[body]:
+            assert seen.setdefault((tile & 1, body), tile) == tile
+    w2 = OracleWorld.from_scene(s, tile_cells=2, tile_cells_y=4)
+    w2.broadphase(DT)
+    rc2 = w2.resolved_config()
+    assert (rc2.tile_cells, rc2.tile_cells_y) == (2, 4)
+    k2, c2, t2 = w2.pair_colors()
+    assert coloring_valid(k2, c2, dyn, t2)
+    for _ in range(3):
+        w.step(DT)
+        w2.step(DT)
+    assert np.isfinite(w.poses()[0]).all() and np.isfinite(w2.poses()[0]).all()
 
 
 def test_overfull_tiles_fall_back():

@@ -2,7 +2,7 @@
 // scripts/dump_scene.py, optionally settles it with damping, runs ticks and prints timings.
 // Used for rocprofv3 runs (the program itself must follow `--`) and as a C example of the ABI.
 //
-//   sfx_run scene.bin [ticks=100] [settle=0] [tile_cells=0]
+//   sfx_run scene.bin [ticks=100] [settle=0] [tile_cells=0] [tile_cells_y=0]
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -59,10 +59,11 @@ static int upload(sfx_world* w, const Scene& s) {
 }
 
 int main(int argc, char** argv) {
-    if (argc < 2) { fprintf(stderr, "usage: %s scene.bin [ticks] [settle] [tile_cells]\n", argv[0]); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: %s scene.bin [ticks] [settle] [tile_cells] [tile_cells_y]\n", argv[0]); return 2; }
     const int ticks = argc > 2 ? atoi(argv[2]) : 100;
     const int settle = argc > 3 ? atoi(argv[3]) : 0;
     const int tile_cells = argc > 4 ? atoi(argv[4]) : 0;
+    const int tile_cells_y = argc > 5 ? atoi(argv[5]) : 0;
     Scene s;
     if (!load(argv[1], s)) { fprintf(stderr, "cannot read %s\n", argv[1]); return 2; }
     const float dt = 1.0f / 60.0f;
@@ -71,6 +72,7 @@ int main(int argc, char** argv) {
     sfx_default_config(&cfg);
     cfg.substeps = s.substeps;
     cfg.tile_cells = (uint32_t)tile_cells;
+    cfg.tile_cells_y = (uint32_t)tile_cells_y;
     if (settle > 0) {
         sfx_config c2 = cfg;
         c2.linear_damping = 3.3f; c2.angular_damping = 1.0f;
