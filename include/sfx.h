@@ -71,9 +71,12 @@ typedef struct sfx_config {
     uint32_t max_pairs;     /* candidate pair capacity; 0 = 12 * bodies              */
     uint32_t color_rounds;  /* parallel colouring rounds before the serial finish; 0 = 12 */
     uint32_t tile_cells;    /* solver tile width in grid cells: 1, 2, 4 or 8; 0 = 1       */
-    uint32_t tile_cells_y;  /* solver tile height in grid cells, a power of two; 0 = as wide;
-                               anything >= the grid height makes full-height strips: then a
-                               sweep has two phases instead of four (wide, shallow scenes)  */
+    uint32_t tile_cells_y;  /* solver tile height in grid cells, a power of two; anything >= the
+                               grid height makes full-height strips: then a sweep has two
+                               phases instead of four.  0 = automatic, decided when the colliders
+                               are uploaded: strips if no two neighbouring tile columns hold more
+                               than 3/4 SFX_TILE_MAX_BODIES colliders at that time (wide, shallow
+                               scenes), else as high as wide                                     */
     float restitution_threshold; /* restitution is dropped when |vn_pre| <= this * |g| * h; 0 = 2.0 */
     float max_depenetration_velocity; /* a contact corrects at most this * h of penetration per
                                substep (m/s); 0 = 3.0; negative = unlimited            */

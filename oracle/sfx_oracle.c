@@ -164,6 +164,13 @@ static float shape_diameter(const sfo_world* w, const sfx_collider* c) {
     }
 }
 
+static int32_t cell_coord(float lo, float inv_cell) {
+    float f = floorf(lo * inv_cell);
+    if (!(f > -1073741824.0f)) f = -1073741824.0f;
+    if (f > 1073741824.0f) f = 1073741824.0f;
+    return (int32_t)f;
+}
+
 static uint32_t ceil_log2(uint32_t v) {
     uint32_t l = 0;
     while ((1u << l) < v && l < 31) ++l;
@@ -198,7 +205,25 @@ static void resolve_grid(sfo_world* w) {
     if (gy < 2) gy = 2;
     /* tile height: as wide by default; a power of two; the grid height at most (= strips) */
     w->tly = w->tlx;
-    if (w->cfg.tile_cells_y) { w->tly = 0; while (w->tly < 31 && (2u << w->tly) <= w->cfg.tile_cells_y) w->tly++; }
+    if (w->cfg.tile_cells_y) {
+        w->tly = 0;
+        while (w->tly < 31 && (2u << w->tly) <= w->cfg.tile_cells_y) w->tly++;
+    } else {
+        /* automatic: colliders per tile column (centre x, wrapped like the cells) at upload time */
+        uint32_t ncol = 1u << (gx - w->tlx), worst = 0;
+        uint32_t* cnt = (uint32_t*)calloc(ncol, sizeof(uint32_t));
+        for (uint32_t i = 0; i < w->n; ++i) {
+            if (w->col[i].type == SFX_SHAPE_NONE) continue;
+            int32_t cx = cell_coord(w->pos[2 * i], w->inv_cell);
+            cnt[((uint32_t)cx >> w->tlx) & (ncol - 1u)]++;   /* two's complement: >> then & wraps negatives too */
+        }
+        for (uint32_t c = 0; c < ncol; ++c) {
+            uint32_t two = cnt[c] + cnt[(c + 1u) & (ncol - 1u)];
+            if (two > worst) worst = two;
+        }
+        free(cnt);
+        if (worst <= 3u * SFX_TILE_MAX_BODIES / 4u) w->tly = gy;
+    }
     if (w->tly > gy) w->tly = gy;
     if (gx > 12) gx = 12;
     if (gy > 12) gy = 12;
@@ -563,12 +588,6 @@ size_t sfo_pairs_sweep(const sfo_world* w, uint64_t* keys, size_t cap) {
  * (ascending id inside a bucket), large ones are kept in an ascending-id list.  Emission:
  * per small slot the own cell (later slots only), then the forward neighbours
  * (1,0) (-1,1) (0,1) (1,1), then every large; per large slot every later large. */
-static int32_t cell_coord(float lo, float inv_cell) {
-    float f = floorf(lo * inv_cell);
-    if (!(f > -1073741824.0f)) f = -1073741824.0f;
-    if (f > 1073741824.0f) f = 1073741824.0f;
-    return (int32_t)f;
-}
 
 static void emit_pair(sfo_world* w, uint32_t i, uint32_t j) {
     if (!aabb_overlap(&w->aabb[4 * i], &w->aabb[4 * j]) || !pair_filter(w, i, j)) return;

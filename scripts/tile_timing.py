@@ -10,7 +10,11 @@ _abi._lib = lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
 s = scenes.mixed_pile(n=n, width=max(50, n // 100))
 s = bench.settle(s, 0, frames=400)
-w = World.from_scene(s)
+kw = {}
+for a in sys.argv[2:]:
+    k, v = a.split("=")
+    kw[k] = int(v)
+w = World.from_scene(s, **kw)
 out = (C.c_ulonglong * 8)()
 lib.sfx_debug_tile_timing.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
 for _ in range(10):
@@ -22,4 +26,4 @@ lib.sfx_debug_tile_timing(w.handle, out, 1)
 o = list(out)
 tiles = max(o[4], 1)
 print("per tile (us): load %.2f narrow %.2f colours %.2f total %.2f  tiles/launch %.0f  mean colours %.2f" % (
-    o[0] / tiles / 100, o[1] / tiles / 100, o[2] / tiles / 100, o[3] / tiles / 100, tiles / 160.0, o[5] / tiles))
+    o[0] / tiles / 100, o[1] / tiles / 100, o[2] / tiles / 100, o[3] / tiles / 100, tiles / (40.0 * (2 if kw.get("tile_cells_y", 0) >= 4096 else 4)), o[5] / tiles))

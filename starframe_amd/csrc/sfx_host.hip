@@ -57,7 +57,7 @@ struct sfx_world {
     // scene
     uint32_t n = 0, m = 0, n_mats = 0, n_poly = 0;
     bool have_bodies = false, have_colliders = false, have_mats = false;
-    std::vector<float> h_inv_mass, h_inv_inertia;
+    std::vector<float> h_inv_mass, h_inv_inertia, h_pos_x;
     std::vector<sfx_collider> h_col;
     std::vector<float> h_poly;
     DevBuf<float4> pose, prev, vel, shape, poly, mats, aabb, sorted_aabb;
@@ -215,7 +215,25 @@ void resolve_grid(sfx_world* w) {
     gy = std::min(std::max(gy, 2u), 12u);
     // tile height: as wide by default; a power of two; the grid height at most (= strips)
     w->tly = w->tlx;
-    if (w->cfg.tile_cells_y) { w->tly = 0; while (w->tly < 31 && (2u << w->tly) <= w->cfg.tile_cells_y) w->tly++; }
+    if (w->cfg.tile_cells_y) {
+        w->tly = 0;
+        while (w->tly < 31 && (2u << w->tly) <= w->cfg.tile_cells_y) w->tly++;
+    } else {
+        // automatic: colliders per tile column (centre x, wrapped like the cells) at upload time
+        const uint32_t ncol = 1u << (gx - w->tlx);
+        std::vector<uint32_t> cnt(ncol, 0u);
+        for (uint32_t i = 0; i < w->n; ++i) {
+            if (w->h_col[i].type == SFX_SHAPE_NONE) continue;
+            float f = floorf(w->h_pos_x[i] * w->inv_cell);
+            if (!(f > -1073741824.0f)) f = -1073741824.0f;
+            if (f > 1073741824.0f) f = 1073741824.0f;
+            const int32_t cx = (int32_t)f;
+            cnt[((uint32_t)cx >> w->tlx) & (ncol - 1u)]++;
+        }
+        uint32_t worst = 0;
+        for (uint32_t c = 0; c < ncol; ++c) worst = std::max(worst, cnt[c] + cnt[(c + 1u) & (ncol - 1u)]);
+        if (worst <= 3u * SFX_TILE_MAX_BODIES / 4u) w->tly = gy;
+    }
     w->tly = std::min(w->tly, gy);
     w->gxl = gx; w->gyl = gy;
     w->ncell = (1u << gx) * (1u << gy);
@@ -545,6 +563,8 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
     std::vector<float2> hm(std::max(n, 1u));
     w->h_inv_mass.assign(inv_mass, inv_mass + n);
     w->h_inv_inertia.assign(inv_inertia, inv_inertia + n);
+    w->h_pos_x.resize(n);
+    for (uint32_t i = 0; i < n; ++i) w->h_pos_x[i] = pos[2 * i];
     for (uint32_t i = 0; i < n; ++i) {
         hp[i] = make_float4(pos[2 * i], pos[2 * i + 1], rot[2 * i], rot[2 * i + 1]);
         hv[i] = make_float4(vel[2 * i], vel[2 * i + 1], angvel[i], 0.0f);

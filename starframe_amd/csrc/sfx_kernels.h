@@ -1188,36 +1188,64 @@ struct PairSlot {
     bool valid;
 };
 
+// The raw fields of one pair as loaded: every field unconditionally and at once (one round trip,
+// no load waits for another, nothing branches on loaded data), decoded only when the pair's colour
+// comes up -- so the loads of colour c + 1 are in flight while colour c is solved.
+struct RawSlot {
+    float2 misc, lam, vp;
+    uint4 pr;
+    float4 hdr, a0, a1;
+    bool in_range;
+};
+
+template <bool VEL>
+__device__ __forceinline__ void fetch_raw(const TileArrays& T, const ContactArrays& C, uint32_t slot, bool in_range,
+                                          RawSlot& q) {
+    q.in_range = in_range;
+    q.misc = make_float2(0.0f, 0.0f); q.lam = q.misc; q.vp = q.misc;
+    q.pr = make_uint4(0, 0, 0, SFX_NO_COLOR);
+    q.hdr = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q.a0 = q.hdr; q.a1 = q.hdr;
+    if (!in_range) return;
+    q.misc = C.misc[slot];
+    q.pr = T.tpair[slot];
+    q.hdr = C.hdr[slot];
+    q.a0 = C.anc0[slot];
+    q.a1 = C.anc1[slot];
+    if (VEL) { q.lam = C.lam[slot]; q.vp = C.vpre[slot]; }
+}
+
+template <bool VEL>
+__device__ __forceinline__ void decode_raw(const RawSlot& q, PairSlot& p) {
+    p.valid = false;
+    p.r.count = 0;
+    p.e = pair_ends(q.pr);
+    const int count = (int)__float_as_uint(q.misc.y);
+    if (!q.in_range || count == 0) return;
+    if (VEL && !(q.lam.x + q.lam.y > 0.0f)) return;  // nothing was pushed: nothing to do in the velocity pass
+    PairRec& r = p.r;
+    r.count = count; r.rest = q.misc.x;
+    r.l0 = q.lam.x; r.l1 = q.lam.y; r.vpre[0] = q.vp.x; r.vpre[1] = q.vp.y;
+    r.nx = q.hdr.x; r.ny = q.hdr.y; r.mu_s = q.hdr.z; r.mu_d = q.hdr.w;
+    r.la[0][0] = q.a0.x; r.la[0][1] = q.a0.y; r.lb[0][0] = q.a0.z; r.lb[0][1] = q.a0.w;
+    const bool two = count == 2;
+    r.la[1][0] = two ? q.a1.x : 0.0f; r.la[1][1] = two ? q.a1.y : 0.0f;
+    r.lb[1][0] = two ? q.a1.z : 0.0f; r.lb[1][1] = two ? q.a1.w : 0.0f;
+    p.valid = true;
+}
+
 template <bool VEL>
 __device__ __forceinline__ void fetch_pair(const TileArrays& T, const ContactArrays& C, uint32_t slot, bool in_range,
                                            PairSlot& p) {
-    p.valid = false;
-    p.r.count = 0;
-    p.e = pair_ends(make_uint4(0, 0, 0, SFX_NO_COLOR));
-    if (!in_range) return;
-    const float2 misc = C.misc[slot];
-    const int count = (int)__float_as_uint(misc.y);
-    if (count == 0) return;
-    PairRec& r = p.r;
-    r.count = count; r.rest = misc.x;
-    r.l0 = r.l1 = 0.0f; r.vpre[0] = r.vpre[1] = 0.0f;
-    if (VEL) {
-        const float2 lam = C.lam[slot];
-        if (!(lam.x + lam.y > 0.0f)) { r.count = 0; return; }  // nothing was pushed: nothing to do in the velocity pass
-        const float2 vp = C.vpre[slot];
-        r.l0 = lam.x; r.l1 = lam.y; r.vpre[0] = vp.x; r.vpre[1] = vp.y;
-    }
-    p.e = pair_ends(T.tpair[slot]);
-    const float4 hdr = C.hdr[slot];
-    r.nx = hdr.x; r.ny = hdr.y; r.mu_s = hdr.z; r.mu_d = hdr.w;
-    const float4 a0 = C.anc0[slot];
-    r.la[0][0] = a0.x; r.la[0][1] = a0.y; r.lb[0][0] = a0.z; r.lb[0][1] = a0.w;
-    r.la[1][0] = r.la[1][1] = r.lb[1][0] = r.lb[1][1] = 0.0f;
-    if (count == 2) {
-        const float4 a1 = C.anc1[slot];
-        r.la[1][0] = a1.x; r.la[1][1] = a1.y; r.lb[1][0] = a1.z; r.lb[1][1] = a1.w;
-    }
-    p.valid = true;
+    RawSlot q;
+    fetch_raw<VEL>(T, C, slot, in_range, q);
+    decode_raw<VEL>(q, p);
+}
+
+// Workgroup barrier for steps that hand data over through LDS only: waits for the LDS traffic,
+// not for the global loads and stores in flight (the record prefetch of the next colour, the
+// lambda stores), which only their own lane depends on.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
 // runs of equal colour in the colour-sorted pair list of a batch -> s_cs / s_ce (LDS, zeroed)
@@ -1291,14 +1319,15 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback,
             }
             C.lam[slot] = make_float2(p.r.l0, p.r.l1);
         };
-        PairSlot cur, nxt;
-        fetch_pair<false>(T, C, start + s_cs[0] + tid, ncol > 0 && s_cs[0] + tid < s_ce[0], nxt);
+        RawSlot nxt;
+        fetch_raw<false>(T, C, start + s_cs[0] + tid, ncol > 0 && s_cs[0] + tid < s_ce[0], nxt);
         for (uint32_t c = 0; c < ncol; ++c) {
-            cur = nxt;
+            PairSlot cur;
+            decode_raw<false>(nxt, cur);
             const uint32_t k0 = s_cs[c] + tid, ce = s_ce[c];
             {   // the next colour's pair, in flight while this one is solved
                 const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
-                fetch_pair<false>(T, C, start + s_cs[c1] + tid, c + 1u < ncol && s_cs[c1] + tid < s_ce[c1], nxt);
+                fetch_raw<false>(T, C, start + s_cs[c1] + tid, c + 1u < ncol && s_cs[c1] + tid < s_ce[c1], nxt);
             }
             if (cur.valid) solve(start + k0, cur);
             for (uint32_t k = k0 + NT; k < ce; k += NT) {  // colour runs longer than the workgroup (rare)
@@ -1306,8 +1335,9 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback,
                 fetch_pair<false>(T, C, start + k, true, more);
                 if (more.valid) solve(start + k, more);
             }
-            __syncthreads();
+            lds_barrier();
         }
+        __syncthreads();
         SFX_TT(tt3);
         SFX_TT_ADD(1, tt1, tt2); SFX_TT_ADD(2, tt2, tt3); SFX_TT_ADD(5, 0ull, (unsigned long long)ncol);
         for (uint32_t l = tid; l < nb; l += NT) {
@@ -1364,14 +1394,15 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph, int with_fallback,
                 if (ch & 2) s_shift = 1u;
             }
         };
-        PairSlot cur, nxt;
-        fetch_pair<true>(T, C, start + s_cs[0] + tid, ncol > 0 && s_cs[0] + tid < s_ce[0], nxt);
+        RawSlot nxt;
+        fetch_raw<true>(T, C, start + s_cs[0] + tid, ncol > 0 && s_cs[0] + tid < s_ce[0], nxt);
         for (uint32_t c = 0; c < ncol; ++c) {
-            cur = nxt;
+            PairSlot cur;
+            decode_raw<true>(nxt, cur);
             const uint32_t k0 = s_cs[c] + tid, ce = s_ce[c];
             {
                 const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
-                fetch_pair<true>(T, C, start + s_cs[c1] + tid, c + 1u < ncol && s_cs[c1] + tid < s_ce[c1], nxt);
+                fetch_raw<true>(T, C, start + s_cs[c1] + tid, c + 1u < ncol && s_cs[c1] + tid < s_ce[c1], nxt);
             }
             if (cur.valid) solve(cur);
             for (uint32_t k = k0 + NT; k < ce; k += NT) {
@@ -1379,8 +1410,9 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph, int with_fallback,
                 fetch_pair<true>(T, C, start + k, true, more);
                 if (more.valid) solve(more);
             }
-            __syncthreads();
+            lds_barrier();
         }
+        __syncthreads();
         const bool shifted = s_shift != 0u;
         for (uint32_t l = tid; l < nb; l += NT) {
             const float2 w = s_mass[l];

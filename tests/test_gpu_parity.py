@@ -103,9 +103,10 @@ def test_single_tick_positions(n, seed, extent):
     print("ulp pos", ulp_diff(gp, op), "rot", ulp_diff(gr, orr))
 
 
-@pytest.mark.parametrize("kw", [dict(tile_cells=2), dict(tile_cells=4), dict(tile_cells=8), dict(cell_size=0.2), dict(color_rounds=1),
+@pytest.mark.parametrize("kw", [dict(tile_cells=1, tile_cells_y=1), dict(tile_cells=2, tile_cells_y=2), dict(tile_cells=4, tile_cells_y=4),
+                                dict(tile_cells=8, tile_cells_y=8), dict(cell_size=0.2, tile_cells_y=1), dict(color_rounds=1),
                                 dict(tile_cells_y=4096), dict(tile_cells=2, tile_cells_y=4)],
-                         ids=["tile2", "tile4", "tile8", "large_dynamic_fallback", "serial_colour_finish", "strips",
+                         ids=["tile1", "tile2", "tile4", "tile8", "large_dynamic_fallback", "serial_colour_finish", "strips",
                               "tile2x4"])
 def test_tiling_variants_match_oracle(kw):
     """Other tile sizes, a cell size that pushes big dynamic bodies onto the fallback list, and a

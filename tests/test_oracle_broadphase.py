@@ -96,7 +96,7 @@ def test_tile_ownership_keeps_phases_disjoint(tile_cells, cell):
     tiles of one phase never share a dynamic body, colours are valid per tile."""
     s = scenes.random_soup(1500, seed=9, extent=7.0)
     dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
-    w = OracleWorld.from_scene(s, tile_cells=tile_cells, cell_size=cell)
+    w = OracleWorld.from_scene(s, tile_cells=tile_cells, tile_cells_y=tile_cells, cell_size=cell)
     w.broadphase(DT)
     k, c, t = w.pair_colors()
     rc = w.resolved_config()
@@ -156,6 +156,8 @@ def test_overfull_tiles_fall_back():
     s = b.build()
     dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
     w = OracleWorld.from_scene(s)
+    rc = w.resolved_config()
+    assert rc.tile_cells_y == rc.tile_cells == 1   # 1600 colliders in two columns: no automatic strips
     w.broadphase(DT)
     k, c, t = w.pair_colors()
     st = w.stats()
@@ -188,4 +190,4 @@ def test_auto_grid_and_cell_resolution():
     assert rc.cell_size > 0.4
     assert rc.grid_log2[0] == rc.grid_log2[1] == 5
     assert rc.max_pairs == 12 * s.n
-    assert rc.tile_cells == 1
+    assert rc.tile_cells == 1 and rc.tile_cells_y == 32   # sparse scene: automatic full-height strips
