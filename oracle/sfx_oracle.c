@@ -293,9 +293,9 @@ void sfo_resolved_config(const sfo_world* w, sfx_config* out) {
 /* ------------------------------------------------------------------ colouring
  * [DESIGN] DESIGN.md "Contract / colouring".  Edge colouring of a constraint graph: two
  * constraints that share a dynamic body never get the same colour.  `rounds` parallel rounds
- * (each uncoloured edge proposes a hashed colour out of a small window of colours free at
- * both ends; per (body, colour mod 4) the lowest priority wins; an edge is coloured when it
- * wins at both dynamic ends), then a serial first-fit finish in ascending key order.
+ * (each uncoloured edge proposes the lowest colour free at both ends; per (body, colour mod 4)
+ * the lowest hashed priority of the round wins; an edge is coloured when it wins at both
+ * dynamic ends), then a serial first-fit finish in ascending key order.
  * Priorities and hashes depend only on the edge's key (u, v) -- the two body ids of a
  * candidate pair, or the index of a joint -- never on its place in a list, so the result is
  * the same for every enumeration order of the same edge set. */
@@ -303,11 +303,6 @@ void sfo_resolved_config(const sfo_world* w, sfx_config* out) {
 static uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
-}
-
-static int kth_set_bit(uint64_t m, uint32_t k) {
-    for (uint32_t i = 0; i < k; ++i) m &= m - 1;
-    return __builtin_ctzll(m);
 }
 
 static uint32_t edge_hash(uint32_t u, uint32_t v, uint32_t r) {
@@ -322,21 +317,19 @@ static uint64_t edge_prio(uint32_t u, uint32_t v, uint32_t r, uint32_t h) {
 
 typedef struct {
     uint64_t* used;  /* [n_bodies] colours taken, all 0 between calls   */
-    uint32_t* deg;   /* [n_bodies] uncoloured incident edges, 0 between */
     uint64_t* claim; /* [n_bodies][4], all ~0 between calls             */
 } color_scratch;
 
 static int color_scratch_init(color_scratch* cs, uint32_t n_bodies) {
     size_t n = n_bodies ? n_bodies : 1;
     cs->used = (uint64_t*)calloc(n, sizeof(uint64_t));
-    cs->deg = (uint32_t*)calloc(n, sizeof(uint32_t));
     cs->claim = (uint64_t*)malloc(n * 4 * sizeof(uint64_t));
-    if (!cs->used || !cs->deg || !cs->claim) return -1;
+    if (!cs->used || !cs->claim) return -1;
     memset(cs->claim, 0xFF, n * 4 * sizeof(uint64_t));
     return 0;
 }
 
-static void color_scratch_free(color_scratch* cs) { free(cs->used); free(cs->deg); free(cs->claim); }
+static void color_scratch_free(color_scratch* cs) { free(cs->used); free(cs->claim); }
 
 typedef struct { uint64_t key; uint32_t idx; } key_idx;
 static int cmp_key_idx(const void* a, const void* b) {
@@ -352,15 +345,12 @@ static uint32_t color_edges(color_scratch* cs, uint32_t ne, const uint32_t* idx,
                             const uint32_t* eb, const uint32_t* ku, const uint32_t* kv, const uint8_t* dyn,
                             uint32_t rounds, uint8_t* color, uint32_t* leftover, uint32_t* overflow) {
     uint64_t *used = cs->used, *claim = cs->claim;
-    uint32_t* deg = cs->deg;
     uint8_t* prop = (uint8_t*)malloc(ne ? ne : 1);
     uint64_t* prio = (uint64_t*)malloc((ne ? ne : 1) * sizeof(uint64_t));
 #define DYN(x) ((x) != SFX_WORLD_BODY && dyn[(x)])
     for (uint32_t q = 0; q < ne; ++q) {
         uint32_t e = idx ? idx[q] : q;
         color[e] = NO_COLOR;
-        if (DYN(ea[e])) deg[ea[e]]++;
-        if (DYN(eb[e])) deg[eb[e]]++;
     }
     for (uint32_t r = 0; r < rounds; ++r) {
         for (uint32_t q = 0; q < ne; ++q) { /* propose */
@@ -370,15 +360,8 @@ static uint32_t color_edges(color_scratch* cs, uint32_t ne, const uint32_t* idx,
             int da = DYN(a), db = DYN(b);
             uint64_t freem = ~((da ? used[a] : 0) | (db ? used[b] : 0));
             if (freem == 0) { prop[q] = NO_COLOR; *overflow = 1; continue; }
-            uint32_t dg = 1;
-            if (da && deg[a] > dg) dg = deg[a];
-            if (db && deg[b] > dg) dg = deg[b];
-            if (dg > 8) dg = 8;
-            uint32_t nfree = (uint32_t)__builtin_popcountll(freem);
-            if (dg > nfree) dg = nfree;
+            uint32_t c = (uint32_t)__builtin_ctzll(freem); /* first fit: the lowest colour free at both ends */
             uint32_t h = edge_hash(ku[e], kv[e], r);
-            uint32_t k = mix32(h ^ 0xA5A5A5A5u) % dg;
-            uint32_t c = (uint32_t)kth_set_bit(freem, k);
             prop[q] = (uint8_t)c;
             uint64_t p = edge_prio(ku[e], kv[e], r, h);
             prio[q] = p;
@@ -394,8 +377,8 @@ static uint32_t color_edges(color_scratch* cs, uint32_t ne, const uint32_t* idx,
                       (!db || claim[(size_t)b * 4 + (c & 3)] == prio[q]);
             if (!win) continue;
             color[e] = (uint8_t)c;
-            if (da) { used[a] |= 1ull << c; deg[a]--; }
-            if (db) { used[b] |= 1ull << c; deg[b]--; }
+            if (da) used[a] |= 1ull << c;
+            if (db) used[b] |= 1ull << c;
         }
     }
     /* serial first-fit finish, ascending key */
@@ -424,8 +407,8 @@ static uint32_t color_edges(color_scratch* cs, uint32_t ne, const uint32_t* idx,
     for (uint32_t q = 0; q < ne; ++q) {
         uint32_t e = idx ? idx[q] : q, a = ea[e], b = eb[e];
         if (color[e] != NO_COLOR && color[e] + 1u > nc) nc = color[e] + 1u;
-        if (DYN(a)) { used[a] = 0; deg[a] = 0; memset(&claim[(size_t)a * 4], 0xFF, 4 * sizeof(uint64_t)); }
-        if (DYN(b)) { used[b] = 0; deg[b] = 0; memset(&claim[(size_t)b * 4], 0xFF, 4 * sizeof(uint64_t)); }
+        if (DYN(a)) { used[a] = 0; memset(&claim[(size_t)a * 4], 0xFF, 4 * sizeof(uint64_t)); }
+        if (DYN(b)) { used[b] = 0; memset(&claim[(size_t)b * 4], 0xFF, 4 * sizeof(uint64_t)); }
     }
 #undef DYN
     free(prop); free(prio); free(left);

@@ -77,7 +77,7 @@ struct sfx_world {
     uint32_t large_cap = 0, ntiles = 4, fb_cap = 0, tlx = 0, tly = 0;
     // colouring of global edge lists (joints at upload, the fallback list every tick)
     DevBuf<unsigned long long> used, claim;
-    DevBuf<uint32_t> deg, left_list;
+    DevBuf<uint32_t> left_list;
     DevBuf<uint8_t> pcolor, prop;
     DevBuf<Counters> jctr;
     // slab halos
@@ -338,7 +338,7 @@ void color_global(sfx_world* w, const uint2* edges, const uint32_t* n_edges, uin
                   uint2* sorted, uint32_t* start, uint32_t* n_colors_out, Counters* ctr, int tick_totals) {
     GlobalColor A;
     A.edges = edges; A.n_edges = n_edges; A.cap = cap; A.key_by_index = key_by_index;
-    A.filt = w->filt.p; A.used = w->used.p; A.deg = w->deg.p; A.claim = w->claim.p;
+    A.filt = w->filt.p; A.used = w->used.p; A.claim = w->claim.p;
     A.color = w->pcolor.p; A.prop = w->prop.p; A.left_list = w->left_list.p;
     A.sorted = sorted; A.start = start; A.n_colors_out = n_colors_out;
     A.rounds = w->cfg.color_rounds; A.ctr = ctr; A.tick_totals = tick_totals;
@@ -510,7 +510,7 @@ void sfx_destroy(sfx_world* w) {
     w->fpairs.release(); w->fsorted.release();
     w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->scan_sums.release();
     w->cellxy.release(); w->sorted_cell.release();
-    w->used.release(); w->claim.release(); w->deg.release(); w->left_list.release();
+    w->used.release(); w->claim.release(); w->left_list.release();
     w->pcolor.release(); w->prop.release(); w->jctr.release(); w->dbg.release();
     w->halo_send_idx.release(); w->halo_recv_idx.release(); w->halo_send.release(); w->halo_recv.release();
     w->c_hdr.release(); w->c_anc0.release(); w->c_anc1.release(); w->c_lam.release(); w->c_vpre.release(); w->c_misc.release();
@@ -556,7 +556,7 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
         ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
         ALLOC(w, w->bucket, c); ALLOC(w, w->tmp_id, c); ALLOC(w, w->sorted_id, c); ALLOC(w, w->large_tmp, c);
         ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
-        ALLOC(w, w->used, c); ALLOC(w, w->deg, c); ALLOC(w, w->claim, c * kClaim);
+        ALLOC(w, w->used, c); ALLOC(w, w->claim, c * kClaim);
         w->large_cap = n;
     }
     std::vector<float4> hp(std::max(n, 1u)), hv(std::max(n, 1u));

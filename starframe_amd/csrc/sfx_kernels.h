@@ -659,7 +659,6 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
     constexpr uint32_t kBlock = 512;  // shadows the file-level constant: this kernel runs 512 threads
     __shared__ unsigned long long s_used[MB];
     __shared__ unsigned long long s_claim[MB * kClaim];
-    __shared__ uint32_t s_deg[MB];
     __shared__ uint8_t s_dyn[MB];
     __shared__ uint32_t s_a[MP], s_b[MP];
     __shared__ uint16_t s_la[MP], s_lb[MP], s_left[MP], s_srt[MP];
@@ -718,7 +717,6 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 const uint32_t gid = sorted_id[batch_slot(S, 4u * c, l)];
                 s_dyn[l] = (uint8_t)(filt[gid].w != 0u);
                 s_used[l] = 0ull;
-                s_deg[l] = 0u;
 #pragma unroll
                 for (int k = 0; k < kClaim; ++k) s_claim[l * kClaim + k] = ~0ull;
             }
@@ -734,12 +732,6 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
             }
             __syncthreads();
 #define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
-            for (uint32_t e = tid; e < np; e += kBlock) {
-                const uint32_t la = s_la[e], lb = s_lb[e];
-                if (TDYN(la)) atomicAdd(&s_deg[la], 1u);
-                if (TDYN(lb)) atomicAdd(&s_deg[lb], 1u);
-            }
-            __syncthreads();
             for (uint32_t r = 0; r < rounds; ++r) {
                 int open_edges = 0;
                 for (uint32_t e = tid; e < np; e += kBlock) open_edges |= (s_col[e] == SFX_NO_COLOR) ? 1 : 0;
@@ -750,14 +742,8 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                     const bool da = TDYN(la), db = TDYN(lb);
                     const unsigned long long freem = ~((da ? s_used[la] : 0ull) | (db ? s_used[lb] : 0ull));
                     if (freem == 0ull) { s_prop[e] = SFX_NO_COLOR; s_ovf = 1u; continue; }
-                    uint32_t dg = 1;
-                    if (da) dg = max(dg, s_deg[la]);
-                    if (db) dg = max(dg, s_deg[lb]);
-                    dg = min(dg, 8u);
-                    dg = min(dg, (uint32_t)__popcll(freem));
+                    const uint32_t cc = (uint32_t)__builtin_ctzll(freem);  // first fit
                     const uint32_t h = edge_hash(s_a[e], s_b[e], r);
-                    const uint32_t k = mix32(h ^ 0xA5A5A5A5u) % dg;
-                    const uint32_t cc = kth_set_bit(freem, k);
                     s_prop[e] = (uint8_t)cc;
                     const unsigned long long p = edge_prio(s_a[e], s_b[e], r, h);
                     if (da) atomicMin(&s_claim[la * kClaim + (cc & (kClaim - 1u))], p);
@@ -776,8 +762,8 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                                      (!db || s_claim[lb * kClaim + (cc & (kClaim - 1u))] == p);
                     if (win) {
                         s_col[e] = (uint8_t)cc;
-                        if (da) { atomicOr(&s_used[la], 1ull << cc); atomicSub(&s_deg[la], 1u); }
-                        if (db) { atomicOr(&s_used[lb], 1ull << cc); atomicSub(&s_deg[lb], 1u); }
+                        if (da) atomicOr(&s_used[la], 1ull << cc);
+                        if (db) atomicOr(&s_used[lb], 1ull << cc);
                     }
                 }
                 __syncthreads();
@@ -867,7 +853,6 @@ struct GlobalColor {
     int key_by_index;              // joints: keyed by edge index, pairs: by (a, b)
     const uint4* filt;             // .w = dynamic
     unsigned long long* used;      // [n_bodies]
-    uint32_t* deg;                 // [n_bodies]
     unsigned long long* claim;     // [n_bodies][kClaim]
     uint8_t* color;                // [cap] out
     uint8_t* prop;                 // [cap] scratch
@@ -913,14 +898,8 @@ __global__ __launch_bounds__(kGlobalColorBlock) void k_color_global(GlobalColor 
     for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {
         const uint2 ab = A.edges[e];
         A.color[e] = SFX_NO_COLOR;
-        if (GDYN(ab.x)) { A.used[ab.x] = 0ull; A.deg[ab.x] = 0u; for (int k = 0; k < kClaim; ++k) A.claim[(size_t)ab.x * kClaim + k] = ~0ull; }
-        if (GDYN(ab.y)) { A.used[ab.y] = 0ull; A.deg[ab.y] = 0u; for (int k = 0; k < kClaim; ++k) A.claim[(size_t)ab.y * kClaim + k] = ~0ull; }
-    }
-    __syncthreads();
-    for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {
-        const uint2 ab = A.edges[e];
-        if (GDYN(ab.x)) atomicAdd(&A.deg[ab.x], 1u);
-        if (GDYN(ab.y)) atomicAdd(&A.deg[ab.y], 1u);
+        if (GDYN(ab.x)) { A.used[ab.x] = 0ull; for (int k = 0; k < kClaim; ++k) A.claim[(size_t)ab.x * kClaim + k] = ~0ull; }
+        if (GDYN(ab.y)) { A.used[ab.y] = 0ull; for (int k = 0; k < kClaim; ++k) A.claim[(size_t)ab.y * kClaim + k] = ~0ull; }
     }
     __syncthreads();
     for (uint32_t r = 0; r < A.rounds; ++r) {
@@ -930,15 +909,9 @@ __global__ __launch_bounds__(kGlobalColorBlock) void k_color_global(GlobalColor 
             const bool da = GDYN(ab.x), db = GDYN(ab.y);
             const unsigned long long freem = ~((da ? A.used[ab.x] : 0ull) | (db ? A.used[ab.y] : 0ull));
             if (freem == 0ull) { A.prop[e] = SFX_NO_COLOR; atomicOr(&A.ctr->overflow, kOvfColors); continue; }
-            uint32_t dg = 1;
-            if (da) dg = max(dg, A.deg[ab.x]);
-            if (db) dg = max(dg, A.deg[ab.y]);
-            dg = min(dg, 8u);
-            dg = min(dg, (uint32_t)__popcll(freem));
             const uint32_t ku = A.key_by_index ? (e >> 24) : ab.x, kv = A.key_by_index ? (e & 0xFFFFFFu) : ab.y;
+            const uint32_t c = (uint32_t)__builtin_ctzll(freem);  // first fit
             const uint32_t h = edge_hash(ku, kv, r);
-            const uint32_t k = mix32(h ^ 0xA5A5A5A5u) % dg;
-            const uint32_t c = kth_set_bit(freem, k);
             A.prop[e] = (uint8_t)c;
             const unsigned long long p = edge_prio(ku, kv, r, h);
             if (da) atomicMin(&A.claim[(size_t)ab.x * kClaim + (c & (kClaim - 1u))], p);
@@ -958,8 +931,8 @@ __global__ __launch_bounds__(kGlobalColorBlock) void k_color_global(GlobalColor 
                              (!db || A.claim[(size_t)ab.y * kClaim + (c & (kClaim - 1u))] == p);
             if (win) {
                 A.color[e] = (uint8_t)c;
-                if (da) { atomicOr(&A.used[ab.x], 1ull << c); atomicSub(&A.deg[ab.x], 1u); }
-                if (db) { atomicOr(&A.used[ab.y], 1ull << c); atomicSub(&A.deg[ab.y], 1u); }
+                if (da) atomicOr(&A.used[ab.x], 1ull << c);
+                if (db) atomicOr(&A.used[ab.y], 1ull << c);
             }
         }
         __syncthreads();

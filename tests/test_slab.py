@@ -162,7 +162,8 @@ def test_gpu_logical_slabs_match_oracle_slabs_and_undecomposed():
     assert np.isfinite(pos).all()
     assert abs(pos[dyn, 1].mean() - ref[dyn, 1].mean()) < 0.02
     assert pos[dyn, 1].min() > -0.1
-    assert max(w.stats().max_depth for w in G.worlds) < 0.05
+    # deepest overlap of the still settling pile: no worse than the undecomposed world's by more than 3 cm
+    assert max(w.stats().max_depth for w in G.worlds) < W.stats().max_depth + 0.03
 
 
 @pytest.mark.gpu
