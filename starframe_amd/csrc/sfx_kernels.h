@@ -654,6 +654,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                                                          const uint32_t* __restrict__ tile_start,
                                                          const uint32_t* __restrict__ list, const uint4* __restrict__ rawp,
                                                          uint4* __restrict__ tpair, BatchDesc* __restrict__ batches,
+                                                         const float4* __restrict__ shape, uint32_t* __restrict__ torder,
                                                          uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr) {
     constexpr uint32_t MB = kMaxB;
     constexpr uint32_t kBlock = 512;  // shadows the file-level constant: this kernel runs 512 threads
@@ -665,6 +666,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
     __shared__ uint8_t s_col[MP], s_prop[MP], s_tj[MP];
     __shared__ uint32_t s_hist[SFX_MAX_COLORS], s_base[SFX_MAX_COLORS];
     __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat;
+    __shared__ uint32_t s_cls[4];
     __shared__ BatchRanges S;
     __shared__ uint32_t s_tile[kMaxGroup], s_tnb[kMaxGroup], s_tnp[kMaxGroup], s_tstart[kMaxGroup];
     __shared__ uint32_t s_bfirst[kMaxGroup + 1], s_poff[kMaxGroup + 1];
@@ -711,6 +713,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 s_nleft = 0u; s_ovf = 0u;
             }
             if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
+            if (tid < 4) s_cls[tid] = 0u;
             __syncthreads();
             const uint32_t nb = min(S.off[4u * c], MB), np = min(s_poff[c], MP);
             for (uint32_t l = tid; l < nb; l += kBlock) {
@@ -830,11 +833,28 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
             if (tid < SFX_MAX_COLORS && s_hist[tid]) atomicAdd(&ctr->color_count[tid], s_hist[tid]);
             __syncthreads();
             const uint32_t bstart = s_bstart;
+            // narrowphase order: the batch's pairs grouped by shape-pair class (circle-circle, circle-
+            // polygon core, core-core, anything with a POLY), so that the lanes of a wave take the
+            // same branch of the narrowphase.  s_prop is free now: it keeps the class.
+            for (uint32_t e = tid; e < np; e += kBlock) {
+                const uint32_t ta = __float_as_uint(shape[s_a[e]].x) & 0xFFu, tb = __float_as_uint(shape[s_b[e]].x) & 0xFFu;
+                const uint32_t nc = (ta == SFX_SHAPE_CIRCLE ? 1u : 0u) + (tb == SFX_SHAPE_CIRCLE ? 1u : 0u);
+                const uint32_t cls = (ta == SFX_SHAPE_POLY || tb == SFX_SHAPE_POLY) ? 3u : 2u - nc;
+                s_prop[e] = (uint8_t)cls;
+                atomicAdd(&s_cls[cls], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                uint32_t run = 0;
+                for (int k = 0; k < 4; ++k) { const uint32_t c4 = s_cls[k]; s_cls[k] = run; run += c4; }
+            }
+            __syncthreads();
             for (uint32_t e = tid; e < np; e += kBlock) {
                 const uint32_t cc = s_col[e];
                 const uint32_t dst = (cc < SFX_MAX_COLORS) ? atomicAdd(&s_base[cc], 1u) : atomicAdd(&s_nleft, 1u);
                 const uint32_t la = s_la[e], lb = s_lb[e];
                 tpair[bstart + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), cc | (s_tile[f + s_tj[e]] << 8));
+                torder[bstart + atomicAdd(&s_cls[s_prop[e]], 1u)] = dst;
             }
             __syncthreads();
         }
@@ -1017,6 +1037,7 @@ struct TileArrays {
     const uint32_t* big;          // tiles that are batches of their own
     const BatchDesc* batches;     // per phase batch tables
     const uint4* tpair;           // colour-major per batch
+    const uint32_t* torder;       // per batch: pair positions grouped by shape-pair class (narrowphase order)
     const uint2* fsorted;         // fallback list, colour-major
     uint32_t max_pairs;           // record slot of fallback pair k = max_pairs + k
     uint32_t fb_cap;
@@ -1269,7 +1290,8 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback,
         colour_runs<NT>(T.tpair, start, np, s_cs, s_ce);
         // narrowphase of every pair at the poses in LDS (a large non-dynamic collider outside the
         // blocks is read from global memory)
-        for (uint32_t k = tid; k < np; k += NT) {
+        for (uint32_t j = tid; j < np; j += NT) {
+            const uint32_t k = T.torder[start + j];
             const PairEnds e = pair_ends(T.tpair[start + k]);
             const float4 pa = e.la == kExt ? B.pose[e.a] : s_pose[e.la];
             const float4 pb = e.lb == kExt ? B.pose[e.b] : s_pose[e.lb];
