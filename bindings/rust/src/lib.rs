@@ -17,9 +17,11 @@ pub struct sfx_config {
     pub grid_log2: [u32; 2],
     pub max_pairs: u32,
     pub color_rounds: u32,
-    pub launch_colors: u32,
+    pub tile_cells: u32,
+    pub tile_cells_y: u32,
     pub restitution_threshold: f32,
     pub max_depenetration_velocity: f32,
+    pub speculative_margin: f32,
     pub linear_damping: f32,
     pub angular_damping: f32,
     pub flags: u32,
@@ -62,6 +64,7 @@ pub struct sfx_world {
     _private: [u8; 0],
 }
 
+pub const SFX_ABI_VERSION: u32 = 4;
 pub const SFX_OK: c_int = 0;
 pub const SFX_WORLD_BODY: u32 = 0xFFFF_FFFF;
 
@@ -77,6 +80,18 @@ extern "C" {
     pub fn sfx_upload_constraints(w: *mut sfx_world, m: u32, c: *const sfx_distance_constraint) -> c_int;
     pub fn sfx_step(w: *mut sfx_world, frame_dt: f32) -> c_int;
     pub fn sfx_sync(w: *mut sfx_world) -> c_int;
+    pub fn sfx_abi_version() -> u32;
+    // the tick in pieces + slab halos (one world per GPU, boundary bodies swapped every substep)
+    pub fn sfx_tick_begin(w: *mut sfx_world, frame_dt: f32) -> c_int;
+    pub fn sfx_tick_substep(w: *mut sfx_world) -> c_int;
+    pub fn sfx_set_stream(w: *mut sfx_world, hip_stream: *mut std::os::raw::c_void) -> c_int;
+    pub fn sfx_halo_set(w: *mut sfx_world, send_idx: *const u32, n_send: u32, recv_idx: *const u32, n_recv: u32) -> c_int;
+    pub fn sfx_halo_pack(w: *mut sfx_world) -> c_int;
+    pub fn sfx_halo_unpack(w: *mut sfx_world) -> c_int;
+    pub fn sfx_halo_buffers(w: *mut sfx_world, send_dev: *mut *mut f32, recv_dev: *mut *mut f32) -> c_int;
+    pub fn sfx_halo_download(w: *mut sfx_world, send_host: *mut f32) -> c_int;
+    pub fn sfx_halo_upload(w: *mut sfx_world, recv_host: *const f32) -> c_int;
+    pub fn sfx_halo_copy(dst: *mut sfx_world, dst_first: u32, src: *mut sfx_world, src_first: u32, count: u32) -> c_int;
     pub fn sfx_download_poses(w: *mut sfx_world, pos: *mut f32, rot: *mut f32) -> c_int;
     pub fn sfx_download_velocities(w: *mut sfx_world, vel: *mut f32, angvel: *mut f32) -> c_int;
     pub fn sfx_last_error(w: *mut sfx_world) -> *const c_char;

@@ -64,14 +64,17 @@ struct sfx_world {
     DevBuf<float2> mass;
     DevBuf<uint4> filt;
     // broadphase.  `zero` is one allocation cleared by a single memset per tick:
-    // [Counters][cell_start: ncell + 1 + pad][tile_cnt: ntiles + 1 + pad][tile_fill: ntiles][tile_flag: ntiles]
+    // [Counters][cell_start: ncell + 1 + pad][tile_cnt: ntiles + 1 + pad][tile_fill: ntiles][tile_flag: ntiles][tile_batch: ntiles]
     DevBuf<uint32_t> zero;
     Counters* ctr = nullptr;
-    uint32_t *cell_start = nullptr, *tile_cnt = nullptr, *tile_fill = nullptr, *tile_flag = nullptr;
+    uint32_t *cell_start = nullptr, *tile_cnt = nullptr, *tile_fill = nullptr, *tile_flag = nullptr, *tile_batch = nullptr;
     size_t zero_bytes = 0;
     DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, scan_sums, active, big_tiles;
     DevBuf<BatchDesc> batches;
-    DevBuf<uint32_t> torder;
+    DevBuf<uint32_t> torder, done;
+    uint32_t epoch = 0;            // one per fused multi-phase launch; never reset, so T.done needs no clearing
+    uint32_t resident_pos = 0, resident_vel = 0;  // workgroups of the solve kernels the device holds at once
+    bool fuse_phases = true;
     DevBuf<int2> cellxy, sorted_cell;
     DevBuf<uint4> rawp, tpair;
     DevBuf<uint2> fpairs, fsorted;
@@ -328,7 +331,7 @@ uint32_t edge_grid(uint32_t cap) { return std::min(std::max(cdiv(cap, kBlock), 1
 TileArrays tile_arrays(sfx_world* w) {
     TileArrays T;
     T.cell_start = w->cell_start; T.sorted_id = w->sorted_id.p; T.tile_start = w->tile_cnt;
-    T.active = w->active.p; T.big = w->big_tiles.p; T.batches = w->batches.p; T.tpair = w->tpair.p; T.torder = w->torder.p; T.fsorted = w->fsorted.p;
+    T.active = w->active.p; T.big = w->big_tiles.p; T.batches = w->batches.p; T.tpair = w->tpair.p; T.torder = w->torder.p; T.tile_batch = w->tile_batch; T.done = w->done.p; T.fsorted = w->fsorted.p;
     T.max_pairs = w->max_pairs; T.fb_cap = w->fb_cap;
     T.dbg = w->dbg.p;
     return T;
@@ -386,7 +389,7 @@ int broadphase(sfx_world* w, float dt) {
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
       hipLaunchKernelGGL((k_batch_color<kBatchP, false>), dim3(w->color_grid, 4), dim3(512), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
-                         w->batches.p, w->shape.p, w->torder.p, w->max_pairs, w->cfg.color_rounds, w->ctr); }
+                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->max_pairs, w->cfg.color_rounds, w->ctr); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
     return SFX_OK;
@@ -468,6 +471,19 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
     w->device = cfg->device;
     // SFX_NULL_STREAM=1 runs the world on the device's default stream (profilers that cannot
     // follow a second queue)
+    {   // how many workgroups of the solve kernels are resident at once: the fused multi-phase launches
+        // never use more, so that no waiting workgroup keeps a not yet started one off the device
+        hipDeviceProp_t prop;
+        int bp = 0, bv = 0;
+        if (hipGetDeviceProperties(&prop, w->device) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_tile_pos<kTileThreads>, kTileThreads, 0) == hipSuccess &&
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&bv, k_tile_vel<kTileThreads>, kTileThreads, 0) == hipSuccess) {
+            w->resident_pos = (uint32_t)std::max(bp, 0) * (uint32_t)prop.multiProcessorCount * 7u / 8u;
+            w->resident_vel = (uint32_t)std::max(bv, 0) * (uint32_t)prop.multiProcessorCount * 7u / 8u;
+        }
+        const char* nf = getenv("SFX_NO_FUSE");   // tuning knob: one launch per phase
+        w->fuse_phases = !(nf && nf[0] == '1') && w->resident_pos >= 32 && w->resident_vel >= 32;
+    }
     if (const char* gr = getenv("SFX_GROUP")) {  // tuning knob: tiles per colouring group
         w->group = std::min(std::max(1, atoi(gr)), kMaxGroup);
         w->group_fixed = true;
@@ -507,7 +523,7 @@ void sfx_destroy(sfx_world* w) {
     w->pose.release(); w->prev.release(); w->vel.release(); w->shape.release(); w->poly.release();
     w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release();
     w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
-    w->active.release(); w->big_tiles.release(); w->batches.release(); w->torder.release(); w->rawp.release(); w->tpair.release();
+    w->active.release(); w->big_tiles.release(); w->batches.release(); w->torder.release(); w->done.release(); w->rawp.release(); w->tpair.release();
     w->fpairs.release(); w->fsorted.release();
     w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->scan_sums.release();
     w->cellxy.release(); w->sorted_cell.release();
@@ -643,7 +659,7 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     w->fb_cap = std::max(65536u, w->max_pairs / 8u);
     const size_t pad = kScanItems;
     const size_t words = sizeof(Counters) / 4 + ((size_t)w->ncell + 1 + pad) + ((size_t)w->ntiles + 1 + pad) +
-                         2 * (size_t)w->ntiles;
+                         3 * (size_t)w->ntiles;
     const size_t words16 = (words + 3) & ~(size_t)3;  // cleared by k_zero in 16-byte units
     ALLOC(w, w->zero, words16);
     w->zero_bytes = words16 * 4;
@@ -652,9 +668,12 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     w->tile_cnt = w->cell_start + ((size_t)w->ncell + 1 + pad);
     w->tile_fill = w->tile_cnt + ((size_t)w->ntiles + 1 + pad);
     w->tile_flag = w->tile_fill + w->ntiles;
+    w->tile_batch = w->tile_flag + w->ntiles;
     ALLOC(w, w->cell_fill, (size_t)w->ncell + 1 + pad);
     ALLOC(w, w->active, 2 * (size_t)w->ntiles); ALLOC(w, w->big_tiles, w->ntiles); ALLOC(w, w->batches, 2 * (size_t)w->ntiles);
     ALLOC(w, w->rawp, w->max_pairs); ALLOC(w, w->tpair, w->max_pairs); ALLOC(w, w->torder, w->max_pairs);
+    ALLOC(w, w->done, 2 * (size_t)w->ntiles);
+    HIPCHK(w, hipMemset(w->done.p, 0, sizeof(uint32_t) * 2 * (size_t)w->ntiles));
     ALLOC(w, w->fpairs, w->fb_cap); ALLOC(w, w->fsorted, w->fb_cap);
     const size_t mc = std::max<size_t>(w->fb_cap, w->m);
     ALLOC(w, w->pcolor, mc); ALLOC(w, w->prop, mc);
@@ -796,17 +815,32 @@ int sfx_tick_substep(sfx_world* w) {
     }
     // full-height strips have one tile row: only the phases 0 and 1 (tile x parity) exist
     const uint32_t nph = (w->tly == w->gyl) ? 2u : 4u;
-    for (uint32_t ph = 0; ph < nph; ++ph) {
-        Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_tile_pairs / nph : 0);
-        hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph,
-                           ph + 1 == nph ? 1 : 0, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
+    uint32_t total_grid = 0;
+    for (uint32_t ph = 0; ph < nph; ++ph) total_grid += w->tile_grid[ph];
+    if (w->fuse_phases) {
+        // all phases in one launch, batches wait for the neighbouring batches of earlier phases
+        Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_tile_pairs : 0);
+        hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(std::min(total_grid, w->resident_pos)), dim3(kTileThreads), 0,
+                           w->stream, 0u, nph, ++w->epoch, 1, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
+    } else {
+        for (uint32_t ph = 0; ph < nph; ++ph) {
+            Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_tile_pairs / nph : 0);
+            hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph, 1u, 0u,
+                               ph + 1 == nph ? 1 : 0, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
+        }
     }
     { Prof p(w, SFX_K_DERIVE_VEL, n);
       hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
-    for (uint32_t ph = 0; ph < nph; ++ph) {
-        Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_tile_pairs / nph : 0);
-        hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph,
-                           ph + 1 == nph ? 1 : 0, g, T, w->ctr, B, C, sp);
+    if (w->fuse_phases) {
+        Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_tile_pairs : 0);
+        hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(std::min(total_grid, w->resident_vel)), dim3(kTileThreads), 0,
+                           w->stream, 0u, nph, ++w->epoch, 1, g, T, w->ctr, B, C, sp);
+    } else {
+        for (uint32_t ph = 0; ph < nph; ++ph) {
+            Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_tile_pairs / nph : 0);
+            hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph, 1u, 0u,
+                               ph + 1 == nph ? 1 : 0, g, T, w->ctr, B, C, sp);
+        }
     }
     HIPCHK(w, hipGetLastError());
     if (++w->substeps_done >= w->cfg.substeps) {
@@ -932,7 +966,7 @@ int sfx_sync(sfx_world* w) {
     HIPCHK(w, hipStreamSynchronize(w->stream));
     poll_counters(w);
     if (w->ctr_valid && w->stale.overflow)
-        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list)",
+        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list, 32 a fused solve launch gave up waiting)",
                     w->stale.overflow);
     return SFX_OK;
 }

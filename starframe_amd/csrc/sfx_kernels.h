@@ -32,7 +32,7 @@ constexpr uint32_t kExt = 0xFFFFu;                  // local index of a body out
 constexpr int kScanItems = 16;                      // items per thread in the block scan
 constexpr int kScanTile = kBlock * kScanItems;      // 4096 items per block
 constexpr uint32_t kLeftCap = 4096;                 // leftover edges the serial finish takes
-constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u, kOvfFallback = 16u;
+constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u, kOvfFallback = 16u, kOvfStall = 32u;
 
 // device-resident counters of one tick (one allocation, zeroed at the start of every tick)
 struct Counters {
@@ -655,6 +655,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                                                          const uint32_t* __restrict__ list, const uint4* __restrict__ rawp,
                                                          uint4* __restrict__ tpair, BatchDesc* __restrict__ batches,
                                                          const float4* __restrict__ shape, uint32_t* __restrict__ torder,
+                                                         uint32_t* __restrict__ tile_batch,
                                                          uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr) {
     constexpr uint32_t MB = kMaxB;
     constexpr uint32_t kBlock = 512;  // shadows the file-level constant: this kernel runs 512 threads
@@ -667,6 +668,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
     __shared__ uint32_t s_hist[SFX_MAX_COLORS], s_base[SFX_MAX_COLORS];
     __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat;
     __shared__ uint32_t s_cls[4];
+    __shared__ uint32_t s_bidx;
     __shared__ BatchRanges S;
     __shared__ uint32_t s_tile[kMaxGroup], s_tnb[kMaxGroup], s_tnp[kMaxGroup], s_tstart[kMaxGroup];
     __shared__ uint32_t s_bfirst[kMaxGroup + 1], s_poff[kMaxGroup + 1];
@@ -826,13 +828,16 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 BatchDesc d;
                 d.first = BIG ? ((e0 + f) | 0x80000000u) : (e0 + f);
                 d.count = c; d.bstart = bstart; d.np = np; d.ncol = nc; d.nb = nb; d.pad[0] = d.pad[1] = 0u;
-                batches[ph * g.pstride + atomicAdd(&ctr->n_batches[ph], 1u)] = d;
+                const uint32_t bidx = atomicAdd(&ctr->n_batches[ph], 1u);
+                batches[ph * g.pstride + bidx] = d;
+                s_bidx = bidx;
                 atomicMax(&ctr->n_colors, nc);
                 if (s_ovf) atomicOr(&ctr->overflow, kOvfColors);
             }
             if (tid < SFX_MAX_COLORS && s_hist[tid]) atomicAdd(&ctr->color_count[tid], s_hist[tid]);
             __syncthreads();
             const uint32_t bstart = s_bstart;
+            if (tid < c) tile_batch[s_tile[f + tid]] = s_bidx + 1u;
             // narrowphase order: the batch's pairs grouped by shape-pair class (circle-circle, circle-
             // polygon core, core-core, anything with a POLY), so that the lanes of a wave take the
             // same branch of the narrowphase.  s_prop is free now: it keeps the class.
@@ -1038,6 +1043,8 @@ struct TileArrays {
     const BatchDesc* batches;     // per phase batch tables
     const uint4* tpair;           // colour-major per batch
     const uint32_t* torder;       // per batch: pair positions grouped by shape-pair class (narrowphase order)
+    const uint32_t* tile_batch;   // per tile: 1 + index of its batch on its phase's table (0: none this tick)
+    uint32_t* done;               // per batch slot: epoch of the last fused launch that finished it
     const uint2* fsorted;         // fallback list, colour-major
     uint32_t max_pairs;           // record slot of fallback pair k = max_pairs + k
     uint32_t fb_cap;
@@ -1147,6 +1154,7 @@ __device__ __forceinline__ void fallback_vel(const TileArrays& T, const Counters
 // others wrote before is visible to it afterwards.
 __device__ __forceinline__ bool last_workgroup(Counters* __restrict__ ctr) {
     __shared__ uint32_t s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every wave: its stores have left before the ticket is taken
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -1254,6 +1262,95 @@ __device__ __forceinline__ void colour_runs(const uint4* __restrict__ tpair, uin
     }
 }
 
+// Several phases in ONE launch (nph > 1): the workgroups take the batches of the phases
+// ph0 .. ph0 + nph - 1 in that order (item I = batches of the earlier phases + index); a batch
+// of a later phase waits until the batches of earlier phases whose blocks overlap its own have
+// published `epoch` in T.done (agent-scope release / acquire), instead of the whole grid waiting
+// for the end of a launch.  Items only ever wait for lower-numbered items and the grid is sized
+// (host side) so that every workgroup is resident: the lowest unfinished item can always run.
+// The wait is bounded all the same: when it gives up, kOvfStall is flagged and the batch runs
+// on what it sees (the tick is then wrong, but nothing hangs).
+struct PhaseItem { uint32_t ph, it; bool ok; };
+
+__device__ __forceinline__ PhaseItem phase_item(const Counters* __restrict__ ctr, uint32_t ph0, uint32_t nph, uint32_t I) {
+    PhaseItem r;
+    r.ph = ph0; r.it = I; r.ok = false;
+    for (uint32_t q = 0; q < nph; ++q) {
+        const uint32_t nb = ctr->n_batches[ph0 + q];
+        if (r.it < nb) { r.ph = ph0 + q; r.ok = true; return r; }
+        r.it -= nb;
+    }
+    return r;
+}
+
+__device__ __forceinline__ uint32_t phase_total(const Counters* __restrict__ ctr, uint32_t ph0, uint32_t nph) {
+    uint32_t t = 0;
+    for (uint32_t q = 0; q < nph; ++q) t += ctr->n_batches[ph0 + q];
+    return t;
+}
+
+// all threads of the workgroup; tiles = the batch's tile ids
+// Hand-off between the batches of one fused launch (MI355X: eight XCDs with private L2s, one L1
+// per CU that other CUs' stores never refresh).  Producer: the poses / velocities a batch writes
+// back are stored write-through (sc1 buffer stores), every storing wave drains its stores
+// (s_waitcnt vmcnt(0)), the workgroup meets at a barrier and one lane stores the batch's flag with
+// an agent-scope atomic store.  Consumer: the first wave polls the flags of the neighbouring
+// batches of earlier phases with relaxed agent-scope loads, runs ONE agent-scope acquire (drops
+// this CU's L1 lines) and waits for it, then the workgroup passes a barrier and loads plainly.
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t record_rsrc(float4* base) {
+    // raw buffer over 16-byte records; the range check is not used (offsets come from body ids)
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0xFFFFFFF0u, 0x00020000);
+}
+
+template <bool WT>
+__device__ __forceinline__ void store_record16(float4* base, __amdgpu_buffer_rsrc_t rs, uint32_t idx, const float4& v) {
+    if constexpr (WT) {
+        const v4u32 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(u, rs, (int)(idx * 16u), 0, 16 /* sc1: write-through */);
+    } else {
+        base[idx] = v;
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void wait_for_earlier_phases(const TileArrays& T, const GridParams& g, Counters* __restrict__ ctr,
+                                                        const uint32_t* __restrict__ tiles, uint32_t count, uint32_t ph,
+                                                        uint32_t ph0, uint32_t epoch) {
+    if (threadIdx.x < 64u) {
+        const uint32_t lx = g.gxl - g.tlx;
+        for (uint32_t j = threadIdx.x; j < count * 8u; j += 64u) {
+            const uint32_t t = tiles[j >> 3], dir = j & 7u;
+            const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
+            const int dx = (dir == 0 || dir == 3 || dir == 5) ? -1 : (dir == 2 || dir == 4 || dir == 7) ? 1 : 0;
+            const int dy = dir < 3 ? -1 : dir < 5 ? 0 : 1;
+            const uint32_t t2 = tile_of(tx + dx, ty + dy, g);
+            const uint32_t ph2 = (t2 & 1u) | (((t2 >> lx) & 1u) << 1);
+            if (ph2 >= ph || ph2 < ph0) continue;
+            const uint32_t b2 = T.tile_batch[t2];
+            if (!b2) continue;  // that tile owns no pairs this tick: nothing touches its block in its phase
+            const uint32_t* flag = &T.done[ph2 * g.pstride + (b2 - 1u)];
+            uint32_t spins = 0;
+            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > 400000u) { atomicOr(&ctr->overflow, kOvfStall); break; }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate has completed before the barrier opens
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void publish_batch(const TileArrays& T, const GridParams& g, uint32_t ph, uint32_t it,
+                                              uint32_t epoch) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have landed
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(&T.done[ph * g.pstride + it], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Position solve of one phase.  A workgroup takes one batch of tiles at a time: the poses of the
 // batch's blocks go to LDS; the narrowphase of the batch's pairs runs at those poses and leaves
 // one record per pair in the contact arrays; then the colours are solved one after the other with
@@ -1262,8 +1359,8 @@ __device__ __forceinline__ void colour_runs(const uint4* __restrict__ tpair, uin
 // next colour's pair while it solves the current one.  Finally the blocks' dynamic bodies are
 // written back.  Batches of one phase have disjoint blocks.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback, GridParams g, TileArrays T,
-                                                  Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
+__global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
+                                                  TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   float max_corr, float sm) {
     __shared__ float4 s_pose[kMaxB];
     __shared__ float2 s_mass[kMaxB];
@@ -1271,11 +1368,15 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback,
     __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
     __shared__ BatchRanges S;
     const uint32_t tid = threadIdx.x;
-    const uint32_t nbat = ctr->n_batches[ph];
-    for (uint32_t it = blockIdx.x; it < nbat; it += gridDim.x) {
+    const __amdgpu_buffer_rsrc_t pose_rs = record_rsrc(B.pose);
+    const uint32_t nitems = phase_total(ctr, ph0, nph);
+    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
         SFX_TT(tt0);
+        const PhaseItem pi = phase_item(ctr, ph0, nph, item);
+        const uint32_t ph = pi.ph, it = pi.it;
         const BatchDesc d = T.batches[ph * g.pstride + it];
         const uint32_t* tiles = T.active + ph * g.pstride + d.first;
+        if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
         batch_ranges(tiles, d.count, g, T.cell_start, S);
         const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
         for (uint32_t l = tid; l < nb; l += NT) {
@@ -1335,11 +1436,20 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback,
         __syncthreads();
         SFX_TT(tt3);
         SFX_TT_ADD(1, tt1, tt2); SFX_TT_ADD(2, tt2, tt3); SFX_TT_ADD(5, 0ull, (unsigned long long)ncol);
-        for (uint32_t l = tid; l < nb; l += NT) {
-            const float2 w = s_mass[l];
-            if (w.x > 0.0f || w.y > 0.0f) B.pose[s_gid[l]] = s_pose[l];
+        if (nph > 1u) {  // fused phases: later batches of this launch read these poses
+            for (uint32_t l = tid; l < nb; l += NT) {
+                const float2 w = s_mass[l];
+                if (w.x > 0.0f || w.y > 0.0f) store_record16<true>(B.pose, pose_rs, s_gid[l], s_pose[l]);
+            }
+            if (ph + 1u < ph0 + nph) publish_batch(T, g, ph, it, epoch);
+            else __syncthreads();
+        } else {
+            for (uint32_t l = tid; l < nb; l += NT) {
+                const float2 w = s_mass[l];
+                if (w.x > 0.0f || w.y > 0.0f) B.pose[s_gid[l]] = s_pose[l];
+            }
+            __syncthreads();
         }
-        __syncthreads();
         SFX_TT(tt4);
         SFX_TT_ADD(0, tt0, tt1); SFX_TT_ADD(3, tt0, tt4); SFX_TT_ADD(4, 0ull, 1ull);
     }
@@ -1347,8 +1457,8 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph, int with_fallback,
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph, int with_fallback, GridParams g, TileArrays T,
-                                                  Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
+__global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
+                                                  TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   StepParams sp) {
     __shared__ float4 s_pose[kMaxB];
     __shared__ float4 s_vel[kMaxB];
@@ -1358,10 +1468,14 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph, int with_fallback,
     __shared__ uint32_t s_shift;
     __shared__ BatchRanges S;
     const uint32_t tid = threadIdx.x;
-    const uint32_t nbat = ctr->n_batches[ph];
-    for (uint32_t it = blockIdx.x; it < nbat; it += gridDim.x) {
+    const __amdgpu_buffer_rsrc_t pose_rs = record_rsrc(B.pose), vel_rs = record_rsrc(B.vel);
+    const uint32_t nitems = phase_total(ctr, ph0, nph);
+    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const PhaseItem pi = phase_item(ctr, ph0, nph, item);
+        const uint32_t ph = pi.ph, it = pi.it;
         const BatchDesc d = T.batches[ph * g.pstride + it];
         const uint32_t* tiles = T.active + ph * g.pstride + d.first;
+        if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
         batch_ranges(tiles, d.count, g, T.cell_start, S);
         const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
         if (tid == 0) s_shift = 0u;
@@ -1409,14 +1523,26 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph, int with_fallback,
         }
         __syncthreads();
         const bool shifted = s_shift != 0u;
-        for (uint32_t l = tid; l < nb; l += NT) {
-            const float2 w = s_mass[l];
-            if (w.x > 0.0f || w.y > 0.0f) {
-                B.vel[s_gid[l]] = s_vel[l];
-                if (shifted) B.pose[s_gid[l]] = s_pose[l];
+        if (nph > 1u) {  // fused phases: later batches of this launch read these records
+            for (uint32_t l = tid; l < nb; l += NT) {
+                const float2 w = s_mass[l];
+                if (w.x > 0.0f || w.y > 0.0f) {
+                    store_record16<true>(B.vel, vel_rs, s_gid[l], s_vel[l]);
+                    if (shifted) store_record16<true>(B.pose, pose_rs, s_gid[l], s_pose[l]);
+                }
             }
+            if (ph + 1u < ph0 + nph) publish_batch(T, g, ph, it, epoch);
+            else __syncthreads();
+        } else {
+            for (uint32_t l = tid; l < nb; l += NT) {
+                const float2 w = s_mass[l];
+                if (w.x > 0.0f || w.y > 0.0f) {
+                    B.vel[s_gid[l]] = s_vel[l];
+                    if (shifted) B.pose[s_gid[l]] = s_pose[l];
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (with_fallback && last_workgroup(ctr)) fallback_vel(T, ctr, B, C, sp);
 }

@@ -101,6 +101,18 @@ int main(int argc, char** argv) {
            st.n_manifolds, st.n_tiles, st.n_fallback, st.n_colors, st.launches);
     printf("ticks %d wall %.4f ms/tick device %.4f ms/tick  %.1f M body-substeps/s\n", ticks, wall / ticks, ms / ticks,
            1e-3 * s.n * s.substeps * ticks / ms);
+    {   // FNV-1a over the final state: two runs of one scene must agree bit for bit (the tick is deterministic)
+        std::vector<float> vel(s.vel.size()), av(s.angvel.size());
+        CHECK(sfx_download_poses(w, s.pos.data(), s.rot.data()));
+        CHECK(sfx_download_velocities(w, vel.data(), av.data()));
+        uint64_t h = 1469598103934665603ull;
+        auto eat = [&h](const std::vector<float>& v) {
+            const unsigned char* p = (const unsigned char*)v.data();
+            for (size_t i = 0; i < v.size() * sizeof(float); ++i) { h ^= p[i]; h *= 1099511628211ull; }
+        };
+        eat(s.pos); eat(s.rot); eat(vel); eat(av);
+        printf("state checksum %016llx\n", (unsigned long long)h);
+    }
     sfx_destroy(w);
     return 0;
 }
