@@ -64,7 +64,7 @@ pub struct sfx_world {
     _private: [u8; 0],
 }
 
-pub const SFX_ABI_VERSION: u32 = 4;
+pub const SFX_ABI_VERSION: u32 = 5;
 pub const SFX_OK: c_int = 0;
 pub const SFX_WORLD_BODY: u32 = 0xFFFF_FFFF;
 

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 4u
+#define SFX_ABI_VERSION 5u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -134,7 +134,7 @@ typedef struct sfx_frame_stats {
     uint32_t n_bodies;
     uint32_t n_small;        /* colliders sorted into the grid               */
     uint32_t n_large;        /* colliders tested against everything          */
-    uint32_t n_pairs;        /* candidate pairs of the last tick             */
+    uint32_t n_pairs;        /* candidate pairs of the last tick (AABB overlap) */
     uint32_t n_colors;       /* most colours used by any tile / the fallback list */
     uint32_t n_leftover;     /* pairs coloured by the serial finishes        */
     uint32_t n_manifolds;    /* pairs that touched in the last substep       */
@@ -147,6 +147,8 @@ typedef struct sfx_frame_stats {
     uint32_t n_fallback;     /* pairs on the fallback list                   */
     uint32_t max_tile_pairs; /* most pairs owned by one tile                 */
     uint32_t max_tile_bodies;/* most grid-sorted colliders in one tile block */
+    uint32_t n_solver_pairs; /* candidate pairs within reach (DESIGN.md "Contract / solver pairs"):
+                                the ones the substeps run the narrowphase and the solves on */
     float max_depth;         /* deepest penetration seen in the last substep */
     float kinetic_energy;    /* sum 1/2 m v^2 + 1/2 I w^2 over dynamic bodies */
     uint32_t color_count[SFX_MAX_COLORS]; /* pairs per colour, summed over tiles + fallback */

@@ -22,6 +22,7 @@
 
 #define EPS_LEN 1e-9f
 #define NO_COLOR 0xFFu
+#define PRUNED_COLOR 0xFEu /* candidate pair dropped by the reach test: never solved this tick */
 #define SFO_FALLBACK 0xFFFFFFFFu
 
 typedef struct { float x, y; } v2;
@@ -71,7 +72,7 @@ struct sfo_world {
     uint8_t* color;      /* colour of the pair inside its batch (tile or fallback list) */
     uint32_t* owner;     /* wrapped owner tile of the pair, SFO_FALLBACK for the fallback list */
     uint32_t n_colors, n_leftover, overflow;
-    uint32_t n_tiles, n_fallback, max_tile_pairs, max_tile_bodies;
+    uint32_t n_tiles, n_fallback, max_tile_pairs, max_tile_bodies, n_solver_pairs;
     uint32_t color_count[SFX_MAX_COLORS];
     uint32_t* order;   /* processing order (indices into pa/pb) */
     uint32_t* batch_end; /* order[] is cut into batches: batch k = [batch_end[k-1], batch_end[k]) */
@@ -635,6 +636,80 @@ static void grid_pairs(sfo_world* w) {
     free(start); free(bucket); free(slot_id); free(large); free(fill);
 }
 
+/* ------------------------------------------------------------------ reach test
+ * [DESIGN] DESIGN.md "Contract / solver pairs".  The padded AABBs say how far a body may move in
+ * the tick (per axis: aabb_margin + min(|v| dt, vel_pad_max)); a candidate pair whose shapes are
+ * further apart than the two reaches plus the speculative margin cannot touch before the next
+ * broadphase and is left out of the solve.  The distance is bounded from below by the gap along a
+ * few axes (the centre line and the local axes of rectangles and capsules): a gap along ANY axis
+ * is a lower bound of the distance, so the test never drops a pair that could touch. */
+static void support_extents(const sfo_world* w, uint32_t i, float nx, float ny, float* hp, float* hm) {
+    const sfx_collider* c = &w->col[i];
+    float rc = w->rot[2 * i], rs = w->rot[2 * i + 1];
+    switch (c->type) {
+    case SFX_SHAPE_CIRCLE:
+        *hp = *hm = c->p[2];
+        break;
+    case SFX_SHAPE_RECT: {
+        float ax = nx * rc + ny * rs, ay = ny * rc - nx * rs;
+        *hp = *hm = (fabsf(ax) * c->p[0] + fabsf(ay) * c->p[1]) + c->p[2];
+        break;
+    }
+    case SFX_SHAPE_CAPSULE: {
+        float ax = nx * rc + ny * rs;
+        *hp = *hm = fabsf(ax) * c->p[0] + c->p[2];
+        break;
+    }
+    case SFX_SHAPE_POLY: {
+        float mx = -INFINITY, mn = INFINITY;
+        for (uint32_t k = 0; k < c->poly_count; ++k) {
+            float lx = w->poly[2 * (c->poly_offset + k)], ly = w->poly[2 * (c->poly_offset + k) + 1];
+            float wx = rc * lx - rs * ly, wy = rs * lx + rc * ly;
+            float pr = nx * wx + ny * wy;
+            mx = fmaxf(mx, pr); mn = fminf(mn, pr);
+        }
+        *hp = mx + c->p[2]; *hm = c->p[2] - mn;
+        break;
+    }
+    default:
+        *hp = *hm = INFINITY;
+    }
+}
+
+static float axis_gap(const sfo_world* w, uint32_t a, uint32_t b, float nx, float ny, float dx, float dy) {
+    float hap, ham, hbp, hbm;
+    support_extents(w, a, nx, ny, &hap, &ham);
+    support_extents(w, b, nx, ny, &hbp, &hbm);
+    float t = nx * dx + ny * dy;
+    return t >= 0.0f ? t - (hap + hbm) : (-t) - (ham + hbp);
+}
+
+static float reach_of(const sfo_world* w, uint32_t i, float dt) {
+    float px = w->cfg.aabb_margin + fminf(fabsf(w->vel[2 * i]) * dt, w->cfg.vel_pad_max);
+    float py = w->cfg.aabb_margin + fminf(fabsf(w->vel[2 * i + 1]) * dt, w->cfg.vel_pad_max);
+    return sqrtf(px * px + py * py);
+}
+
+static int pair_in_reach(const sfo_world* w, uint32_t a, uint32_t b, float dt) {
+    float dx = w->pos[2 * b] - w->pos[2 * a], dy = w->pos[2 * b + 1] - w->pos[2 * a + 1];
+    float d2 = dx * dx + dy * dy;
+    float gap = -INFINITY;
+    if (d2 > 1e-12f) {
+        float d = sqrtf(d2);
+        gap = axis_gap(w, a, b, dx / d, dy / d, dx, dy);
+    }
+    for (int k = 0; k < 2; ++k) {
+        uint32_t i = k ? b : a;
+        uint32_t t = w->col[i].type;
+        if (t != SFX_SHAPE_RECT && t != SFX_SHAPE_CAPSULE) continue;
+        float rc = w->rot[2 * i], rs = w->rot[2 * i + 1];
+        gap = fmaxf(gap, axis_gap(w, a, b, rc, rs, dx, dy));
+        gap = fmaxf(gap, axis_gap(w, a, b, -rs, rc, dx, dy));
+    }
+    float thr = (reach_of(w, a, dt) + reach_of(w, b, dt)) + w->cfg.speculative_margin;
+    return !(gap > thr);
+}
+
 /* ------------------------------------------------------------------ tile order
  * [DESIGN] DESIGN.md "Contract / tiles".  Tiles are 2^tlx x 2^tly blocks of grid cells (true
  * cell coordinates, wrapped onto the torus like the cells).  A candidate pair of two small
@@ -653,7 +728,7 @@ static uint32_t wrapped_tile(const sfo_world* w, int32_t tx, int32_t ty) {
 
 static int32_t tile_coord(int32_t c, uint32_t tl) { return c >= 0 ? (int32_t)((uint32_t)c >> tl) : -(int32_t)(((uint32_t)(-(c + 1)) >> tl) + 1u); }
 
-static void build_order(sfo_world* w) {
+static void build_order(sfo_world* w, float frame_dt) {
     uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
     uint32_t lx = w->gxl - w->tlx, ly = w->gyl - w->tly, ntiles = 1u << (lx + ly);
     uint32_t* tbodies = (uint32_t*)calloc(ntiles, sizeof(uint32_t));
@@ -703,6 +778,7 @@ static void build_order(sfo_world* w) {
     memset(w->color_count, 0, sizeof(w->color_count));
     w->n_colors = 0; w->n_leftover = 0; w->n_batches = 0; w->n_order = 0;
     uint32_t ovf = 0;
+    uint32_t* kept = (uint32_t*)malloc((np ? np : 1) * sizeof(uint32_t));
     /* batches: phase by phase, inside a phase tile by tile (independent of each other), the
      * fallback list last; inside a batch colour-major */
     for (uint32_t ph = 0; ph <= 4; ++ph) {
@@ -714,12 +790,23 @@ static void build_order(sfo_world* w) {
             } else if (t != ntiles) continue;
             uint32_t s0 = tstart[t], cnt = tstart[t + 1] - s0;
             if (!cnt) continue;
-            uint32_t nc = color_edges(&cs, cnt, &bytile[s0], w->pa, w->pb, w->pa, w->pb, dyn, w->cfg.color_rounds,
+            const uint32_t* idx = &bytile[s0];
+            if (ph < 4) { /* tile-owned pairs: only those within reach are coloured and solved */
+                uint32_t nk = 0;
+                for (uint32_t q = 0; q < cnt; ++q) {
+                    uint32_t e = bytile[s0 + q];
+                    if (pair_in_reach(w, w->pa[e], w->pb[e], frame_dt)) kept[nk++] = e;
+                    else w->color[e] = PRUNED_COLOR;
+                }
+                idx = kept; cnt = nk;
+                if (!cnt) continue;
+            }
+            uint32_t nc = color_edges(&cs, cnt, idx, w->pa, w->pb, w->pa, w->pb, dyn, w->cfg.color_rounds,
                                       w->color, &w->n_leftover, &ovf);
             if (nc > w->n_colors) w->n_colors = nc;
             for (uint32_t c = 0; c < nc; ++c)
                 for (uint32_t q = 0; q < cnt; ++q) {
-                    uint32_t e = bytile[s0 + q];
+                    uint32_t e = idx[q];
                     if (w->color[e] == c) { w->order[w->n_order++] = e; w->color_count[c]++; }
                 }
             w->batch_end[w->n_batches++] = w->n_order;
@@ -728,7 +815,8 @@ static void build_order(sfo_world* w) {
     color_scratch_free(&cs);
     if (ovf) w->overflow = 1;
     w->order_valid = 1;
-    free(tbodies); free(tcnt); free(tover); free(dyn); free(tstart); free(bytile); free(fill);
+    w->n_solver_pairs = w->n_order;
+    free(tbodies); free(tcnt); free(tover); free(dyn); free(tstart); free(bytile); free(fill); free(kept);
 }
 
 static void broadphase_core(sfo_world* w, float frame_dt) {
@@ -740,7 +828,7 @@ static void broadphase_core(sfo_world* w, float frame_dt) {
 int sfo_broadphase(sfo_world* w, float frame_dt) {
     if (!w->col) return SFX_ERR_INVALID;
     broadphase_core(w, frame_dt);
-    build_order(w);
+    build_order(w, frame_dt);
     return w->overflow ? SFX_ERR_CAPACITY : SFX_OK;
 }
 
@@ -1397,11 +1485,14 @@ int sfo_tick_begin(sfo_world* w, float frame_dt, int order) {
         key_idx* ki = (key_idx*)malloc((np ? np : 1) * sizeof(key_idx));
         for (uint32_t e = 0; e < np; ++e) { ki[e].key = ((uint64_t)w->pa[e] << 32) | w->pb[e]; ki[e].idx = e; }
         qsort(ki, np, sizeof(key_idx), cmp_key_idx);
-        for (uint32_t e = 0; e < np; ++e) w->order[e] = ki[e].idx;
+        uint32_t nk = 0; /* the reach test (DESIGN.md "Contract / solver pairs") applies to every order */
+        for (uint32_t e = 0; e < np; ++e)
+            if (pair_in_reach(w, w->pa[ki[e].idx], w->pb[ki[e].idx], frame_dt)) w->order[nk++] = ki[e].idx;
         free(ki);
-        w->batch_end[0] = np;
+        w->batch_end[0] = nk;
+        w->n_solver_pairs = nk;
     } else {
-        build_order(w);
+        build_order(w, frame_dt);
         w->tick_nbatch = w->n_batches;
     }
     w->tick_h = frame_dt / (float)w->cfg.substeps;
@@ -1504,6 +1595,7 @@ int sfo_stats(const sfo_world* w, sfx_frame_stats* out) {
     out->overflow = w->overflow;
     out->n_tiles = w->n_tiles; out->n_fallback = w->n_fallback;
     out->max_tile_pairs = w->max_tile_pairs; out->max_tile_bodies = w->max_tile_bodies;
+    out->n_solver_pairs = w->n_solver_pairs;
     memcpy(out->color_count, w->color_count, sizeof(w->color_count));
     /* deepest penetration at the current poses */
     float md = 0.0f;

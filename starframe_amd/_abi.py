@@ -72,6 +72,7 @@ class SfxFrameStats(C.Structure):
         ("n_fallback", C.c_uint32),
         ("max_tile_pairs", C.c_uint32),
         ("max_tile_bodies", C.c_uint32),
+        ("n_solver_pairs", C.c_uint32),
         ("max_depth", C.c_float),
         ("kinetic_energy", C.c_float),
         ("color_count", C.c_uint32 * MAX_COLORS),

@@ -18,6 +18,7 @@
 
 #define SFX_EPS_LEN 1e-9f
 #define SFX_NO_COLOR 0xFFu
+#define SFX_PRUNED_COLOR 0xFEu  // candidate pair dropped by the reach test: never solved this tick
 #define SFX_NO_BUCKET 0xFFFFFFFFu
 
 namespace sfx {
@@ -87,6 +88,75 @@ __device__ __forceinline__ float4 compute_aabb(const float4& pose, const float4&
 
 __device__ __forceinline__ bool aabb_overlap(const float4& A, const float4& B) {
     return A.x <= B.z && B.x <= A.z && A.y <= B.w && B.y <= A.w;
+}
+
+// ---- reach test (DESIGN.md "Contract / solver pairs") --------------------------------
+// A gap along any axis is a lower bound of the distance between two convex shapes; a pair
+// whose gap exceeds what the two bodies may move in the tick (the AABB pads) plus the
+// speculative margin cannot touch before the next broadphase.
+__device__ __forceinline__ void support_extents(const float4& pose, const float4& shape, const float4* __restrict__ poly,
+                                                float nx, float ny, float& hp, float& hm) {
+    const float rc = pose.z, rs = pose.w;
+    const uint32_t type = shape_type(shape);
+    if (type == SFX_SHAPE_CIRCLE) {
+        hp = hm = shape.w;
+    } else if (type == SFX_SHAPE_RECT) {
+        const float ax = nx * rc + ny * rs, ay = ny * rc - nx * rs;
+        hp = hm = (fabsf(ax) * shape.y + fabsf(ay) * shape.z) + shape.w;
+    } else if (type == SFX_SHAPE_CAPSULE) {
+        const float ax = nx * rc + ny * rs;
+        hp = hm = fabsf(ax) * shape.y + shape.w;
+    } else if (type == SFX_SHAPE_POLY) {
+        const uint32_t off = __float_as_uint(shape.y), cnt = __float_as_uint(shape.z);
+        float mx = -INFINITY, mn = INFINITY;
+        for (uint32_t k = 0; k < cnt; ++k) {
+            const float4 v = poly[off + k];
+            const float wx = rc * v.x - rs * v.y, wy = rs * v.x + rc * v.y;
+            const float pr = nx * wx + ny * wy;
+            mx = fmaxf(mx, pr); mn = fminf(mn, pr);
+        }
+        hp = mx + shape.w; hm = shape.w - mn;
+    } else {
+        hp = hm = INFINITY;
+    }
+}
+
+__device__ __forceinline__ float axis_gap(const float4& pa, const float4& sa, const float4& pb, const float4& sb,
+                                          const float4* __restrict__ poly, float nx, float ny, float dx, float dy) {
+    float hap, ham, hbp, hbm;
+    support_extents(pa, sa, poly, nx, ny, hap, ham);
+    support_extents(pb, sb, poly, nx, ny, hbp, hbm);
+    const float t = nx * dx + ny * dy;
+    return t >= 0.0f ? t - (hap + hbm) : (-t) - (ham + hbp);
+}
+
+__device__ __forceinline__ float reach_of(const float4& vel, float margin, float vel_pad_max, float dt) {
+    const float px = margin + fminf(fabsf(vel.x) * dt, vel_pad_max);
+    const float py = margin + fminf(fabsf(vel.y) * dt, vel_pad_max);
+    return sqrtf(px * px + py * py);
+}
+
+__device__ __forceinline__ bool pair_in_reach(const float4& pa, const float4& sa, const float4& va, const float4& pb,
+                                              const float4& sb, const float4& vb, const float4* __restrict__ poly,
+                                              float margin, float vel_pad_max, float dt, float sm) {
+    const float dx = pb.x - pa.x, dy = pb.y - pa.y;
+    const float d2 = dx * dx + dy * dy;
+    float gap = -INFINITY;
+    if (d2 > 1e-12f) {
+        const float d = sqrtf(d2);
+        gap = axis_gap(pa, sa, pb, sb, poly, dx / d, dy / d, dx, dy);
+    }
+    const uint32_t ta = shape_type(sa), tb = shape_type(sb);
+    if (ta == SFX_SHAPE_RECT || ta == SFX_SHAPE_CAPSULE) {
+        gap = fmaxf(gap, axis_gap(pa, sa, pb, sb, poly, pa.z, pa.w, dx, dy));
+        gap = fmaxf(gap, axis_gap(pa, sa, pb, sb, poly, -pa.w, pa.z, dx, dy));
+    }
+    if (tb == SFX_SHAPE_RECT || tb == SFX_SHAPE_CAPSULE) {
+        gap = fmaxf(gap, axis_gap(pa, sa, pb, sb, poly, pb.z, pb.w, dx, dy));
+        gap = fmaxf(gap, axis_gap(pa, sa, pb, sb, poly, -pb.w, pb.z, dx, dy));
+    }
+    const float thr = (reach_of(va, margin, vel_pad_max, dt) + reach_of(vb, margin, vel_pad_max, dt)) + sm;
+    return !(gap > thr);
 }
 
 __device__ __forceinline__ bool pair_filter(const uint4& a, const uint4& b) {

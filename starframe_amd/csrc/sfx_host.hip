@@ -386,10 +386,13 @@ int broadphase(sfx_world* w, float dt) {
     { Prof p(w, SFX_K_PAIR_FILL, n);
       hipLaunchKernelGGL(k_pairs<true>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
                          w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }
+    ReachParams RP;
+    RP.pose = w->pose.p; RP.vel = w->vel.p; RP.poly = w->poly.p;
+    RP.margin = w->cfg.aabb_margin; RP.vel_pad_max = w->cfg.vel_pad_max; RP.dt = dt; RP.sm = w->cfg.speculative_margin;
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
       hipLaunchKernelGGL((k_batch_color<kBatchP, false>), dim3(w->color_grid, 4), dim3(512), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
-                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->max_pairs, w->cfg.color_rounds, w->ctr); }
+                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, RP, w->max_pairs, w->cfg.color_rounds, w->ctr); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
     return SFX_OK;
@@ -819,12 +822,12 @@ int sfx_tick_substep(sfx_world* w) {
     for (uint32_t ph = 0; ph < nph; ++ph) total_grid += w->tile_grid[ph];
     if (w->fuse_phases) {
         // all phases in one launch, batches wait for the neighbouring batches of earlier phases
-        Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_tile_pairs : 0);
+        Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_kept : 0);
         hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(std::min(total_grid, w->resident_pos)), dim3(kTileThreads), 0,
                            w->stream, 0u, nph, ++w->epoch, 1, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
     } else {
         for (uint32_t ph = 0; ph < nph; ++ph) {
-            Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_tile_pairs / nph : 0);
+            Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_kept / nph : 0);
             hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph, 1u, 0u,
                                ph + 1 == nph ? 1 : 0, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
         }
@@ -832,12 +835,12 @@ int sfx_tick_substep(sfx_world* w) {
     { Prof p(w, SFX_K_DERIVE_VEL, n);
       hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
     if (w->fuse_phases) {
-        Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_tile_pairs : 0);
+        Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_kept : 0);
         hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(std::min(total_grid, w->resident_vel)), dim3(kTileThreads), 0,
                            w->stream, 0u, nph, ++w->epoch, 1, g, T, w->ctr, B, C, sp);
     } else {
         for (uint32_t ph = 0; ph < nph; ++ph) {
-            Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_tile_pairs / nph : 0);
+            Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_kept / nph : 0);
             hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph, 1u, 0u,
                                ph + 1 == nph ? 1 : 0, g, T, w->ctr, B, C, sp);
         }
@@ -1134,6 +1137,7 @@ int sfx_stats(sfx_world* w, sfx_frame_stats* out) {
     out->n_leftover = c.n_leftover; out->overflow = c.overflow;
     out->n_tiles = c.n_active[0];
     out->n_fallback = c.n_fb; out->max_tile_pairs = c.max_tile_pairs; out->max_tile_bodies = c.max_tile_bodies;
+    out->n_solver_pairs = c.n_kept + std::min(c.n_fb, w->fb_cap);
     out->n_contacts = s.n_contacts;
     out->n_manifolds = s.n_manifolds;
     out->n_manifolds2 = s.n_manifolds2;

@@ -59,7 +59,8 @@ struct Counters {
     uint32_t n_listed[4];   // tiles on the per-phase lists (all but the big ones)
     uint32_t color_count[SFX_MAX_COLORS];
     uint32_t fb_start[SFX_MAX_COLORS + 1];  // colour-major offsets into the sorted fallback list
-    uint32_t pad3[3];
+    uint32_t n_kept;        // tile pairs within reach (the solves' pairs; the fallback list is not tested)
+    uint32_t pad3[2];
 };
 static_assert(sizeof(Counters) % 16 == 0, "the per-tick block is cleared in 16-byte units");
 
@@ -586,7 +587,7 @@ struct BatchDesc {
     uint32_t first;    // index of the first tile on the phase's list (bit 31: on the big list)
     uint32_t count;    // tiles
     uint32_t bstart;   // first pair in tpair / first record slot
-    uint32_t np;       // pairs
+    uint32_t np;       // pairs within reach: the ones the solves take (the others follow them in tpair)
     uint32_t ncol;     // most colours of any of its tiles
     uint32_t nb;       // bodies of all its blocks
     uint32_t pad[2];
@@ -642,8 +643,17 @@ __device__ __forceinline__ uint32_t batch_local(const BatchRanges& S, uint32_t j
     return l;
 }
 
+// frame-start state and pads for the reach test of k_batch_color
+struct ReachParams {
+    const float4* pose;
+    const float4* vel;
+    const float4* poly;
+    float margin, vel_pad_max, dt, sm;
+};
+
 // Forms the batches and edge-colours every tile's pair graph, all state in LDS (DESIGN.md
-// "Contract / colouring").  A workgroup takes `group` consecutive tiles of a phase's list and
+// "Contract / colouring").  Pairs that fail the reach test (DESIGN.md "Contract / solver pairs")
+// are not coloured; they are listed behind the batch's pairs with SFX_PRUNED_COLOR.  A workgroup takes `group` consecutive tiles of a phase's list and
 // cuts them greedily into batches of at most kBatchP pairs and kMaxB bodies (BIG: one tile of
 // the big list per batch, up to kMaxP pairs).  Per batch it writes the pairs colour-major as
 // (id a, id b, local a | local b << 16, colour | tile << 8) and a BatchDesc on the phase's table.
@@ -655,7 +665,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                                                          const uint32_t* __restrict__ list, const uint4* __restrict__ rawp,
                                                          uint4* __restrict__ tpair, BatchDesc* __restrict__ batches,
                                                          const float4* __restrict__ shape, uint32_t* __restrict__ torder,
-                                                         uint32_t* __restrict__ tile_batch,
+                                                         uint32_t* __restrict__ tile_batch, ReachParams RP,
                                                          uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr) {
     constexpr uint32_t MB = kMaxB;
     constexpr uint32_t kBlock = 512;  // shadows the file-level constant: this kernel runs 512 threads
@@ -666,7 +676,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
     __shared__ uint16_t s_la[MP], s_lb[MP], s_left[MP], s_srt[MP];
     __shared__ uint8_t s_col[MP], s_prop[MP], s_tj[MP];
     __shared__ uint32_t s_hist[SFX_MAX_COLORS], s_base[SFX_MAX_COLORS];
-    __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat;
+    __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat, s_npruned, s_ptail;
     __shared__ uint32_t s_cls[4];
     __shared__ uint32_t s_bidx;
     __shared__ BatchRanges S;
@@ -712,7 +722,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 uint32_t run = 0;
                 for (uint32_t j = 0; j < c; ++j) { s_poff[j] = run; run += s_tnp[f + j]; }
                 s_poff[c] = run;
-                s_nleft = 0u; s_ovf = 0u;
+                s_nleft = 0u; s_ovf = 0u; s_npruned = 0u;
             }
             if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
             if (tid < 4) s_cls[tid] = 0u;
@@ -733,7 +743,10 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 s_la[e] = (uint16_t)batch_local(S, j, rp.z);
                 s_lb[e] = (uint16_t)batch_local(S, j, rp.w);
                 s_tj[e] = (uint8_t)j;
-                s_col[e] = SFX_NO_COLOR;
+                const bool keep = pair_in_reach(RP.pose[rp.x], shape[rp.x], RP.vel[rp.x], RP.pose[rp.y], shape[rp.y],
+                                                RP.vel[rp.y], RP.poly, RP.margin, RP.vel_pad_max, RP.dt, RP.sm);
+                s_col[e] = keep ? SFX_NO_COLOR : SFX_PRUNED_COLOR;
+                if (!keep) atomicAdd(&s_npruned, 1u);
             }
             __syncthreads();
 #define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
@@ -820,6 +833,9 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                     run += s_hist[cc];
                 }
                 s_nleft = run;  // reused: cursor of the uncoloured tail
+                const uint32_t kept = np - s_npruned;
+                s_ptail = kept;  // cursor of the pruned pairs behind them
+                atomicAdd(&ctr->n_kept, kept);
                 const uint32_t bstart = atomicAdd(&ctr->tp_cursor, np);
                 s_bstart = bstart;
                 const uint32_t t0 = s_tile[f];
@@ -827,7 +843,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 const uint32_t ph = (t0 & 1u) | (((t0 >> lx) & 1u) << 1);
                 BatchDesc d;
                 d.first = BIG ? ((e0 + f) | 0x80000000u) : (e0 + f);
-                d.count = c; d.bstart = bstart; d.np = np; d.ncol = nc; d.nb = nb; d.pad[0] = d.pad[1] = 0u;
+                d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nb; d.pad[0] = d.pad[1] = 0u;
                 const uint32_t bidx = atomicAdd(&ctr->n_batches[ph], 1u);
                 batches[ph * g.pstride + bidx] = d;
                 s_bidx = bidx;
@@ -842,6 +858,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
             // polygon core, core-core, anything with a POLY), so that the lanes of a wave take the
             // same branch of the narrowphase.  s_prop is free now: it keeps the class.
             for (uint32_t e = tid; e < np; e += kBlock) {
+                if (s_col[e] == SFX_PRUNED_COLOR) continue;
                 const uint32_t ta = __float_as_uint(shape[s_a[e]].x) & 0xFFu, tb = __float_as_uint(shape[s_b[e]].x) & 0xFFu;
                 const uint32_t nc = (ta == SFX_SHAPE_CIRCLE ? 1u : 0u) + (tb == SFX_SHAPE_CIRCLE ? 1u : 0u);
                 const uint32_t cls = (ta == SFX_SHAPE_POLY || tb == SFX_SHAPE_POLY) ? 3u : 2u - nc;
@@ -856,10 +873,11 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
             __syncthreads();
             for (uint32_t e = tid; e < np; e += kBlock) {
                 const uint32_t cc = s_col[e];
-                const uint32_t dst = (cc < SFX_MAX_COLORS) ? atomicAdd(&s_base[cc], 1u) : atomicAdd(&s_nleft, 1u);
+                const uint32_t dst = (cc < SFX_MAX_COLORS) ? atomicAdd(&s_base[cc], 1u)
+                                     : (cc == SFX_PRUNED_COLOR) ? atomicAdd(&s_ptail, 1u) : atomicAdd(&s_nleft, 1u);
                 const uint32_t la = s_la[e], lb = s_lb[e];
                 tpair[bstart + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), cc | (s_tile[f + s_tj[e]] << 8));
-                torder[bstart + atomicAdd(&s_cls[s_prop[e]], 1u)] = dst;
+                if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_prop[e]], 1u)] = dst;
             }
             __syncthreads();
         }

@@ -28,9 +28,16 @@ def colors_by_key(keys, colors, tiles=None):
     return keys[order], colors[order], tiles[order]
 
 
+PRUNED_COLOR = 0xFE
+
+
 def coloring_valid(keys, colors, dynamic, tiles=None):
     """No dynamic body appears twice within one colour of one batch (tile / fallback list);
-    every pair coloured."""
+    every pair within reach coloured (PRUNED_COLOR marks the pairs the reach test dropped)."""
+    live = colors != PRUNED_COLOR
+    keys, colors = keys[live], colors[live]
+    if tiles is not None:
+        tiles = tiles[live]
     a = (keys >> np.uint64(32)).astype(np.int64)
     b = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
     if np.any(colors >= 64):

@@ -7,7 +7,7 @@ import pytest
 from oracle.oracle import OracleWorld
 from starframe_amd import scenes
 from starframe_amd.scenes import SceneBuilder
-from tests.helpers import coloring_valid, colors_by_key, tile_phases_disjoint
+from tests.helpers import PRUNED_COLOR, coloring_valid, colors_by_key, tile_phases_disjoint
 
 DT = 1.0 / 60.0
 
@@ -80,7 +80,8 @@ def test_colouring_is_valid_and_deterministic(rounds):
     assert tile_phases_disjoint(k1, t1, dyn, tuple(rc.grid_log2), rc.tile_cells)
     st = w.stats()
     assert st.n_colors <= 40
-    assert sum(st.color_count) == st.n_pairs
+    assert sum(st.color_count) == st.n_solver_pairs == int((c1 != PRUNED_COLOR).sum())
+    assert 0 < st.n_solver_pairs < st.n_pairs   # the reach test dropped some AABB-only candidates
     assert st.n_tiles > 4 and st.n_fallback == int((t1 == 0xFFFFFFFF).sum())
     if rounds == 1:
         assert st.n_leftover > 0  # the serial finish did real work
@@ -191,3 +192,34 @@ def test_auto_grid_and_cell_resolution():
     assert rc.grid_log2[0] == rc.grid_log2[1] == 5
     assert rc.max_pairs == 12 * s.n
     assert rc.tile_cells == 1 and rc.tile_cells_y == 32   # sparse scene: automatic full-height strips
+
+
+@pytest.mark.parametrize("speed", [0.0, 1.5])
+def test_reach_test_only_drops_pairs_that_cannot_touch(speed):
+    """DESIGN.md "Contract / solver pairs": a dropped candidate pair has no contact point, not even
+    a speculative one, at the tick's start, and stays apart for the whole tick when the bodies move
+    as far as their AABB pads allow for."""
+    s = scenes.random_soup(1500, seed=11, extent=7.0)
+    rng = np.random.default_rng(5)
+    s.vel[:] = speed * rng.uniform(-1, 1, s.vel.shape).astype(np.float32) * (s.inv_mass > 0)[:, None]
+    w = OracleWorld.from_scene(s, gravity=(0.0, 0.0))
+    w.broadphase(DT)
+    k, c, t = w.pair_colors()
+    dropped = set(int(x) for x in k[c == PRUNED_COLOR])
+    assert len(dropped) > 50
+    assert set(int(x) for x in k) == set(int(x) for x in w.pairs())  # the candidate set itself is untouched
+
+    def touching():
+        con = w.contacts()
+        keys = (con["body_a"].astype(np.uint64) << np.uint64(32)) | con["body_b"].astype(np.uint64)
+        return set(int(x) for x in keys[con["count"] > 0])
+
+    assert not (touching() & dropped)
+    if speed:
+        # move everything by its velocity over the tick (no forces, no solve): still nothing dropped touches
+        pos, rot = w.poses()
+        w2 = OracleWorld.from_scene(s.with_state(pos + s.vel * DT, rot), gravity=(0.0, 0.0))
+        w2.broadphase(DT)
+        con = w2.contacts()
+        keys = (con["body_a"].astype(np.uint64) << np.uint64(32)) | con["body_b"].astype(np.uint64)
+        assert not (set(int(x) for x in keys[con["count"] > 0]) & dropped)
