@@ -390,9 +390,13 @@ int broadphase(sfx_world* w, float dt) {
     RP.pose = w->pose.p; RP.vel = w->vel.p; RP.poly = w->poly.p;
     RP.margin = w->cfg.aabb_margin; RP.vel_pad_max = w->cfg.vel_pad_max; RP.dt = dt; RP.sm = w->cfg.speculative_margin;
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
+      const uint32_t est = w->ctr_valid ? w->stale.n_tile_pairs + w->stale.n_tile_pairs / 4u + 4096u : w->max_pairs;
+      hipLaunchKernelGGL(k_reach, dim3(cdiv(std::min(est, w->max_pairs), kBlock)), dim3(kBlock), 0, w->stream, w->tile_cnt,
+                         w->ntiles, w->max_pairs, w->rawp.p, w->shape.p, RP); }
+    { Prof p(w, SFX_K_COLOR, w->max_pairs);
       hipLaunchKernelGGL((k_batch_color<kBatchP, false>), dim3(w->color_grid, 4), dim3(512), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
-                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, RP, w->max_pairs, w->cfg.color_rounds, w->ctr); }
+                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->max_pairs, w->cfg.color_rounds, w->ctr); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
     return SFX_OK;

@@ -651,9 +651,24 @@ struct ReachParams {
     float margin, vel_pad_max, dt, sm;
 };
 
+// Reach test of every tile-owned pair (DESIGN.md "Contract / solver pairs"), one pair per lane:
+// a pair that cannot touch in this tick gets bit 31 of its first slot word set.
+constexpr uint32_t kOutOfReach = 0x80000000u;
+
+__global__ __launch_bounds__(kBlock) void k_reach(const uint32_t* __restrict__ tile_start, uint32_t ntiles, uint32_t max_pairs,
+                                                   uint4* __restrict__ rawp, const float4* __restrict__ shape, ReachParams RP) {
+    const uint32_t total = min(tile_start[ntiles], max_pairs);
+    for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < total; k += gridDim.x * kBlock) {
+        const uint4 rp = rawp[k];
+        const bool keep = pair_in_reach(RP.pose[rp.x], shape[rp.x], RP.vel[rp.x], RP.pose[rp.y], shape[rp.y], RP.vel[rp.y],
+                                        RP.poly, RP.margin, RP.vel_pad_max, RP.dt, RP.sm);
+        if (!keep) rawp[k].z = rp.z | kOutOfReach;
+    }
+}
+
 // Forms the batches and edge-colours every tile's pair graph, all state in LDS (DESIGN.md
-// "Contract / colouring").  Pairs that fail the reach test (DESIGN.md "Contract / solver pairs")
-// are not coloured; they are listed behind the batch's pairs with SFX_PRUNED_COLOR.  A workgroup takes `group` consecutive tiles of a phase's list and
+// "Contract / colouring").  Pairs that failed the reach test are not coloured; they are listed
+// behind the batch's pairs with SFX_PRUNED_COLOR.  A workgroup takes `group` consecutive tiles of a phase's list and
 // cuts them greedily into batches of at most kBatchP pairs and kMaxB bodies (BIG: one tile of
 // the big list per batch, up to kMaxP pairs).  Per batch it writes the pairs colour-major as
 // (id a, id b, local a | local b << 16, colour | tile << 8) and a BatchDesc on the phase's table.
@@ -665,7 +680,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                                                          const uint32_t* __restrict__ list, const uint4* __restrict__ rawp,
                                                          uint4* __restrict__ tpair, BatchDesc* __restrict__ batches,
                                                          const float4* __restrict__ shape, uint32_t* __restrict__ torder,
-                                                         uint32_t* __restrict__ tile_batch, ReachParams RP,
+                                                         uint32_t* __restrict__ tile_batch,
                                                          uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr) {
     constexpr uint32_t MB = kMaxB;
     constexpr uint32_t kBlock = 512;  // shadows the file-level constant: this kernel runs 512 threads
@@ -740,11 +755,10 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 while (j + 1 < c && s_poff[j + 1] <= e) ++j;
                 const uint4 rp = rawp[s_tstart[f + j] + (e - s_poff[j])];
                 s_a[e] = rp.x; s_b[e] = rp.y;
-                s_la[e] = (uint16_t)batch_local(S, j, rp.z);
+                s_la[e] = (uint16_t)batch_local(S, j, rp.z & ~kOutOfReach);
                 s_lb[e] = (uint16_t)batch_local(S, j, rp.w);
                 s_tj[e] = (uint8_t)j;
-                const bool keep = pair_in_reach(RP.pose[rp.x], shape[rp.x], RP.vel[rp.x], RP.pose[rp.y], shape[rp.y],
-                                                RP.vel[rp.y], RP.poly, RP.margin, RP.vel_pad_max, RP.dt, RP.sm);
+                const bool keep = !(rp.z & kOutOfReach);
                 s_col[e] = keep ? SFX_NO_COLOR : SFX_PRUNED_COLOR;
                 if (!keep) atomicAdd(&s_npruned, 1u);
             }
