@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 5u
+#define SFX_ABI_VERSION 6u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -154,11 +154,19 @@ typedef struct sfx_frame_stats {
     uint32_t color_count[SFX_MAX_COLORS]; /* pairs per colour, summed over tiles + fallback */
 } sfx_frame_stats;
 
+/* closest hit of one ray, as returned by sfx_query_rays */
+#define SFX_NO_BODY 0xFFFFFFFFu
+typedef struct sfx_ray_hit {
+    uint32_t body;   /* SFX_NO_BODY: nothing hit within max_t                        */
+    float t;         /* hit point = origin + t * direction (0 when the origin is inside) */
+    float normal[2]; /* outward unit normal of the surface hit; (0, 0) when t == 0 inside */
+} sfx_ray_hit;
+
 /* per kernel-class device time, filled while profiling is on */
 typedef enum sfx_kernel_class {
     SFX_K_AABB_COUNT = 0, SFX_K_SCAN, SFX_K_SCATTER, SFX_K_PAIR_COUNT, SFX_K_PAIR_FILL,
     SFX_K_TILE_LIST, SFX_K_COLOR, SFX_K_INTEGRATE, SFX_K_SOLVE_JOINTS, SFX_K_SOLVE_POS,
-    SFX_K_DERIVE_VEL, SFX_K_SOLVE_VEL, SFX_K_STATS, SFX_K_HALO, SFX_K_CLASSES
+    SFX_K_DERIVE_VEL, SFX_K_SOLVE_VEL, SFX_K_STATS, SFX_K_HALO, SFX_K_QUERY, SFX_K_CLASSES
 } sfx_kernel_class;
 
 typedef struct sfx_kernel_time {
@@ -223,6 +231,30 @@ int sfx_halo_copy(sfx_world* dst, uint32_t dst_first, sfx_world* src, uint32_t s
 
 int sfx_download_poses(sfx_world* w, float* pos, float* rot);
 int sfx_download_velocities(sfx_world* w, float* vel, float* angvel);
+
+/* ---- spatial queries over the device grid ("ray cast,
+ * point/AABB query -- upstream's mouse-pick/raycast API"; the reference source is absent, so the
+ * contract is DESIGN.md "Contract / spatial queries") -------------------------------------------
+ * Queries see the colliders at their CURRENT poses.  The first query after a tick or an upload
+ * sorts the colliders' tight AABBs (no margin, no velocity pad) into a grid index of its own
+ * (same cell size as the tick's broadphase; allocated at the first query), later queries reuse
+ * it.  A collider takes part when (category & mask) != 0.  Not allowed between sfx_tick_begin
+ * and the tick's last sfx_tick_substep.  Arrays are caller-owned host memory; the calls
+ * synchronise. */
+/* point query: per point the lowest id of the bodies whose collider contains it (boundary
+ * included; SFX_NO_BODY if none) and, if count != NULL, how many do */
+int sfx_query_points(sfx_world* w, uint32_t n, const float* points /* [n][2] */, uint32_t mask,
+                     uint32_t* body /* [n] */, uint32_t* count /* [n] or NULL */);
+/* box query: (query << 32 | body) for every collider whose tight AABB overlaps box q =
+ * (lo.x, lo.y, hi.x, hi.y) (closed intervals), ascending.  *n_hits is the full count even when
+ * it exceeds cap: then SFX_ERR_CAPACITY is returned, hits holds some cap of them, and the caller
+ * repeats the query with room for *n_hits */
+int sfx_query_aabbs(sfx_world* w, uint32_t n, const float* boxes /* [n][4] */, uint32_t mask,
+                    uint64_t* hits, size_t cap, size_t* n_hits);
+/* ray cast: closest hit of origin + t * direction, 0 <= t <= max_t[q], per ray
+ * (origin.x, origin.y, dir.x, dir.y); equal t: lowest body id.  direction need not be unit */
+int sfx_query_rays(sfx_world* w, uint32_t n, const float* rays /* [n][4] */, const float* max_t /* [n] */,
+                   uint32_t mask, sfx_ray_hit* hits /* [n] */);
 
 /* ---- parity hooks (slow paths, used by tests) ----------------------------- */
 /* world AABBs [n][4] = (lo.x, lo.y, hi.x, hi.y) of the last tick's broadphase */

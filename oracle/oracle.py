@@ -71,6 +71,12 @@ def load():
     lib.sfo_contact_pair.restype = C.c_int
     lib.sfo_joint_order.argtypes = [vp, vp, vp, C.c_size_t]
     lib.sfo_joint_order.restype = C.c_size_t
+    lib.sfo_query_points.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_uint32, vp, vp, C.c_int]
+    lib.sfo_query_points.restype = C.c_int
+    lib.sfo_query_aabbs.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_uint32, vp, C.c_size_t, C.c_int]
+    lib.sfo_query_aabbs.restype = C.c_size_t
+    lib.sfo_query_rays.argtypes = [vp, C.c_uint32, P(C.c_float), P(C.c_float), C.c_uint32, vp, C.c_int]
+    lib.sfo_query_rays.restype = C.c_int
     _lib = lib
     return lib
 
@@ -134,6 +140,32 @@ class OracleWorld(WorldBase):
         a = np.ascontiguousarray(arr, np.float32)
         assert a.shape == (self.n_halo_recv, 8)
         self._check(self.lib.sfo_halo_put(self.handle, vptr(self._recv_idx), self.n_halo_recv, fptr(a)))
+
+    # ---- spatial queries: brute=True walks all colliders, else the grid index (must agree exactly)
+    def query_points(self, points, mask=0xFFFFFFFF, brute=False):
+        p = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+        body = np.empty(len(p), np.uint32)
+        count = np.empty(len(p), np.uint32)
+        self._check(self.lib.sfo_query_points(self.handle, len(p), fptr(p), mask, vptr(body), vptr(count), int(brute)))
+        return body, count
+
+    def query_aabbs(self, boxes, mask=0xFFFFFFFF, brute=False):
+        b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4)
+        cap = max(16 * len(b), 1024)
+        while True:
+            hits = np.empty(cap, np.uint64)
+            n = self.lib.sfo_query_aabbs(self.handle, len(b), fptr(b), mask, vptr(hits), cap, int(brute))
+            if n > cap:
+                cap = n
+                continue
+            return hits[:n]
+
+    def query_rays(self, rays, max_t, mask=0xFFFFFFFF, brute=False):
+        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 4)
+        mt = np.ascontiguousarray(np.broadcast_to(np.asarray(max_t, np.float32), (len(r),)))
+        out = np.zeros(len(r), _abi.ray_hit_dtype)
+        self._check(self.lib.sfo_query_rays(self.handle, len(r), fptr(r), fptr(mt), mask, vptr(out), int(brute)))
+        return out
 
     def broadphase(self, dt):
         self._check(self.lib.sfo_broadphase(self.handle, dt))

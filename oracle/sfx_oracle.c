@@ -16,6 +16,7 @@
  */
 #include "sfx_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -455,7 +456,7 @@ int sfo_upload_constraints(sfo_world* w, uint32_t m, const sfx_distance_constrai
 
 /* ------------------------------------------------------------------ AABB
  * [DESIGN] DESIGN.md "Contract / AABB".  Operation order is part of the contract. */
-static void compute_aabb(const sfo_world* w, uint32_t i, float dt, float* out) {
+static void compute_aabb_ex(const sfo_world* w, uint32_t i, float dt, float margin, float vel_pad_max, float* out) {
     const sfx_collider* c = &w->col[i];
     float px = w->pos[2 * i], py = w->pos[2 * i + 1];
     float rc = w->rot[2 * i], rs = w->rot[2 * i + 1];
@@ -491,12 +492,16 @@ static void compute_aabb(const sfo_world* w, uint32_t i, float dt, float* out) {
         out[0] = out[1] = INFINITY; out[2] = out[3] = -INFINITY;
         return;
     }
-    float padx = w->cfg.aabb_margin + fminf(fabsf(w->vel[2 * i]) * dt, w->cfg.vel_pad_max);
-    float pady = w->cfg.aabb_margin + fminf(fabsf(w->vel[2 * i + 1]) * dt, w->cfg.vel_pad_max);
+    float padx = margin + fminf(fabsf(w->vel[2 * i]) * dt, vel_pad_max);
+    float pady = margin + fminf(fabsf(w->vel[2 * i + 1]) * dt, vel_pad_max);
     out[0] = (px + minx) - padx;
     out[1] = (py + miny) - pady;
     out[2] = (px + maxx) + padx;
     out[3] = (py + maxy) + pady;
+}
+
+static void compute_aabb(const sfo_world* w, uint32_t i, float dt, float* out) {
+    compute_aabb_ex(w, i, dt, w->cfg.aabb_margin, w->cfg.vel_pad_max, out);
 }
 
 static int pair_filter(const sfo_world* w, uint32_t i, uint32_t j) {
@@ -1614,5 +1619,328 @@ int sfo_stats(const sfo_world* w, sfx_frame_stats* out) {
             ke += 0.5 * (1.0 / w->inv_inertia[i]) * (double)w->angvel[i] * w->angvel[i];
     }
     out->kinetic_energy = (float)ke;
+    return SFX_OK;
+}
+
+/* ------------------------------------------------------------------ spatial queries
+ * [DESIGN] DESIGN.md "Contract / spatial queries" (no reference
+ * source to follow).  Queries see the colliders at their current poses through their TIGHT
+ * AABBs (the contract's AABB with margin 0 and no velocity pad).  Per collider the tests are
+ *   point : box contains the point (closed) and the shape contains it (circle: d^2 <= r^2; core
+ *           of >= 3 vertices: no face separates, else distance to the core boundary <= r);
+ *   box   : closed-interval overlap of the two boxes;
+ *   ray   : slab test of the box over [0, max_t], then the origin inside the shape (t = 0) or the
+ *           first entry into the union of the core's offset faces and (r > 0) vertex discs.
+ * Each query comes in two enumerations that must agree exactly: brute force over all colliders,
+ * and the grid index (small colliders by home cell of the box's low corner, large ones listed). */
+
+typedef struct {
+    float* box;       /* [n][4] tight AABBs */
+    uint32_t* start;  /* [ncell + 1] */
+    uint32_t* slot;   /* small ids, bucket-major, ascending id inside a bucket */
+    int32_t *cx, *cy; /* home cell per body */
+    uint32_t* large;
+    uint32_t ns, nl;
+    float blo[2], bhi[2]; /* bounds of the small colliders' boxes */
+} qindex;
+
+static void qindex_free(qindex* q) {
+    free(q->box); free(q->start); free(q->slot); free(q->cx); free(q->cy); free(q->large);
+}
+
+static void qindex_build(const sfo_world* w, qindex* q, int with_grid) {
+    uint32_t n = w->n, GX = 1u << w->gxl, GY = 1u << w->gyl, ncell = GX * GY;
+    memset(q, 0, sizeof(*q));
+    q->box = (float*)malloc((n ? n : 1) * 4 * sizeof(float));
+    for (uint32_t i = 0; i < n; ++i) compute_aabb_ex(w, i, 0.0f, 0.0f, 0.0f, &q->box[4 * i]);
+    if (!with_grid) return;
+    q->start = (uint32_t*)calloc((size_t)ncell + 1, sizeof(uint32_t));
+    q->slot = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    q->cx = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+    q->cy = (int32_t*)malloc((n ? n : 1) * sizeof(int32_t));
+    q->large = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    uint32_t* bucket = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    float lim = 0.9f * w->cell;
+    q->blo[0] = q->blo[1] = INFINITY; q->bhi[0] = q->bhi[1] = -INFINITY;
+    for (uint32_t i = 0; i < n; ++i) {
+        bucket[i] = 0xFFFFFFFFu;
+        if (w->col[i].type == SFX_SHAPE_NONE) continue;
+        const float* A = &q->box[4 * i];
+        if ((A[2] - A[0]) <= lim && (A[3] - A[1]) <= lim) {
+            q->cx[i] = cell_coord(A[0], w->inv_cell);
+            q->cy[i] = cell_coord(A[1], w->inv_cell);
+            bucket[i] = (((uint32_t)q->cy[i] & (GY - 1)) << w->gxl) | ((uint32_t)q->cx[i] & (GX - 1));
+            q->start[bucket[i] + 1]++;
+            q->ns++;
+            q->blo[0] = fminf(q->blo[0], A[0]); q->blo[1] = fminf(q->blo[1], A[1]);
+            q->bhi[0] = fmaxf(q->bhi[0], A[2]); q->bhi[1] = fmaxf(q->bhi[1], A[3]);
+        } else {
+            q->large[q->nl++] = i;
+        }
+    }
+    for (uint32_t c = 0; c < ncell; ++c) q->start[c + 1] += q->start[c];
+    uint32_t* fill = (uint32_t*)malloc((size_t)ncell * sizeof(uint32_t));
+    memcpy(fill, q->start, (size_t)ncell * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; ++i)
+        if (bucket[i] != 0xFFFFFFFFu) q->slot[fill[bucket[i]]++] = i;
+    free(fill); free(bucket);
+}
+
+static int shape_contains(const core_t* c, float px, float py) {
+    if (c->n <= 0) return 0;
+    if (c->n == 1) {
+        float dx = px - c->vx[0], dy = py - c->vy[0];
+        return dx * dx + dy * dy <= c->r * c->r;
+    }
+    if (c->n >= 3) {
+        float sep = -INFINITY;
+        for (int k = 0; k < c->n; ++k) {
+            float s = c->nx[k] * (px - c->vx[k]) + c->ny[k] * (py - c->vy[k]);
+            if (s > sep) sep = s;
+        }
+        if (sep <= 0.0f) return 1;
+    }
+    float qx, qy, d2;
+    closest_on_poly(c, px, py, &qx, &qy, &d2);
+    return d2 <= c->r * c->r;
+}
+
+/* first entry of the ray into the disc (cx, cy, r), origin outside it */
+static int ray_disc(float ox, float oy, float dx, float dy, float cx, float cy, float r, float* t, float* nx, float* ny) {
+    if (!(r > 0.0f)) return 0;
+    float mx = ox - cx, my = oy - cy;
+    float a = dx * dx + dy * dy;
+    float b = mx * dx + my * dy;
+    float c = (mx * mx + my * my) - r * r;
+    if (!(a > 0.0f) || !(b < 0.0f)) return 0;
+    float disc = b * b - a * c;
+    if (!(disc >= 0.0f)) return 0;
+    float tt = (-b - sqrtf(disc)) / a;
+    if (!(tt >= 0.0f)) return 0;
+    *t = tt;
+    *nx = (mx + tt * dx) / r;
+    *ny = (my + tt * dy) / r;
+    return 1;
+}
+
+/* first entry of the ray into the posed shape, origin outside it; first minimum wins
+ * (faces in order, then vertex discs in order) */
+static int ray_shape(const core_t* c, float ox, float oy, float dx, float dy, float* t, float* nx, float* ny) {
+    if (c->n <= 0) return 0;
+    if (c->n == 1) return ray_disc(ox, oy, dx, dy, c->vx[0], c->vy[0], c->r, t, nx, ny);
+    float best = INFINITY, bnx = 0.0f, bny = 0.0f;
+    for (int k = 0; k < c->n; ++k) {
+        int k1 = (k + 1 == c->n) ? 0 : k + 1;
+        float denom = dx * c->nx[k] + dy * c->ny[k];
+        if (denom < 0.0f) {
+            float p0x = c->vx[k] + c->r * c->nx[k], p0y = c->vy[k] + c->r * c->ny[k];
+            float num = (p0x - ox) * c->nx[k] + (p0y - oy) * c->ny[k];
+            float tt = num / denom;
+            if (tt >= 0.0f && tt < best) {
+                float hx = ox + tt * dx, hy = oy + tt * dy;
+                float ex = c->vx[k1] - c->vx[k], ey = c->vy[k1] - c->vy[k];
+                float u = (hx - p0x) * ex + (hy - p0y) * ey;
+                float ee = ex * ex + ey * ey;
+                if (u >= 0.0f && u <= ee) { best = tt; bnx = c->nx[k]; bny = c->ny[k]; }
+            }
+        }
+    }
+    if (c->r > 0.0f) {
+        for (int k = 0; k < c->n; ++k) {
+            float tt, mx, my;
+            if (ray_disc(ox, oy, dx, dy, c->vx[k], c->vy[k], c->r, &tt, &mx, &my) && tt < best) {
+                best = tt; bnx = mx; bny = my;
+            }
+        }
+    }
+    if (!(best < INFINITY)) return 0;
+    *t = best; *nx = bnx; *ny = bny;
+    return 1;
+}
+
+static int ray_box(const float* A, float ox, float oy, float dx, float dy, float max_t) {
+    float t0 = 0.0f, t1 = max_t;
+    if (dx != 0.0f) {
+        float ta = (A[0] - ox) / dx, tb = (A[2] - ox) / dx;
+        if (ta > tb) { float s = ta; ta = tb; tb = s; }
+        t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
+    } else if (ox < A[0] || ox > A[2]) return 0;
+    if (dy != 0.0f) {
+        float ta = (A[1] - oy) / dy, tb = (A[3] - oy) / dy;
+        if (ta > tb) { float s = ta; ta = tb; tb = s; }
+        t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
+    } else if (oy < A[1] || oy > A[3]) return 0;
+    return t0 <= t1;
+}
+
+typedef struct { uint32_t body; float t, nx, ny; } ray_best;
+
+static void ray_try(const sfo_world* w, const qindex* q, uint32_t i, uint32_t mask, const float* ray, float max_t,
+                    ray_best* best) {
+    if (!(w->col[i].category & mask)) return;
+    if (!ray_box(&q->box[4 * i], ray[0], ray[1], ray[2], ray[3], max_t)) return;
+    core_t c;
+    build_core(w, i, &c);
+    float t = 0.0f, nx = 0.0f, ny = 0.0f;
+    if (!shape_contains(&c, ray[0], ray[1])) {
+        if (!ray_shape(&c, ray[0], ray[1], ray[2], ray[3], &t, &nx, &ny)) return;
+        if (!(t <= max_t)) return;
+    }
+    if (best->body == SFX_NO_BODY || t < best->t || (t == best->t && i < best->body)) {
+        best->body = i; best->t = t; best->nx = nx; best->ny = ny;
+    }
+}
+
+static void point_try(const sfo_world* w, const qindex* q, uint32_t i, uint32_t mask, float px, float py,
+                      uint32_t* lowest, uint32_t* count) {
+    if (!(w->col[i].category & mask)) return;
+    const float* A = &q->box[4 * i];
+    if (px < A[0] || px > A[2] || py < A[1] || py > A[3]) return;
+    core_t c;
+    build_core(w, i, &c);
+    if (!shape_contains(&c, px, py)) return;
+    if (i < *lowest) *lowest = i;
+    ++*count;
+}
+
+/* clamps to the cell range of the small colliders before converting (rays may be infinite) */
+static int32_t cell_clamped(float v_cells, float lo_cells, float hi_cells) {
+    float f = floorf(fminf(fmaxf(v_cells, lo_cells - 2.0f), hi_cells + 2.0f));
+    return (int32_t)f;
+}
+
+int sfo_query_points(const sfo_world* w, uint32_t n, const float* points, uint32_t mask, uint32_t* body,
+                     uint32_t* count, int brute) {
+    if (!w->col) return SFX_ERR_INVALID;
+    qindex q;
+    qindex_build(w, &q, !brute);
+    uint32_t GX = 1u << w->gxl, GY = 1u << w->gyl;
+    for (uint32_t k = 0; k < n; ++k) {
+        float px = points[2 * k], py = points[2 * k + 1];
+        uint32_t lowest = SFX_NO_BODY, cnt = 0;
+        if (brute) {
+            for (uint32_t i = 0; i < w->n; ++i)
+                if (w->col[i].type != SFX_SHAPE_NONE) point_try(w, &q, i, mask, px, py, &lowest, &cnt);
+        } else {
+            /* a small box holding the point has its low corner in the point's cell or the one before */
+            int32_t cx = cell_coord(px, w->inv_cell), cy = cell_coord(py, w->inv_cell);
+            for (int32_t Y = cy - 1; Y <= cy; ++Y)
+                for (int32_t X = cx - 1; X <= cx; ++X) {
+                    uint32_t b = (((uint32_t)Y & (GY - 1)) << w->gxl) | ((uint32_t)X & (GX - 1));
+                    for (uint32_t s = q.start[b]; s < q.start[b + 1]; ++s) {
+                        uint32_t i = q.slot[s];
+                        if (q.cx[i] == X && q.cy[i] == Y) point_try(w, &q, i, mask, px, py, &lowest, &cnt);
+                    }
+                }
+            for (uint32_t l = 0; l < q.nl; ++l) point_try(w, &q, q.large[l], mask, px, py, &lowest, &cnt);
+        }
+        body[k] = lowest;
+        if (count) count[k] = cnt;
+    }
+    qindex_free(&q);
+    return SFX_OK;
+}
+
+size_t sfo_query_aabbs(const sfo_world* w, uint32_t n, const float* boxes, uint32_t mask, uint64_t* hits, size_t cap,
+                       int brute) {
+    if (!w->col) return 0;
+    qindex q;
+    qindex_build(w, &q, !brute);
+    uint32_t GX = 1u << w->gxl, GY = 1u << w->gyl;
+    size_t nh = 0;
+#define BOX_TRY(i)                                                                              \
+    do {                                                                                        \
+        if ((w->col[(i)].category & mask) && aabb_overlap(B, &q.box[4 * (i)])) {                \
+            if (nh < cap) hits[nh] = ((uint64_t)k << 32) | (i);                                 \
+            ++nh;                                                                               \
+        }                                                                                       \
+    } while (0)
+    for (uint32_t k = 0; k < n; ++k) {
+        const float* B = &boxes[4 * k];
+        if (brute) {
+            for (uint32_t i = 0; i < w->n; ++i)
+                if (w->col[i].type != SFX_SHAPE_NONE) BOX_TRY(i);
+            continue;
+        }
+        if (q.ns && B[0] <= B[2] && B[1] <= B[3]) {
+            float lox = q.blo[0] * w->inv_cell, hix = q.bhi[0] * w->inv_cell;
+            float loy = q.blo[1] * w->inv_cell, hiy = q.bhi[1] * w->inv_cell;
+            int32_t x0 = cell_clamped(B[0] * w->inv_cell, lox, hix) - 1, x1 = cell_clamped(B[2] * w->inv_cell, lox, hix);
+            int32_t y0 = cell_clamped(B[1] * w->inv_cell, loy, hiy) - 1, y1 = cell_clamped(B[3] * w->inv_cell, loy, hiy);
+            uint32_t nx = (uint32_t)(x1 - x0 + 1), ny = (uint32_t)(y1 - y0 + 1);
+            if (nx > GX) nx = GX;
+            if (ny > GY) ny = GY;
+            for (uint32_t by = 0; by < ny; ++by)
+                for (uint32_t bx = 0; bx < nx; ++bx) {
+                    uint32_t b = ((((uint32_t)y0 + by) & (GY - 1)) << w->gxl) | (((uint32_t)x0 + bx) & (GX - 1));
+                    for (uint32_t s = q.start[b]; s < q.start[b + 1]; ++s) {
+                        uint32_t i = q.slot[s];
+                        if (q.cx[i] >= x0 && q.cx[i] <= x1 && q.cy[i] >= y0 && q.cy[i] <= y1) BOX_TRY(i);
+                    }
+                }
+        }
+        for (uint32_t l = 0; l < q.nl; ++l) BOX_TRY(q.large[l]);
+    }
+#undef BOX_TRY
+    qsort(hits, nh < cap ? nh : cap, sizeof(uint64_t), cmp_u64);
+    qindex_free(&q);
+    return nh;
+}
+
+int sfo_query_rays(const sfo_world* w, uint32_t n, const float* rays, const float* max_t, uint32_t mask,
+                   sfx_ray_hit* out, int brute) {
+    if (!w->col) return SFX_ERR_INVALID;
+    qindex q;
+    qindex_build(w, &q, !brute);
+    uint32_t GX = 1u << w->gxl, GY = 1u << w->gyl;
+    for (uint32_t k = 0; k < n; ++k) {
+        const float* ray = &rays[4 * k];
+        ray_best best = {SFX_NO_BODY, 0.0f, 0.0f, 0.0f};
+        float mt = max_t[k];
+        if (mt >= 0.0f) {
+            mt = fminf(mt, FLT_MAX);
+            if (brute) {
+                for (uint32_t i = 0; i < w->n; ++i)
+                    if (w->col[i].type != SFX_SHAPE_NONE) ray_try(w, &q, i, mask, ray, mt, &best);
+            } else {
+                for (uint32_t l = 0; l < q.nl; ++l) ray_try(w, &q, q.large[l], mask, ray, mt, &best);
+                if (q.ns) {
+                    /* columns of home cells along the major axis; a collider homed in column X lies
+                     * within [X, X + 1.9) cells of that axis */
+                    const int M = fabsf(ray[3]) > fabsf(ray[2]) ? 1 : 0, m = 1 - M;
+                    const float oM = ray[M], dM = ray[2 + M], om = ray[m], dm = ray[2 + m];
+                    const float inv = w->inv_cell, cell = w->cell;
+                    const float bloM = q.blo[M] * inv, bhiM = q.bhi[M] * inv, blom = q.blo[m] * inv, bhim = q.bhi[m] * inv;
+                    const float a = oM * inv, b = (oM + mt * dM) * inv;
+                    const int32_t X0 = cell_clamped(fminf(a, b) - 0.05f, bloM, bhiM) - 1;
+                    const int32_t X1 = cell_clamped(fmaxf(a, b) + 0.05f, bloM, bhiM);
+                    const int32_t step = dM < 0.0f ? -1 : 1;
+                    for (int32_t X = step > 0 ? X0 : X1; X >= X0 && X <= X1; X += step) {
+                        float ta = -INFINITY, tb = INFINITY;
+                        if (dM != 0.0f) {
+                            ta = (((float)X - 0.05f) * cell - oM) / dM;
+                            tb = (((float)X + 2.0f) * cell - oM) / dM;
+                            if (ta > tb) { float s = ta; ta = tb; tb = s; }
+                        }
+                        if (best.body != SFX_NO_BODY && best.t < ta) break; /* nothing further on can be closer */
+                        const float tin = fminf(fmaxf(ta, 0.0f), mt), tout = fmaxf(fminf(tb, mt), 0.0f);
+                        const float ya = (om + tin * dm) * inv, yb = (om + tout * dm) * inv;
+                        const int32_t Y0 = cell_clamped(fminf(ya, yb) - 0.05f, blom, bhim) - 1;
+                        const int32_t Y1 = cell_clamped(fmaxf(ya, yb) + 0.05f, blom, bhim);
+                        for (int32_t Y = Y0; Y <= Y1; ++Y) {
+                            const int32_t hx = M ? Y : X, hy = M ? X : Y;
+                            uint32_t bk = (((uint32_t)hy & (GY - 1)) << w->gxl) | ((uint32_t)hx & (GX - 1));
+                            for (uint32_t s = q.start[bk]; s < q.start[bk + 1]; ++s) {
+                                uint32_t i = q.slot[s];
+                                if (q.cx[i] == hx && q.cy[i] == hy) ray_try(w, &q, i, mask, ray, mt, &best);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        out[k].body = best.body; out[k].t = best.t; out[k].normal[0] = best.nx; out[k].normal[1] = best.ny;
+    }
+    qindex_free(&q);
     return SFX_OK;
 }

@@ -78,6 +78,15 @@ int sfo_contact_pair(const sfo_world* w, uint32_t a, uint32_t b, sfx_contact* ou
 size_t sfo_joint_order(const sfo_world* w, uint32_t* perm, uint8_t* colors, size_t cap);
 int sfo_stats(const sfo_world* w, sfx_frame_stats* out);
 
+/* spatial queries at the current poses (sfx.h: sfx_query_*); brute != 0: over all colliders,
+ * else through the grid index -- the two must agree exactly */
+int sfo_query_points(const sfo_world* w, uint32_t n, const float* points, uint32_t mask, uint32_t* body,
+                     uint32_t* count, int brute);
+size_t sfo_query_aabbs(const sfo_world* w, uint32_t n, const float* boxes, uint32_t mask, uint64_t* hits, size_t cap,
+                       int brute);
+int sfo_query_rays(const sfo_world* w, uint32_t n, const float* rays, const float* max_t, uint32_t mask,
+                   sfx_ray_hit* out, int brute);
+
 #ifdef __cplusplus
 }
 #endif

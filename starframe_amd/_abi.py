@@ -83,7 +83,8 @@ class SfxKernelTime(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("launches", C.c_uint64), ("items", C.c_uint64)]
 
 
-K_CLASSES = 14
+K_CLASSES = 15
+NO_BODY = 0xFFFFFFFF
 
 collider_dtype = np.dtype(
     [
@@ -122,7 +123,9 @@ contact_dtype = np.dtype(
 assert collider_dtype.itemsize == 40
 assert material_dtype.itemsize == 12
 assert constraint_dtype.itemsize == 32
+ray_hit_dtype = np.dtype([("body", "<u4"), ("t", "<f4"), ("normal", "<f4", (2,))])
 assert contact_dtype.itemsize == 60
+assert ray_hit_dtype.itemsize == 16
 
 
 def make_config(
@@ -181,6 +184,7 @@ SFX_SYMBOLS = [
     "sfx_step", "sfx_sync", "sfx_download_poses", "sfx_download_velocities",
     "sfx_tick_begin", "sfx_tick_substep", "sfx_set_stream", "sfx_halo_set", "sfx_halo_pack", "sfx_halo_unpack",
     "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy",
+    "sfx_query_points", "sfx_query_aabbs", "sfx_query_rays",
     "sfx_debug_aabbs", "sfx_debug_pairs", "sfx_debug_pair_colors", "sfx_debug_broadphase",
     "sfx_debug_contacts", "sfx_debug_joint_order",
     "sfx_stats", "sfx_set_profiling", "sfx_kernel_times", "sfx_kernel_class_name",
@@ -245,6 +249,11 @@ def load_libsfx(path=None):
     lib.sfx_halo_copy.argtypes = [vp, C.c_uint32, vp, C.c_uint32, C.c_uint32]
     for n in ("sfx_tick_begin", "sfx_tick_substep", "sfx_set_stream", "sfx_halo_set", "sfx_halo_pack",
               "sfx_halo_unpack", "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy"):
+        getattr(lib, n).restype = C.c_int
+    lib.sfx_query_points.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_uint32, vp, vp]
+    lib.sfx_query_aabbs.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_uint32, vp, C.c_size_t, P(C.c_size_t)]
+    lib.sfx_query_rays.argtypes = [vp, C.c_uint32, P(C.c_float), P(C.c_float), C.c_uint32, vp]
+    for n in ("sfx_query_points", "sfx_query_aabbs", "sfx_query_rays"):
         getattr(lib, n).restype = C.c_int
     lib.sfx_debug_aabbs.argtypes = [vp, P(C.c_float)]
     lib.sfx_debug_pairs.argtypes = [vp, vp, C.c_size_t, P(C.c_size_t)]

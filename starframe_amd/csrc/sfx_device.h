@@ -856,4 +856,136 @@ __device__ __forceinline__ void solve_joint(const BodyArrays& B, const JointArra
     }
 }
 
+// ---- spatial queries (DESIGN.md "Contract / spatial queries") -----------------------------
+// Same operations in the same order as oracle/sfx_oracle.c (shape_contains, ray_disc, ray_shape,
+// ray_box): the results are compared bit for bit.
+template <int MAXV>
+__device__ __forceinline__ bool shape_contains(const Core<MAXV>& c, float px, float py) {
+    if (c.n <= 0) return false;
+    if (c.n == 1) {
+        const float dx = px - c.vx[0], dy = py - c.vy[0];
+        return dx * dx + dy * dy <= c.r * c.r;
+    }
+    if (c.n >= 3) {
+        float sep = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            if (k < c.n) {
+                const float s = c.nx[k] * (px - c.vx[k]) + c.ny[k] * (py - c.vy[k]);
+                if (s > sep) sep = s;
+            }
+        }
+        if (sep <= 0.0f) return true;
+    }
+    float qx, qy, d2;
+    closest_on_poly<MAXV>(c, px, py, qx, qy, d2);
+    return d2 <= c.r * c.r;
+}
+
+// first entry of the ray into the disc (cx, cy, r), origin outside it
+__device__ __forceinline__ bool ray_disc(float ox, float oy, float dx, float dy, float cx, float cy, float r, float& t,
+                                         float& nx, float& ny) {
+    if (!(r > 0.0f)) return false;
+    const float mx = ox - cx, my = oy - cy;
+    const float a = dx * dx + dy * dy;
+    const float b = mx * dx + my * dy;
+    const float c = (mx * mx + my * my) - r * r;
+    if (!(a > 0.0f) || !(b < 0.0f)) return false;
+    const float disc = b * b - a * c;
+    if (!(disc >= 0.0f)) return false;
+    const float tt = (-b - sqrtf(disc)) / a;
+    if (!(tt >= 0.0f)) return false;
+    t = tt;
+    nx = (mx + tt * dx) / r;
+    ny = (my + tt * dy) / r;
+    return true;
+}
+
+// first entry of the ray into the posed shape, origin outside it; first minimum wins (faces in
+// order, then vertex discs in order)
+template <int MAXV>
+__device__ __forceinline__ bool ray_shape(const Core<MAXV>& c, float ox, float oy, float dx, float dy, float& t, float& nx,
+                                          float& ny) {
+    if (c.n <= 0) return false;
+    if (c.n == 1) return ray_disc(ox, oy, dx, dy, c.vx[0], c.vy[0], c.r, t, nx, ny);
+    float best = INFINITY, bnx = 0.0f, bny = 0.0f;
+#pragma unroll
+    for (int k = 0; k < MAXV; ++k) {
+        if (k < c.n) {
+            const bool wrap = (k + 1 == c.n) || (k + 1 == MAXV);
+            const float x1 = wrap ? c.vx[0] : c.vx[(k + 1) % MAXV];
+            const float y1 = wrap ? c.vy[0] : c.vy[(k + 1) % MAXV];
+            const float denom = dx * c.nx[k] + dy * c.ny[k];
+            if (denom < 0.0f) {
+                const float p0x = c.vx[k] + c.r * c.nx[k], p0y = c.vy[k] + c.r * c.ny[k];
+                const float num = (p0x - ox) * c.nx[k] + (p0y - oy) * c.ny[k];
+                const float tt = num / denom;
+                if (tt >= 0.0f && tt < best) {
+                    const float hx = ox + tt * dx, hy = oy + tt * dy;
+                    const float ex = x1 - c.vx[k], ey = y1 - c.vy[k];
+                    const float u = (hx - p0x) * ex + (hy - p0y) * ey;
+                    const float ee = ex * ex + ey * ey;
+                    if (u >= 0.0f && u <= ee) { best = tt; bnx = c.nx[k]; bny = c.ny[k]; }
+                }
+            }
+        }
+    }
+    if (c.r > 0.0f) {
+#pragma unroll
+        for (int k = 0; k < MAXV; ++k) {
+            if (k < c.n) {
+                float tt, mx, my;
+                if (ray_disc(ox, oy, dx, dy, c.vx[k], c.vy[k], c.r, tt, mx, my) && tt < best) { best = tt; bnx = mx; bny = my; }
+            }
+        }
+    }
+    if (!(best < INFINITY)) return false;
+    t = best; nx = bnx; ny = bny;
+    return true;
+}
+
+__device__ __forceinline__ bool ray_box(const float4& A, float ox, float oy, float dx, float dy, float max_t) {
+    float t0 = 0.0f, t1 = max_t;
+    if (dx != 0.0f) {
+        float ta = (A.x - ox) / dx, tb = (A.z - ox) / dx;
+        if (ta > tb) { const float s = ta; ta = tb; tb = s; }
+        t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
+    } else if (ox < A.x || ox > A.z) return false;
+    if (dy != 0.0f) {
+        float ta = (A.y - oy) / dy, tb = (A.w - oy) / dy;
+        if (ta > tb) { const float s = ta; ta = tb; tb = s; }
+        t0 = fmaxf(t0, ta); t1 = fminf(t1, tb);
+    } else if (oy < A.y || oy > A.w) return false;
+    return t0 <= t1;
+}
+
+// point / ray against one posed collider of any type
+__device__ __forceinline__ bool collider_contains(const float4& pose, const float4& shape, const float4* __restrict__ poly,
+                                                  float px, float py) {
+    if (shape_type(shape) == SFX_SHAPE_POLY) {
+        Core<8> c;
+        build_core<8>(pose, shape, poly, c);
+        return shape_contains<8>(c, px, py);
+    }
+    Core<4> c;
+    build_core<4>(pose, shape, poly, c);
+    return shape_contains<4>(c, px, py);
+}
+
+// origin inside: t = 0, normal (0, 0); else the first entry, if any
+__device__ __forceinline__ bool collider_ray(const float4& pose, const float4& shape, const float4* __restrict__ poly,
+                                             float ox, float oy, float dx, float dy, float& t, float& nx, float& ny) {
+    t = 0.0f; nx = 0.0f; ny = 0.0f;
+    if (shape_type(shape) == SFX_SHAPE_POLY) {
+        Core<8> c;
+        build_core<8>(pose, shape, poly, c);
+        if (shape_contains<8>(c, ox, oy)) return true;
+        return ray_shape<8>(c, ox, oy, dx, dy, t, nx, ny);
+    }
+    Core<4> c;
+    build_core<4>(pose, shape, poly, c);
+    if (shape_contains<4>(c, ox, oy)) return true;
+    return ray_shape<4>(c, ox, oy, dx, dy, t, nx, ny);
+}
+
 }  // namespace sfx

@@ -88,6 +88,13 @@ struct sfx_world {
     DevBuf<uint32_t> halo_send_idx, halo_recv_idx;
     DevBuf<float4> halo_send, halo_recv;
     uint32_t n_halo_send = 0, n_halo_recv = 0;
+    // spatial query index (allocated at the first query; DESIGN.md "Contract / spatial queries")
+    DevBuf<uint32_t> q_zero, q_bucket, q_cell_fill, q_tmp_id, q_sorted_id, q_large_tmp, q_bounds, q_nhits;
+    DevBuf<float4> q_aabb, q_sorted_aabb;
+    DevBuf<int2> q_cellxy, q_sorted_cell;
+    size_t q_zero_bytes = 0;
+    uint32_t q_n = 0, q_ncell = 0;
+    bool q_valid = false;
     // tick in pieces
     StepParams sp{};
     bool tick_open = false;
@@ -537,6 +544,9 @@ void sfx_destroy(sfx_world* w) {
     w->used.release(); w->claim.release(); w->left_list.release();
     w->pcolor.release(); w->prop.release(); w->jctr.release(); w->dbg.release();
     w->halo_send_idx.release(); w->halo_recv_idx.release(); w->halo_send.release(); w->halo_recv.release();
+    w->q_zero.release(); w->q_bucket.release(); w->q_cell_fill.release(); w->q_tmp_id.release(); w->q_sorted_id.release();
+    w->q_large_tmp.release(); w->q_bounds.release(); w->q_nhits.release(); w->q_aabb.release(); w->q_sorted_aabb.release();
+    w->q_cellxy.release(); w->q_sorted_cell.release();
     w->c_hdr.release(); w->c_anc0.release(); w->c_anc1.release(); w->c_lam.release(); w->c_vpre.release(); w->c_misc.release();
     w->j_bodies.release(); w->j_anchors.release(); w->j_params.release(); w->j_count_dev.release();
     if (w->h_ctr) (void)hipHostFree(w->h_ctr);
@@ -601,6 +611,7 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
     HIPCHK(w, hipStreamSynchronize(w->stream));
     w->have_bodies = true;
     w->ticked = false;
+    w->q_valid = false;
     return rebuild_filt(w);
 }
 
@@ -690,6 +701,7 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     HIPCHK(w, hipMemset(w->zero.p, 0, w->zero_bytes));
     w->ctr_valid = false; w->ctr_pending = false;
     w->ticked = false;
+    w->q_valid = false;
     return rebuild_filt(w);
 }
 
@@ -802,6 +814,7 @@ int sfx_tick_substep(sfx_world* w) {
     HIPCHK(w, hipSetDevice(w->device));
     const uint32_t n = w->n;
     const StepParams sp = w->sp;
+    w->q_valid = false;
     const BodyArrays B = body_arrays(w);
     const ContactArrays C = contact_arrays(w);
     JointArrays J;
@@ -908,6 +921,7 @@ int sfx_halo_unpack(sfx_world* w) {
     if (!w) return SFX_ERR_INVALID;
     if (!w->n_halo_recv) return SFX_OK;
     HIPCHK(w, hipSetDevice(w->device));
+    w->q_valid = false;
     Prof p(w, SFX_K_HALO, w->n_halo_recv);
     hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv(w->n_halo_recv, kBlock)), dim3(kBlock), 0, w->stream, w->n_halo_recv,
                        w->halo_recv_idx.p, w->halo_recv.p, w->pose.p, w->vel.p);
@@ -965,6 +979,140 @@ int sfx_halo_copy(sfx_world* dst, uint32_t dst_first, sfx_world* src, uint32_t s
         HIPCHK(dst, hipEventDestroy(ev));
     }
     return SFX_OK;
+}
+
+// ---- spatial queries ------------------------------------------------------------------
+namespace {
+
+// (re)builds the query index at the current poses: the broadphase's counting sort on tight AABBs
+// (margin, pad and dt = 0, row-major buckets) in buffers of its own, then the bounds of the small boxes
+int ensure_query_index(sfx_world* w) {
+    int rc = ready(w);
+    if (rc) return rc;
+    if (w->tick_open) return fail(w, SFX_ERR_INVALID, "spatial queries are not allowed inside an open tick");
+    HIPCHK(w, hipSetDevice(w->device));
+    const uint32_t n = w->n;
+    const size_t pad = kScanItems;
+    if (w->q_n != n || w->q_ncell != w->ncell || !w->q_zero.p) {
+        const size_t c = std::max(n, 1u);
+        const size_t words = sizeof(Counters) / 4 + ((size_t)w->ncell + 1 + pad);
+        const size_t words16 = (words + 3) & ~(size_t)3;
+        ALLOC(w, w->q_zero, words16);
+        w->q_zero_bytes = words16 * 4;
+        ALLOC(w, w->q_cell_fill, (size_t)w->ncell + 1 + pad);
+        ALLOC(w, w->q_bucket, c); ALLOC(w, w->q_tmp_id, c); ALLOC(w, w->q_sorted_id, c); ALLOC(w, w->q_large_tmp, c);
+        ALLOC(w, w->q_aabb, c); ALLOC(w, w->q_sorted_aabb, c); ALLOC(w, w->q_cellxy, c); ALLOC(w, w->q_sorted_cell, c);
+        ALLOC(w, w->q_bounds, 4); ALLOC(w, w->q_nhits, 1);
+        w->q_n = n; w->q_ncell = w->ncell;
+        w->q_valid = false;
+    }
+    if (w->q_valid) return SFX_OK;
+    Counters* qctr = reinterpret_cast<Counters*>(w->q_zero.p);
+    uint32_t* qcs = w->q_zero.p + sizeof(Counters) / 4;
+    GridParams g = grid_params(w);
+    g.tlx = 0; g.tly = 0; g.ntiles = w->ncell; g.pstride = 0;  // plain row-major buckets
+    const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
+    { Prof p(w, SFX_K_QUERY, 0);
+      const uint32_t n16 = (uint32_t)(w->q_zero_bytes / 16);
+      hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, reinterpret_cast<uint4*>(w->q_zero.p), n16); }
+    HIPCHK(w, hipMemsetAsync(w->q_bounds.p, 0, 4 * sizeof(uint32_t), w->stream));
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p, w->poly.p,
+                         0.0f, 0.0f, 0.0f, g, w->q_aabb.p, w->q_bucket.p, w->q_cellxy.p, qcs, w->q_large_tmp.p, w->large_cap, qctr); }
+    rc = scan_u32(w, qcs, w->ncell + 1, w->q_cell_fill.p);
+    if (rc) return rc;
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(kBlock), 0, w->stream, n, w->q_bucket.p, w->q_cell_fill.p, w->q_tmp_id.p); }
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_finalize_slots, dim3(gb), dim3(kBlock), 0, w->stream, n, g, qcs, w->q_tmp_id.p, w->q_bucket.p,
+                         w->q_aabb.p, w->q_cellxy.p, w->q_large_tmp.p, w->large_cap, w->q_sorted_id.p, w->q_sorted_aabb.p,
+                         w->q_sorted_cell.p, qctr); }
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_query_bounds, dim3(std::min(gb, 1024u)), dim3(kBlock), 0, w->stream, qcs, w->ncell,
+                         w->q_sorted_aabb.p, w->q_bounds.p); }
+    HIPCHK(w, hipGetLastError());
+    w->q_valid = true;
+    return SFX_OK;
+}
+
+QueryIndex query_index(sfx_world* w) {
+    QueryIndex Q;
+    Q.cell_start = w->q_zero.p + sizeof(Counters) / 4;
+    Q.sorted_id = w->q_sorted_id.p; Q.sorted_aabb = w->q_sorted_aabb.p; Q.sorted_cell = w->q_sorted_cell.p;
+    Q.ctr = reinterpret_cast<const Counters*>(w->q_zero.p);
+    Q.bounds = w->q_bounds.p;
+    Q.gxl = w->gxl; Q.gyl = w->gyl; Q.ncell = w->ncell; Q.large_cap = w->large_cap;
+    Q.inv_cell = w->inv_cell; Q.cell = w->cell;
+    return Q;
+}
+
+}  // namespace
+
+int sfx_query_points(sfx_world* w, uint32_t n, const float* points, uint32_t mask, uint32_t* body, uint32_t* count) {
+    if (!w || (n && (!points || !body))) return fail(w, SFX_ERR_INVALID, "null argument");
+    int rc = ensure_query_index(w);
+    if (rc || n == 0) return rc;
+    DevBuf<float2> d_pts;
+    DevBuf<uint32_t> d_out;
+    ALLOC(w, d_pts, n); ALLOC(w, d_out, 2 * (size_t)n);
+    HIPCHK(w, hipMemcpyAsync(d_pts.p, points, sizeof(float2) * n, hipMemcpyHostToDevice, w->stream));
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_query_points, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, w->stream, n, d_pts.p, mask, query_index(w),
+                         body_arrays(w), d_out.p, d_out.p + n); }
+    hipError_t e = hipMemcpyAsync(body, d_out.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, w->stream);
+    if (e == hipSuccess && count) e = hipMemcpyAsync(count, d_out.p + n, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, w->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+    d_pts.release(); d_out.release();
+    if (e != hipSuccess) return fail(w, SFX_ERR_DEVICE, "point query failed: %s", hipGetErrorString(e));
+    return w->profiling ? collect_profile(w) : SFX_OK;
+}
+
+int sfx_query_aabbs(sfx_world* w, uint32_t n, const float* boxes, uint32_t mask, uint64_t* hits, size_t cap, size_t* n_hits) {
+    if (!w || (n && !boxes) || !n_hits || (cap && !hits)) return fail(w, SFX_ERR_INVALID, "null argument");
+    *n_hits = 0;
+    int rc = ensure_query_index(w);
+    if (rc || n == 0) return rc;
+    const uint32_t dcap = (uint32_t)std::min<size_t>(cap, 0xFFFFFFF0u);
+    DevBuf<float4> d_box;
+    DevBuf<unsigned long long> d_hits;
+    ALLOC(w, d_box, n); ALLOC(w, d_hits, std::max<size_t>(dcap, 1));
+    HIPCHK(w, hipMemcpyAsync(d_box.p, boxes, sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipMemsetAsync(w->q_nhits.p, 0, sizeof(uint32_t), w->stream));
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_query_aabbs, dim3(std::min(cdiv(n, kBlock / 64), 4096u)), dim3(kBlock), 0, w->stream, n, d_box.p, mask,
+                         query_index(w), body_arrays(w), d_hits.p, dcap, w->q_nhits.p); }
+    uint32_t total = 0;
+    hipError_t e = hipMemcpyAsync(&total, w->q_nhits.p, sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+    const size_t got = std::min<size_t>(total, dcap);
+    if (e == hipSuccess && got) e = hipMemcpy(hits, d_hits.p, sizeof(uint64_t) * got, hipMemcpyDeviceToHost);
+    d_box.release(); d_hits.release();
+    if (e != hipSuccess) return fail(w, SFX_ERR_DEVICE, "box query failed: %s", hipGetErrorString(e));
+    std::sort(hits, hits + got);
+    *n_hits = total;
+    if (w->profiling) { rc = collect_profile(w); if (rc) return rc; }
+    if (total > dcap) return fail(w, SFX_ERR_CAPACITY, "box query found %u hits, room for %zu", total, cap);
+    return SFX_OK;
+}
+
+int sfx_query_rays(sfx_world* w, uint32_t n, const float* rays, const float* max_t, uint32_t mask, sfx_ray_hit* hits) {
+    if (!w || (n && (!rays || !max_t || !hits))) return fail(w, SFX_ERR_INVALID, "null argument");
+    int rc = ensure_query_index(w);
+    if (rc || n == 0) return rc;
+    DevBuf<float4> d_rays;
+    DevBuf<float> d_mt;
+    DevBuf<sfx_ray_hit> d_out;
+    ALLOC(w, d_rays, n); ALLOC(w, d_mt, n); ALLOC(w, d_out, n);
+    HIPCHK(w, hipMemcpyAsync(d_rays.p, rays, sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipMemcpyAsync(d_mt.p, max_t, sizeof(float) * n, hipMemcpyHostToDevice, w->stream));
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_query_rays, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, w->stream, n, d_rays.p, d_mt.p, mask, query_index(w),
+                         body_arrays(w), d_out.p); }
+    hipError_t e = hipMemcpyAsync(hits, d_out.p, sizeof(sfx_ray_hit) * n, hipMemcpyDeviceToHost, w->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
+    d_rays.release(); d_mt.release(); d_out.release();
+    if (e != hipSuccess) return fail(w, SFX_ERR_DEVICE, "ray query failed: %s", hipGetErrorString(e));
+    return w->profiling ? collect_profile(w) : SFX_OK;
 }
 
 int sfx_sync(sfx_world* w) {
@@ -1182,7 +1330,7 @@ int sfx_debug_tile_timing(sfx_world* w, unsigned long long* out, int reset) {
 const char* sfx_kernel_class_name(int cls) {
     static const char* names[SFX_K_CLASSES] = {
         "aabb_count", "scan", "scatter", "pair_count", "pair_fill", "tile_list", "color", "integrate",
-        "solve_joints", "solve_pos", "derive_vel", "solve_vel", "stats", "halo"};
+        "solve_joints", "solve_pos", "derive_vel", "solve_vel", "stats", "halo", "query"};
     return (cls >= 0 && cls < SFX_K_CLASSES) ? names[cls] : "?";
 }
 

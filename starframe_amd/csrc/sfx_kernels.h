@@ -1683,4 +1683,195 @@ __global__ __launch_bounds__(kBlock) void k_contacts_debug(uint32_t np, const ui
     out[k] = c;
 }
 
+// ---------------------------------------------------------------- spatial queries
+// DESIGN.md "Contract / spatial queries".  The query index is the broadphase's counting sort run
+// on the colliders' tight AABBs at the current poses (k_aabb_count with margin, pad and dt = 0,
+// row-major buckets; k_scan_*, k_scatter, k_finalize_slots) into buffers of its own, plus the
+// bounds of the small colliders' boxes (k_query_bounds), which keep rays and boxes of any length
+// to a bounded walk.  Every kernel enumerates a superset of the colliders that can pass the
+// per-collider test and applies that test exactly as the oracle does.
+struct QueryIndex {
+    const uint32_t* cell_start;
+    const uint32_t* sorted_id;
+    const float4* sorted_aabb;
+    const int2* sorted_cell;
+    const Counters* ctr;      // n_large
+    const uint32_t* bounds;   // ordered keys, see fkey(): [~min x, ~min y, max x, max y], 0 = nothing yet
+    uint32_t gxl, gyl, ncell, large_cap;
+    float inv_cell, cell;
+};
+
+// monotone map float -> uint32 (and back), so that integer atomicMax orders floats
+__device__ __forceinline__ uint32_t fkey(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7FFFFFFFu) : ~k);
+}
+
+__global__ __launch_bounds__(kBlock) void k_query_bounds(const uint32_t* __restrict__ cell_start, uint32_t ncell,
+                                                          const float4* __restrict__ sorted_aabb,
+                                                          uint32_t* __restrict__ bounds) {
+    const uint32_t ns = cell_start[ncell];
+    uint32_t k0 = 0u, k1 = 0u, k2 = 0u, k3 = 0u;
+    for (uint32_t p = blockIdx.x * kBlock + threadIdx.x; p < ns; p += gridDim.x * kBlock) {
+        const float4 A = sorted_aabb[p];
+        k0 = max(k0, ~fkey(A.x)); k1 = max(k1, ~fkey(A.y)); k2 = max(k2, fkey(A.z)); k3 = max(k3, fkey(A.w));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        k0 = max(k0, (uint32_t)__shfl_xor((int)k0, off, 64)); k1 = max(k1, (uint32_t)__shfl_xor((int)k1, off, 64));
+        k2 = max(k2, (uint32_t)__shfl_xor((int)k2, off, 64)); k3 = max(k3, (uint32_t)__shfl_xor((int)k3, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0 && k2) {
+        atomicMax(&bounds[0], k0); atomicMax(&bounds[1], k1); atomicMax(&bounds[2], k2); atomicMax(&bounds[3], k3);
+    }
+}
+
+// clamps to the cell range of the small colliders before converting (rays may be infinite)
+__device__ __forceinline__ int32_t cell_clamped(float v_cells, float lo_cells, float hi_cells) {
+    const float f = floorf(fminf(fmaxf(v_cells, lo_cells - 2.0f), hi_cells + 2.0f));
+    return (int32_t)f;
+}
+
+__device__ __forceinline__ uint32_t query_bucket(const QueryIndex& Q, int32_t X, int32_t Y) {
+    return (((uint32_t)Y & ((1u << Q.gyl) - 1u)) << Q.gxl) | ((uint32_t)X & ((1u << Q.gxl) - 1u));
+}
+
+// one point per lane: the four home cells a small box holding the point can have, then the large list
+__global__ __launch_bounds__(kBlock) void k_query_points(uint32_t nq, const float2* __restrict__ pts, uint32_t mask,
+                                                          QueryIndex Q, BodyArrays B, uint32_t* __restrict__ body,
+                                                          uint32_t* __restrict__ count) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nq) return;
+    const float2 p = pts[k];
+    const uint32_t ns = Q.cell_start[Q.ncell], nl = min(Q.ctr->n_large, Q.large_cap);
+    uint32_t lowest = SFX_NO_BODY, cnt = 0u;
+    auto try_slot = [&](uint32_t slot) {
+        const uint32_t i = Q.sorted_id[slot];
+        if (!(B.filt[i].x & mask)) return;
+        const float4 A = Q.sorted_aabb[slot];
+        if (p.x < A.x || p.x > A.z || p.y < A.y || p.y > A.w) return;
+        if (!collider_contains(B.pose[i], B.shape[i], B.poly, p.x, p.y)) return;
+        lowest = min(lowest, i);
+        ++cnt;
+    };
+    if (ns) {
+        const int32_t cx = cell_coord(p.x, Q.inv_cell), cy = cell_coord(p.y, Q.inv_cell);
+        for (int32_t Y = cy - 1; Y <= cy; ++Y)
+            for (int32_t X = cx - 1; X <= cx; ++X) {
+                const uint32_t b = query_bucket(Q, X, Y);
+                for (uint32_t s = Q.cell_start[b], e = Q.cell_start[b + 1]; s < e; ++s) {
+                    const int2 c = Q.sorted_cell[s];
+                    if (c.x == X && c.y == Y) try_slot(s);
+                }
+            }
+    }
+    for (uint32_t l = 0; l < nl; ++l) try_slot(ns + l);
+    body[k] = lowest;
+    if (count) count[k] = cnt;
+}
+
+// one box per wave: the lanes share the home cells the box reaches, then the large list; hits are
+// appended (query << 32 | body) in no particular order, n_hits counts all of them
+__global__ __launch_bounds__(kBlock) void k_query_aabbs(uint32_t nq, const float4* __restrict__ boxes, uint32_t mask,
+                                                         QueryIndex Q, BodyArrays B, unsigned long long* __restrict__ hits,
+                                                         uint32_t cap, uint32_t* __restrict__ n_hits) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
+    const uint32_t ns = Q.cell_start[Q.ncell], nl = min(Q.ctr->n_large, Q.large_cap);
+    const uint32_t GX = 1u << Q.gxl, GY = 1u << Q.gyl;
+    for (uint32_t k = wave; k < nq; k += nwaves) {
+        const float4 Bx = boxes[k];
+        auto try_slot = [&](uint32_t slot) {
+            const uint32_t i = Q.sorted_id[slot];
+            if (!(B.filt[i].x & mask)) return;
+            if (!aabb_overlap(Bx, Q.sorted_aabb[slot])) return;
+            const uint32_t idx = atomicAdd(n_hits, 1u);
+            if (idx < cap) hits[idx] = ((unsigned long long)k << 32) | i;
+        };
+        if (ns && Bx.x <= Bx.z && Bx.y <= Bx.w) {
+            const float lox = fkey_inv(~Q.bounds[0]) * Q.inv_cell, hix = fkey_inv(Q.bounds[2]) * Q.inv_cell;
+            const float loy = fkey_inv(~Q.bounds[1]) * Q.inv_cell, hiy = fkey_inv(Q.bounds[3]) * Q.inv_cell;
+            const int32_t x0 = cell_clamped(Bx.x * Q.inv_cell, lox, hix) - 1, x1 = cell_clamped(Bx.z * Q.inv_cell, lox, hix);
+            const int32_t y0 = cell_clamped(Bx.y * Q.inv_cell, loy, hiy) - 1, y1 = cell_clamped(Bx.w * Q.inv_cell, loy, hiy);
+            const uint32_t nx = min((uint32_t)(x1 - x0 + 1), GX), ny = min((uint32_t)(y1 - y0 + 1), GY);
+            for (uint32_t c = (uint32_t)lane; c < nx * ny; c += 64u) {
+                const uint32_t by = c / nx, bx = c - by * nx;
+                const uint32_t b = query_bucket(Q, x0 + (int32_t)bx, y0 + (int32_t)by);
+                for (uint32_t s = Q.cell_start[b], e = Q.cell_start[b + 1]; s < e; ++s) {
+                    const int2 cc = Q.sorted_cell[s];
+                    if (cc.x >= x0 && cc.x <= x1 && cc.y >= y0 && cc.y <= y1) try_slot(s);
+                }
+            }
+        }
+        for (uint32_t l = (uint32_t)lane; l < nl; l += 64u) try_slot(ns + l);
+    }
+}
+
+// one ray per lane: the large list, then columns of home cells along the ray's major axis (a
+// collider homed in column X lies within [X, X + 1.9) cells of that axis), nearest column first,
+// until the best hit lies before the next column
+__global__ __launch_bounds__(kBlock) void k_query_rays(uint32_t nq, const float4* __restrict__ rays,
+                                                        const float* __restrict__ max_t, uint32_t mask, QueryIndex Q,
+                                                        BodyArrays B, sfx_ray_hit* __restrict__ out) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nq) return;
+    const float4 ray = rays[k];
+    const uint32_t ns = Q.cell_start[Q.ncell], nl = min(Q.ctr->n_large, Q.large_cap);
+    uint32_t bbody = SFX_NO_BODY;
+    float bt = 0.0f, bnx = 0.0f, bny = 0.0f;
+    float mt = max_t[k];
+    if (mt >= 0.0f) {
+        mt = fminf(mt, 3.402823466e+38f);
+        auto try_slot = [&](uint32_t slot) {
+            const uint32_t i = Q.sorted_id[slot];
+            if (!(B.filt[i].x & mask)) return;
+            if (!ray_box(Q.sorted_aabb[slot], ray.x, ray.y, ray.z, ray.w, mt)) return;
+            float t, nx, ny;
+            if (!collider_ray(B.pose[i], B.shape[i], B.poly, ray.x, ray.y, ray.z, ray.w, t, nx, ny)) return;
+            if (!(t <= mt)) return;
+            if (bbody == SFX_NO_BODY || t < bt || (t == bt && i < bbody)) { bbody = i; bt = t; bnx = nx; bny = ny; }
+        };
+        for (uint32_t l = 0; l < nl; ++l) try_slot(ns + l);
+        if (ns) {
+            const bool My = fabsf(ray.w) > fabsf(ray.z);
+            const float oM = My ? ray.y : ray.x, dM = My ? ray.w : ray.z, om = My ? ray.x : ray.y, dm = My ? ray.z : ray.w;
+            const float inv = Q.inv_cell, cell = Q.cell;
+            const float blx = fkey_inv(~Q.bounds[0]) * inv, bhx = fkey_inv(Q.bounds[2]) * inv;
+            const float bly = fkey_inv(~Q.bounds[1]) * inv, bhy = fkey_inv(Q.bounds[3]) * inv;
+            const float bloM = My ? bly : blx, bhiM = My ? bhy : bhx, blom = My ? blx : bly, bhim = My ? bhx : bhy;
+            const float a = oM * inv, b = (oM + mt * dM) * inv;
+            const int32_t X0 = cell_clamped(fminf(a, b) - 0.05f, bloM, bhiM) - 1;
+            const int32_t X1 = cell_clamped(fmaxf(a, b) + 0.05f, bloM, bhiM);
+            const int32_t step = dM < 0.0f ? -1 : 1;
+            for (int32_t X = step > 0 ? X0 : X1; X >= X0 && X <= X1; X += step) {
+                float ta = -INFINITY, tb = INFINITY;
+                if (dM != 0.0f) {
+                    ta = (((float)X - 0.05f) * cell - oM) / dM;
+                    tb = (((float)X + 2.0f) * cell - oM) / dM;
+                    if (ta > tb) { const float s = ta; ta = tb; tb = s; }
+                }
+                if (bbody != SFX_NO_BODY && bt < ta) break;  // nothing further on can be closer
+                const float tin = fminf(fmaxf(ta, 0.0f), mt), tout = fmaxf(fminf(tb, mt), 0.0f);
+                const float ya = (om + tin * dm) * inv, yb = (om + tout * dm) * inv;
+                const int32_t Y0 = cell_clamped(fminf(ya, yb) - 0.05f, blom, bhim) - 1;
+                const int32_t Y1 = cell_clamped(fmaxf(ya, yb) + 0.05f, blom, bhim);
+                for (int32_t Y = Y0; Y <= Y1; ++Y) {
+                    const int32_t hx = My ? Y : X, hy = My ? X : Y;
+                    const uint32_t bk = query_bucket(Q, hx, hy);
+                    for (uint32_t s = Q.cell_start[bk], e = Q.cell_start[bk + 1]; s < e; ++s) {
+                        const int2 c = Q.sorted_cell[s];
+                        if (c.x == hx && c.y == hy) try_slot(s);
+                    }
+                }
+            }
+        }
+    }
+    sfx_ray_hit h;
+    h.body = bbody; h.t = bt; h.normal[0] = bnx; h.normal[1] = bny;
+    out[k] = h;
+}
+
 }  // namespace sfx

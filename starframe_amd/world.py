@@ -9,7 +9,8 @@ import numpy as np
 
 from . import _abi
 from ._abi import (
-    K_CLASSES, SFX_OK, SfxFrameStats, SfxKernelTime, contact_dtype, fptr, make_config, vptr,
+    K_CLASSES, SFX_ERR_CAPACITY, SFX_OK, SfxFrameStats, SfxKernelTime, contact_dtype, fptr, make_config,
+    ray_hit_dtype, vptr,
 )
 
 
@@ -167,6 +168,37 @@ class World(WorldBase):
     def halo_copy_from(self, src, dst_first, src_first, count):
         """Device-to-device: src's send buffer [src_first, +count) -> this world's receive buffer."""
         self._check(self.lib.sfx_halo_copy(self.handle, dst_first, src.handle, src_first, count))
+
+    # ---- spatial queries at the current poses (include/sfx.h "spatial queries")
+    def query_points(self, points, mask=0xFFFFFFFF):
+        """Per point: lowest id of the bodies whose collider contains it (NO_BODY if none), and how many do."""
+        p = np.ascontiguousarray(points, np.float32).reshape(-1, 2)
+        body = np.empty(len(p), np.uint32)
+        count = np.empty(len(p), np.uint32)
+        self._check(self.lib.sfx_query_points(self.handle, len(p), fptr(p), mask, vptr(body), vptr(count)))
+        return body, count
+
+    def query_aabbs(self, boxes, mask=0xFFFFFFFF, cap=None):
+        """Ascending keys (query << 32 | body) of the colliders whose tight AABB overlaps each box."""
+        b = np.ascontiguousarray(boxes, np.float32).reshape(-1, 4)
+        cap = cap if cap is not None else max(16 * len(b), 1024)
+        while True:
+            hits = np.empty(cap, np.uint64)
+            n = C.c_size_t()
+            rc = self.lib.sfx_query_aabbs(self.handle, len(b), fptr(b), mask, vptr(hits), cap, C.byref(n))
+            if rc == SFX_ERR_CAPACITY and n.value > cap:
+                cap = n.value
+                continue
+            self._check(rc)
+            return hits[: n.value]
+
+    def query_rays(self, rays, max_t, mask=0xFFFFFFFF):
+        """Closest hit per ray (origin.x, origin.y, dir.x, dir.y): structured array (body, t, normal)."""
+        r = np.ascontiguousarray(rays, np.float32).reshape(-1, 4)
+        mt = np.ascontiguousarray(np.broadcast_to(np.asarray(max_t, np.float32), (len(r),)))
+        out = np.zeros(len(r), ray_hit_dtype)
+        self._check(self.lib.sfx_query_rays(self.handle, len(r), fptr(r), fptr(mt), mask, vptr(out)))
+        return out
 
     # ---- parity hooks
     def broadphase(self, dt):

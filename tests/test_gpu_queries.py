@@ -1,0 +1,101 @@
+"""GPU parity of the spatial queries (include/sfx.h "spatial queries"):
+libsfx through the C ABI against the CPU oracle on identical inputs.  Body ids, containment counts
+and box hits bit-exact; ray parameters and normals within 1e-5 relative (same operation order on
+both sides, so 0 ulp is what is observed).  PARITY UNPINNED against starframe itself."""
+import numpy as np
+import pytest
+
+from starframe_amd import scenes
+from starframe_amd._abi import NO_BODY
+from tests.test_oracle_queries import query_inputs
+
+pytestmark = pytest.mark.gpu
+
+DT = 1.0 / 60.0
+
+
+def make_pair(scene, **kw):
+    from oracle.oracle import OracleWorld
+    from starframe_amd.world import World
+
+    return World.from_scene(scene, **kw), OracleWorld.from_scene(scene, **kw)
+
+
+def check_queries(g, o, pts, boxes, rays, max_t, masks=(0xFFFFFFFF, 2)):
+    n_hit = 0
+    for mask in masks:
+        gb, gc = g.query_points(pts, mask)
+        ob, oc = o.query_points(pts, mask)
+        assert np.array_equal(gb, ob) and np.array_equal(gc, oc)
+        assert np.array_equal(g.query_aabbs(boxes, mask), o.query_aabbs(boxes, mask))
+        gh = g.query_rays(rays, max_t, mask)
+        oh = o.query_rays(rays, max_t, mask)
+        assert np.array_equal(gh["body"], oh["body"])
+        hit = oh["body"] != NO_BODY
+        assert np.allclose(gh["t"][hit], oh["t"][hit], rtol=1e-5, atol=1e-7)
+        assert np.allclose(gh["normal"][hit], oh["normal"][hit], rtol=0, atol=1e-5)
+        n_hit += int(hit.sum())
+    return n_hit
+
+
+@pytest.mark.parametrize("n,seed,extent,grid", [(300, 1, 3.0, (0, 0)), (2000, 2, 10.0, (0, 0)), (400, 3, 4.0, (3, 2))])
+def test_queries_match_oracle_on_soups(n, seed, extent, grid):
+    s = scenes.random_soup(n, seed=seed, extent=extent)
+    g, o = make_pair(s, grid_log2=grid)
+    pts, boxes, rays, max_t = query_inputs(seed, extent, n=600, near=s.pos)
+    assert check_queries(g, o, pts, boxes, rays, max_t) > 100
+
+
+def test_queries_follow_the_poses_after_ticks():
+    """The index is rebuilt at the current poses: same answers as the oracle after both have ticked
+    (colour order on both sides), and a query inside an open tick is refused."""
+    from oracle.oracle import ORDER_COLORED
+    from starframe_amd.world import SfxError
+
+    s = scenes.random_soup(500, seed=5, extent=4.0)
+    g, o = make_pair(s)
+    pts, boxes, rays, max_t = query_inputs(5, 4.0, n=300, near=s.pos)
+    check_queries(g, o, pts, boxes, rays, max_t, masks=(0xFFFFFFFF,))
+    g.step(DT)
+    o.step(DT, ORDER_COLORED)
+    gp, gr = g.poses()
+    op, orr = o.poses()
+    if np.array_equal(gp, op) and np.array_equal(gr, orr):   # 0 ulp is the observed state; then the answers are equal too
+        check_queries(g, o, pts, boxes, rays, max_t, masks=(0xFFFFFFFF,))
+    else:                                                    # else put the oracle on the GPU's poses
+        v, av = g.velocities()
+        o.set_state(gp, gr, v, av, s.inv_mass, s.inv_inertia)
+        check_queries(g, o, pts, boxes, rays, max_t, masks=(0xFFFFFFFF,))
+    g.tick_begin(DT)
+    with pytest.raises(SfxError):
+        g.query_points(pts)
+    for _ in range(s.substeps):
+        g.tick_substep()
+    g.query_points(pts)
+
+
+def test_queries_on_a_pile_with_large_static_colliders():
+    s = scenes.circles_container(n=3000, width=60, floor_hw=9.0, wall_hh=8.0)
+    g, o = make_pair(s)
+    ext = 9.0
+    pts, boxes, rays, max_t = query_inputs(11, ext, n=500, near=s.pos)
+    rays[:250, 1] = np.abs(rays[:250, 1]) + 12.0   # from above the lattice, downwards
+    rays[:250, 2:] = (0.05, -1.0)
+    assert check_queries(g, o, pts, boxes, rays, max_t) > 200
+    st = g.stats()
+    assert st.n_bodies == s.n
+
+
+def test_box_query_capacity_is_reported():
+    from starframe_amd._abi import SFX_ERR_CAPACITY, fptr, vptr
+    import ctypes as C
+
+    s = scenes.random_soup(300, seed=1, extent=3.0)
+    g, o = make_pair(s)
+    box = np.array([[-100, -100, 100, 100]], np.float32)
+    full = o.query_aabbs(box)
+    hits = np.empty(8, np.uint64)
+    n = C.c_size_t()
+    rc = g.lib.sfx_query_aabbs(g.handle, 1, fptr(box), 0xFFFFFFFF, vptr(hits), 8, C.byref(n))
+    assert rc == SFX_ERR_CAPACITY and n.value == len(full)
+    assert np.array_equal(g.query_aabbs(box), full)
