@@ -42,12 +42,12 @@ def dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def settle(scene, device, frames=600, damping=3.3):
+def settle(scene, device, frames=600, damping=3.3, angular=1.0):
     """Let the lattice fall into a pile on the GPU (damped, so nothing tunnels), return the
     scene with the settled poses and zero velocities.  Not timed."""
     from starframe_amd.world import World
 
-    w = World.from_scene(scene, linear_damping=damping, angular_damping=1.0, device=device)
+    w = World.from_scene(scene, linear_damping=damping, angular_damping=angular, device=device)
     for _ in range(frames):
         w.step(DT)
     pos, rot = w.poses()

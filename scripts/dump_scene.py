@@ -19,9 +19,18 @@ def dump(s, path):
 
 
 if __name__ == "__main__":
+    # python scripts/dump_scene.py KIND N OUT.bin [SETTLE_TICKS]   (settling runs on the GPU, damped, like bench.py)
     kind, n, path = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    settle = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    relax = int(sys.argv[5]) if len(sys.argv) > 5 else 0   # further undamped ticks (bench.py's warm-up + timed region)
     s = {"pile": lambda: scenes.mixed_pile(n=n, width=max(50, n // 100)),
          "circles": lambda: scenes.circles_container(n=n),
+         "slab": lambda: scenes.granular_slab(n=n, width=max(50, n // 100)),
          "chains": lambda: scenes.chains(n_chains=n // 100, links=100)}[kind]()
+    if settle:
+        import bench
+        s = bench.settle(s, 0, frames=settle)
+        if relax:
+            s = bench.settle(s, 0, frames=relax, damping=0.0, angular=0.0)
     dump(s, path)
-    print(path, s.n, "bodies")
+    print(path, s.n, "bodies", "settled" if settle else "")

@@ -73,7 +73,9 @@ struct sfx_world {
     DevBuf<BatchDesc> batches;
     DevBuf<uint32_t> torder, done;
     uint32_t epoch = 0;            // one per fused multi-phase launch; never reset, so T.done needs no clearing
-    uint32_t resident_pos = 0, resident_vel = 0;  // workgroups of the solve kernels the device holds at once
+    // workgroups of the solve kernels the device holds at once, per workgroup size variant (512, 256 threads)
+    uint32_t resident_pos_v[2] = {0, 0}, resident_vel_v[2] = {0, 0};
+    int tile_variant_fixed = -1;   // SFX_TILE_NT=512|256 pins the variant (tuning); -1: chosen per tick
     bool fuse_phases = true;
     DevBuf<int2> cellxy, sorted_cell;
     DevBuf<uint4> rawp, tpair;
@@ -488,15 +490,21 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
     {   // how many workgroups of the solve kernels are resident at once: the fused multi-phase launches
         // never use more, so that no waiting workgroup keeps a not yet started one off the device
         hipDeviceProp_t prop;
-        int bp = 0, bv = 0;
-        if (hipGetDeviceProperties(&prop, w->device) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&bp, k_tile_pos<kTileThreads>, kTileThreads, 0) == hipSuccess &&
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&bv, k_tile_vel<kTileThreads>, kTileThreads, 0) == hipSuccess) {
-            w->resident_pos = (uint32_t)std::max(bp, 0) * (uint32_t)prop.multiProcessorCount * 7u / 8u;
-            w->resident_vel = (uint32_t)std::max(bv, 0) * (uint32_t)prop.multiProcessorCount * 7u / 8u;
+        bool ok = hipGetDeviceProperties(&prop, w->device) == hipSuccess;
+        auto occ = [&](auto kernel, int nt, uint32_t& out) {
+            int b = 0;
+            if (ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kernel, nt, 0) == hipSuccess)
+                out = (uint32_t)std::max(b, 0) * (uint32_t)prop.multiProcessorCount * 7u / 8u;
+            else ok = false;
+        };
+        occ(k_tile_pos<512>, 512, w->resident_pos_v[0]); occ(k_tile_vel<512>, 512, w->resident_vel_v[0]);
+        occ(k_tile_pos<256>, 256, w->resident_pos_v[1]); occ(k_tile_vel<256>, 256, w->resident_vel_v[1]);
+        if (const char* nt = getenv("SFX_TILE_NT")) {
+            const int v = atoi(nt);
+            w->tile_variant_fixed = v == 512 ? 0 : v == 256 ? 1 : -1;
         }
         const char* nf = getenv("SFX_NO_FUSE");   // tuning knob: one launch per phase
-        w->fuse_phases = !(nf && nf[0] == '1') && w->resident_pos >= 32 && w->resident_vel >= 32;
+        w->fuse_phases = !(nf && nf[0] == '1') && ok && w->resident_pos_v[0] >= 32 && w->resident_vel_v[0] >= 32;
     }
     if (const char* gr = getenv("SFX_GROUP")) {  // tuning knob: tiles per colouring group
         w->group = std::min(std::max(1, atoi(gr)), kMaxGroup);
@@ -837,29 +845,45 @@ int sfx_tick_substep(sfx_world* w) {
     const uint32_t nph = (w->tly == w->gyl) ? 2u : 4u;
     uint32_t total_grid = 0;
     for (uint32_t ph = 0; ph < nph; ++ph) total_grid += w->tile_grid[ph];
+    // Workgroup size of the tile solves.  A batch is a dependent chain (narrowphase, then one short step
+    // per colour) that keeps few lanes busy, so a CU only fills up when it holds several batches at once:
+    // 512 threads (one workgroup per CU) finish a batch soonest and win while all batches of a sweep fit
+    // on the device together (the 100 k pile); 256 threads (three per CU) win as soon as they do not.
+    int tv = w->tile_variant_fixed;
+    if (tv < 0) {
+        uint32_t nbatch = 0;
+        if (w->ctr_valid) for (uint32_t ph = 0; ph < nph; ++ph) nbatch += w->stale.n_batches[ph];
+        tv = (nbatch > 2u * w->resident_pos_v[0]) ? 1 : 0;
+    }
+    const uint32_t nt = tv == 0 ? 512u : 256u;
+    const uint32_t res_pos = w->resident_pos_v[tv], res_vel = w->resident_vel_v[tv];
+    auto launch_pos = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
+        if (tv == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
+        else hipLaunchKernelGGL(k_tile_pos<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
+    };
+    auto launch_vel = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
+        if (tv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
+        else hipLaunchKernelGGL(k_tile_vel<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
+    };
     if (w->fuse_phases) {
         // all phases in one launch, batches wait for the neighbouring batches of earlier phases
         Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_kept : 0);
-        hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(std::min(total_grid, w->resident_pos)), dim3(kTileThreads), 0,
-                           w->stream, 0u, nph, ++w->epoch, 1, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
+        launch_pos(std::min(total_grid, res_pos), 0u, nph, ++w->epoch, 1);
     } else {
         for (uint32_t ph = 0; ph < nph; ++ph) {
             Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_kept / nph : 0);
-            hipLaunchKernelGGL(k_tile_pos<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph, 1u, 0u,
-                               ph + 1 == nph ? 1 : 0, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
+            launch_pos(w->tile_grid[ph], ph, 1u, 0u, ph + 1 == nph ? 1 : 0);
         }
     }
     { Prof p(w, SFX_K_DERIVE_VEL, n);
       hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
     if (w->fuse_phases) {
         Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_kept : 0);
-        hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(std::min(total_grid, w->resident_vel)), dim3(kTileThreads), 0,
-                           w->stream, 0u, nph, ++w->epoch, 1, g, T, w->ctr, B, C, sp);
+        launch_vel(std::min(total_grid, res_vel), 0u, nph, ++w->epoch, 1);
     } else {
         for (uint32_t ph = 0; ph < nph; ++ph) {
             Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_kept / nph : 0);
-            hipLaunchKernelGGL(k_tile_vel<kTileThreads>, dim3(w->tile_grid[ph]), dim3(kTileThreads), 0, w->stream, ph, 1u, 0u,
-                               ph + 1 == nph ? 1 : 0, g, T, w->ctr, B, C, sp);
+            launch_vel(w->tile_grid[ph], ph, 1u, 0u, ph + 1 == nph ? 1 : 0);
         }
     }
     HIPCHK(w, hipGetLastError());
@@ -1316,13 +1340,14 @@ int sfx_kernel_times(sfx_world* w, sfx_kernel_time* out, int reset) {
 }
 
 #ifdef SFX_TILE_TIMING
-// development hook: stage timing of k_tile_pos in 10 ns units: [load, narrowphase, colour loop, whole tile, tiles, colours]
+// development hook: stage timing in 10 ns units, 16 slots.  k_tile_pos: [load, narrowphase, colour loop, whole batch,
+// batches, colours, wait, write-back]; k_tile_vel: [8 wait, 9 load, 10 colour loop, 11 write-back, 12 whole batch, 13 batches]
 int sfx_debug_tile_timing(sfx_world* w, unsigned long long* out, int reset) {
     if (!w) return SFX_ERR_INVALID;
-    if (!w->dbg.p) { if (w->dbg.alloc(8)) return SFX_ERR_NOMEM; (void)hipMemset(w->dbg.p, 0, 64); }
+    if (!w->dbg.p) { if (w->dbg.alloc(16)) return SFX_ERR_NOMEM; (void)hipMemset(w->dbg.p, 0, 128); }
     (void)hipStreamSynchronize(w->stream);
-    if (out) (void)hipMemcpy(out, w->dbg.p, 64, hipMemcpyDeviceToHost);
-    if (reset) (void)hipMemset(w->dbg.p, 0, 64);
+    if (out) (void)hipMemcpy(out, w->dbg.p, 128, hipMemcpyDeviceToHost);
+    if (reset) (void)hipMemset(w->dbg.p, 0, 128);
     return SFX_OK;
 }
 #endif

@@ -25,6 +25,9 @@ constexpr int kClaim = 4;                           // claim slots per body in t
 #ifndef SFX_TILE_THREADS
 #define SFX_TILE_THREADS 512
 #endif
+#ifndef SFX_TILE_MIN_WAVES
+#define SFX_TILE_MIN_WAVES 1
+#endif
 constexpr int kTileThreads = SFX_TILE_THREADS;      // workgroup of the tile solves = pairs on the register path
 constexpr uint32_t kBatchP = kMaxP;                 // pairs of a batch of tiles
 constexpr int kMaxGroup = 16;                       // tiles per batch at most
@@ -688,7 +691,12 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
     __shared__ unsigned long long s_claim[MB * kClaim];
     __shared__ uint8_t s_dyn[MB];
     __shared__ uint32_t s_a[MP], s_b[MP];
-    __shared__ uint16_t s_la[MP], s_lb[MP], s_left[MP], s_srt[MP];
+    __shared__ uint16_t s_la[MP], s_lb[MP];
+    // the leftover lists of the serial finish live in the claim table, which is dead once the rounds are
+    // over: 8 KB less LDS, so that two of these workgroups fit on a CU
+    static_assert(2 * MP * sizeof(uint16_t) <= MB * kClaim * sizeof(unsigned long long), "leftover lists alias s_claim");
+    uint16_t* const s_left = reinterpret_cast<uint16_t*>(s_claim);
+    uint16_t* const s_srt = s_left + MP;
     __shared__ uint8_t s_col[MP], s_prop[MP], s_tj[MP];
     __shared__ uint32_t s_hist[SFX_MAX_COLORS], s_base[SFX_MAX_COLORS];
     __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat, s_npruned, s_ptail;
@@ -1391,7 +1399,7 @@ __device__ __forceinline__ void publish_batch(const TileArrays& T, const GridPar
 // next colour's pair while it solves the current one.  Finally the blocks' dynamic bodies are
 // written back.  Batches of one phase have disjoint blocks.
 template <int NT>
-__global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
+__global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   float max_corr, float sm) {
     __shared__ float4 s_pose[kMaxB];
@@ -1409,6 +1417,8 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph0, uint32_t nph, uin
         const BatchDesc d = T.batches[ph * g.pstride + it];
         const uint32_t* tiles = T.active + ph * g.pstride + d.first;
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
+        SFX_TT(ttw);
+        SFX_TT_ADD(6, tt0, ttw);
         batch_ranges(tiles, d.count, g, T.cell_start, S);
         const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
         for (uint32_t l = tid; l < nb; l += NT) {
@@ -1483,13 +1493,13 @@ __global__ __launch_bounds__(NT) void k_tile_pos(uint32_t ph0, uint32_t nph, uin
             __syncthreads();
         }
         SFX_TT(tt4);
-        SFX_TT_ADD(0, tt0, tt1); SFX_TT_ADD(3, tt0, tt4); SFX_TT_ADD(4, 0ull, 1ull);
+        SFX_TT_ADD(0, ttw, tt1); SFX_TT_ADD(3, tt0, tt4); SFX_TT_ADD(4, 0ull, 1ull); SFX_TT_ADD(7, tt3, tt4);
     }
     if (with_fallback && last_workgroup(ctr)) fallback_pos(T, ctr, B, C, max_corr, sm);
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
+__global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   StepParams sp) {
     __shared__ float4 s_pose[kMaxB];
@@ -1507,7 +1517,9 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph0, uint32_t nph, uin
         const uint32_t ph = pi.ph, it = pi.it;
         const BatchDesc d = T.batches[ph * g.pstride + it];
         const uint32_t* tiles = T.active + ph * g.pstride + d.first;
+        SFX_TT(tv0);
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
+        SFX_TT(tvw);
         batch_ranges(tiles, d.count, g, T.cell_start, S);
         const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
         if (tid == 0) s_shift = 0u;
@@ -1522,6 +1534,7 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph0, uint32_t nph, uin
         __syncthreads();
         colour_runs<NT>(T.tpair, start, np, s_cs, s_ce);
         __syncthreads();
+        SFX_TT(tv1);
         auto solve = [&](const PairSlot& p) {
             const PairEnds& e = p.e;
             const bool ea = e.la == kExt, eb = e.lb == kExt;
@@ -1554,6 +1567,7 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph0, uint32_t nph, uin
             lds_barrier();
         }
         __syncthreads();
+        SFX_TT(tv2);
         const bool shifted = s_shift != 0u;
         if (nph > 1u) {  // fused phases: later batches of this launch read these records
             for (uint32_t l = tid; l < nb; l += NT) {
@@ -1575,6 +1589,9 @@ __global__ __launch_bounds__(NT) void k_tile_vel(uint32_t ph0, uint32_t nph, uin
             }
             __syncthreads();
         }
+        SFX_TT(tv3);
+        SFX_TT_ADD(8, tv0, tvw); SFX_TT_ADD(9, tvw, tv1); SFX_TT_ADD(10, tv1, tv2); SFX_TT_ADD(11, tv2, tv3);
+        SFX_TT_ADD(12, tv0, tv3); SFX_TT_ADD(13, 0ull, 1ull);
     }
     if (with_fallback && last_workgroup(ctr)) fallback_vel(T, ctr, B, C, sp);
 }
