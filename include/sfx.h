@@ -166,7 +166,7 @@ typedef struct sfx_ray_hit {
 typedef enum sfx_kernel_class {
     SFX_K_AABB_COUNT = 0, SFX_K_SCAN, SFX_K_SCATTER, SFX_K_PAIR_COUNT, SFX_K_PAIR_FILL,
     SFX_K_TILE_LIST, SFX_K_COLOR, SFX_K_INTEGRATE, SFX_K_SOLVE_JOINTS, SFX_K_SOLVE_POS,
-    SFX_K_DERIVE_VEL, SFX_K_SOLVE_VEL, SFX_K_STATS, SFX_K_HALO, SFX_K_QUERY, SFX_K_CLASSES
+    SFX_K_DERIVE_VEL, SFX_K_SOLVE_VEL, SFX_K_STATS, SFX_K_HALO, SFX_K_QUERY, SFX_K_NARROW, SFX_K_CLASSES
 } sfx_kernel_class;
 
 typedef struct sfx_kernel_time {
@@ -198,8 +198,8 @@ int sfx_upload_materials(sfx_world* w, uint32_t n, const sfx_material* materials
 int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constraint* c);
 
 /* ---- the tick (BASELINE.json:5 "the per-frame tick entry point") ---------- */
-/* One frame: broadphase + colouring once, then `substeps` x (integrate, position solve
- * with fused narrowphase, velocity derive, velocity pass).  Asynchronous on the world's
+/* One frame: broadphase + colouring once, then `substeps` x (integrate, narrowphase, position
+ * solve, velocity derive, velocity pass).  Asynchronous on the world's
  * stream; sfx_sync / any download waits for it. */
 int sfx_step(sfx_world* w, float frame_dt);
 int sfx_sync(sfx_world* w);

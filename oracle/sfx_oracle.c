@@ -1520,12 +1520,12 @@ int sfo_tick_substep(sfo_world* w) {
         if (order != SFO_ORDER_SEQUENTIAL && w->joint_color[jk] == NO_COLOR) continue;
         solve_joint(w, &w->joints[jk], inv_h2);
     }
-    for (uint32_t bt = 0, k0 = 0; bt < nbatch; ++bt) {
-        uint32_t k1 = w->batch_end[bt];
-        for (uint32_t k = k0; k < k1; ++k) prepare_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]]);
-        for (uint32_t k = k0; k < k1; ++k) solve_pos_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]], max_corr);
-        k0 = k1;
-    }
+    /* [DESIGN] DESIGN.md "Contract / sweep order": the manifolds of ALL solver pairs are computed
+     * first, at the poses the substep's integration (and the joints) left -- Mueller et al. 2020
+     * Alg. 2 "collect collision pairs" per substep -- then the solves run in the chosen order */
+    uint32_t n_ord = nbatch ? w->batch_end[nbatch - 1] : 0;
+    for (uint32_t k = 0; k < n_ord; ++k) prepare_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]]);
+    for (uint32_t k = 0; k < n_ord; ++k) solve_pos_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]], max_corr);
     derive_velocities(w, inv_h);
     for (uint32_t bt = 0, k0 = 0; bt < nbatch; ++bt) {
         uint32_t k1 = w->batch_end[bt];

@@ -76,6 +76,7 @@ struct sfx_world {
     // workgroups of the solve kernels the device holds at once, per workgroup size variant (512, 256 threads)
     uint32_t resident_pos_v[2] = {0, 0}, resident_vel_v[2] = {0, 0};
     int tile_variant_fixed = -1;   // SFX_TILE_NT=512|256 pins the variant (tuning); -1: chosen per tick
+    int tile_variant_pos = -1, tile_variant_vel = -1;  // SFX_TILE_NT_POS / SFX_TILE_NT_VEL: per kernel (tuning)
     bool fuse_phases = true;
     DevBuf<int2> cellxy, sorted_cell;
     DevBuf<uint4> rawp, tpair;
@@ -503,6 +504,8 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
             const int v = atoi(nt);
             w->tile_variant_fixed = v == 512 ? 0 : v == 256 ? 1 : -1;
         }
+        if (const char* nt = getenv("SFX_TILE_NT_POS")) { const int v = atoi(nt); w->tile_variant_pos = v == 512 ? 0 : v == 256 ? 1 : -1; }
+        if (const char* nt = getenv("SFX_TILE_NT_VEL")) { const int v = atoi(nt); w->tile_variant_vel = v == 512 ? 0 : v == 256 ? 1 : -1; }
         const char* nf = getenv("SFX_NO_FUSE");   // tuning knob: one launch per phase
         w->fuse_phases = !(nf && nf[0] == '1') && ok && w->resident_pos_v[0] >= 32 && w->resident_vel_v[0] >= 32;
     }
@@ -855,16 +858,24 @@ int sfx_tick_substep(sfx_world* w) {
         if (w->ctr_valid) for (uint32_t ph = 0; ph < nph; ++ph) nbatch += w->stale.n_batches[ph];
         tv = (nbatch > 2u * w->resident_pos_v[0]) ? 1 : 0;
     }
-    const uint32_t nt = tv == 0 ? 512u : 256u;
-    const uint32_t res_pos = w->resident_pos_v[tv], res_vel = w->resident_vel_v[tv];
+    const int tvp = w->tile_variant_pos >= 0 ? w->tile_variant_pos : tv, tvv = w->tile_variant_vel >= 0 ? w->tile_variant_vel : tv;
+    const uint32_t res_pos = w->resident_pos_v[tvp], res_vel = w->resident_vel_v[tvv];
     auto launch_pos = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
-        if (tv == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
-        else hipLaunchKernelGGL(k_tile_pos<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin);
+        const uint32_t nt = tvp == 0 ? 512u : 256u;
+        if (tvp == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
+        else hipLaunchKernelGGL(k_tile_pos<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
     };
     auto launch_vel = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
-        if (tv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
+        const uint32_t nt = tvv == 0 ? 512u : 256u;
+        if (tvv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
         else hipLaunchKernelGGL(k_tile_vel<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
     };
+    {   // manifolds of all solver pairs at the poses integration and joints left (one pair per lane)
+        const uint32_t est = w->ctr_valid ? w->stale.n_pairs : w->max_pairs;
+        Prof p(w, SFX_K_NARROW, w->ctr_valid ? w->stale.n_kept : 0);
+        hipLaunchKernelGGL(k_narrow, dim3(std::min(std::max(cdiv(est, kBlock), 1u), 16384u)), dim3(kBlock), 0, w->stream, T, w->ctr,
+                           B, C, w->cfg.speculative_margin);
+    }
     if (w->fuse_phases) {
         // all phases in one launch, batches wait for the neighbouring batches of earlier phases
         Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_kept : 0);
@@ -1355,7 +1366,7 @@ int sfx_debug_tile_timing(sfx_world* w, unsigned long long* out, int reset) {
 const char* sfx_kernel_class_name(int cls) {
     static const char* names[SFX_K_CLASSES] = {
         "aabb_count", "scan", "scatter", "pair_count", "pair_fill", "tile_list", "color", "integrate",
-        "solve_joints", "solve_pos", "derive_vel", "solve_vel", "stats", "halo", "query"};
+        "solve_joints", "solve_pos", "derive_vel", "solve_vel", "stats", "halo", "query", "narrow"};
     return (cls >= 0 && cls < SFX_K_CLASSES) ? names[cls] : "?";
 }
 

@@ -657,6 +657,7 @@ struct ReachParams {
 // Reach test of every tile-owned pair (DESIGN.md "Contract / solver pairs"), one pair per lane:
 // a pair that cannot touch in this tick gets bit 31 of its first slot word set.
 constexpr uint32_t kOutOfReach = 0x80000000u;
+constexpr uint32_t kNoPair = 0xFFFFFFFFu;  // torder entry of a pair that is not solved this tick
 
 __global__ __launch_bounds__(kBlock) void k_reach(const uint32_t* __restrict__ tile_start, uint32_t ntiles, uint32_t max_pairs,
                                                    uint4* __restrict__ rawp, const float4* __restrict__ shape, ReachParams RP) {
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
     uint16_t* const s_srt = s_left + MP;
     __shared__ uint8_t s_col[MP], s_prop[MP], s_tj[MP];
     __shared__ uint32_t s_hist[SFX_MAX_COLORS], s_base[SFX_MAX_COLORS];
-    __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat, s_npruned, s_ptail;
+    __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat, s_npruned, s_ptail, s_ptail_first;
     __shared__ uint32_t s_cls[4];
     __shared__ uint32_t s_bidx;
     __shared__ BatchRanges S;
@@ -857,6 +858,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 s_nleft = run;  // reused: cursor of the uncoloured tail
                 const uint32_t kept = np - s_npruned;
                 s_ptail = kept;  // cursor of the pruned pairs behind them
+                s_ptail_first = kept;
                 atomicAdd(&ctr->n_kept, kept);
                 const uint32_t bstart = atomicAdd(&ctr->tp_cursor, np);
                 s_bstart = bstart;
@@ -899,8 +901,9 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                                      : (cc == SFX_PRUNED_COLOR) ? atomicAdd(&s_ptail, 1u) : atomicAdd(&s_nleft, 1u);
                 const uint32_t la = s_la[e], lb = s_lb[e];
                 tpair[bstart + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), cc | (s_tile[f + s_tj[e]] << 8));
-                if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_prop[e]], 1u)] = dst;
+                if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_prop[e]], 1u)] = bstart + dst;
             }
+            for (uint32_t e = s_ptail_first + tid; e < np; e += kBlock) torder[bstart + e] = kNoPair;  // pruned pairs: no narrowphase
             __syncthreads();
         }
     }
@@ -1082,7 +1085,7 @@ struct TileArrays {
     const uint32_t* big;          // tiles that are batches of their own
     const BatchDesc* batches;     // per phase batch tables
     const uint4* tpair;           // colour-major per batch
-    const uint32_t* torder;       // per batch: pair positions grouped by shape-pair class (narrowphase order)
+    const uint32_t* torder;       // narrowphase order: positions in tpair, per batch grouped by shape-pair class (kNoPair: skip)
     const uint32_t* tile_batch;   // per tile: 1 + index of its batch on its phase's table (0: none this tick)
     uint32_t* done;               // per batch slot: epoch of the last fused launch that finished it
     const uint2* fsorted;         // fallback list, colour-major
@@ -1130,20 +1133,37 @@ __device__ __forceinline__ void load_record(const ContactArrays& C, uint32_t slo
     }
 }
 
+// Narrowphase of one substep (DESIGN.md "Contract / sweep order"): the manifolds of every solver pair
+// -- the tile pairs in the batches' class-grouped order, then the fallback list -- at the poses the
+// integration (and the joints) left, one pair per lane, records to the contact arrays.  Every pair
+// is independent, so this is the one stage of the contact sweep that fills the whole device.
+__global__ __launch_bounds__(kBlock) void k_narrow(TileArrays T, const Counters* __restrict__ ctr, BodyArrays B,
+                                                    ContactArrays C, float sm) {
+    const uint32_t ntp = min(ctr->tp_cursor, T.max_pairs);
+    const uint32_t nfb = min(ctr->n_fb, T.fb_cap) ? ctr->fb_start[SFX_MAX_COLORS] : 0u;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < ntp + nfb; j += gridDim.x * kBlock) {
+        uint32_t a, b, slot;
+        if (j < ntp) {
+            slot = T.torder[j];
+            if (slot == kNoPair) continue;
+            const uint4 pr = T.tpair[slot];
+            a = pr.x; b = pr.y;
+        } else {
+            const uint2 ab = T.fsorted[j - ntp];
+            a = ab.x; b = ab.y; slot = T.max_pairs + (j - ntp);
+        }
+        PairRec r;
+        prepare_pair(B.pose[a], B.shape[a], B.vel[a], B.pose[b], B.shape[b], B.vel[b], B.poly, B.mats, sm, r);
+        store_record(C, slot, r);
+    }
+}
+
 // The fallback list, solved by one whole workgroup directly on global memory after the last
-// phase: narrowphase of every fallback pair, then the XPBD solves colour by colour.
+// phase, colour by colour (its manifolds come from k_narrow like everybody else's).
 __device__ __forceinline__ void fallback_pos(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
-                                             const ContactArrays& C, float max_corr, float sm) {
+                                             const ContactArrays& C, float max_corr) {
     const uint32_t nfb = min(ctr->n_fb, T.fb_cap);
     if (nfb == 0) return;
-    const uint32_t total = ctr->fb_start[SFX_MAX_COLORS];
-    for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) {
-        const uint2 ab = T.fsorted[k];
-        PairRec r;
-        prepare_pair(B.pose[ab.x], B.shape[ab.x], B.vel[ab.x], B.pose[ab.y], B.shape[ab.y], B.vel[ab.y], B.poly, B.mats, sm, r);
-        store_record(C, T.max_pairs + k, r);
-    }
-    __syncthreads();
     const uint32_t nc = ctr->n_fb_colors;
     for (uint32_t c = 0; c < nc; ++c) {
         const uint32_t s = ctr->fb_start[c], e = ctr->fb_start[c + 1];
@@ -1401,7 +1421,7 @@ __device__ __forceinline__ void publish_batch(const TileArrays& T, const GridPar
 template <int NT>
 __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
-                                                  float max_corr, float sm) {
+                                                  float max_corr) {
     __shared__ float4 s_pose[kMaxB];
     __shared__ float2 s_mass[kMaxB];
     __shared__ uint32_t s_gid[kMaxB];
@@ -1431,17 +1451,6 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         __syncthreads();
         SFX_TT(tt1);
         colour_runs<NT>(T.tpair, start, np, s_cs, s_ce);
-        // narrowphase of every pair at the poses in LDS (a large non-dynamic collider outside the
-        // blocks is read from global memory)
-        for (uint32_t j = tid; j < np; j += NT) {
-            const uint32_t k = T.torder[start + j];
-            const PairEnds e = pair_ends(T.tpair[start + k]);
-            const float4 pa = e.la == kExt ? B.pose[e.a] : s_pose[e.la];
-            const float4 pb = e.lb == kExt ? B.pose[e.b] : s_pose[e.lb];
-            PairRec r;
-            prepare_pair(pa, B.shape[e.a], B.vel[e.a], pb, B.shape[e.b], B.vel[e.b], B.poly, B.mats, sm, r);
-            store_record(C, start + k, r);
-        }
         __syncthreads();
         SFX_TT(tt2);
         auto solve = [&](uint32_t slot, PairSlot& p) {
@@ -1495,7 +1504,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         SFX_TT(tt4);
         SFX_TT_ADD(0, ttw, tt1); SFX_TT_ADD(3, tt0, tt4); SFX_TT_ADD(4, 0ull, 1ull); SFX_TT_ADD(7, tt3, tt4);
     }
-    if (with_fallback && last_workgroup(ctr)) fallback_pos(T, ctr, B, C, max_corr, sm);
+    if (with_fallback && last_workgroup(ctr)) fallback_pos(T, ctr, B, C, max_corr);
 }
 
 template <int NT>
