@@ -80,7 +80,7 @@ struct sfx_world {
     bool fuse_phases = true;
     DevBuf<int2> cellxy, sorted_cell;
     DevBuf<uint4> rawp, tpair;
-    DevBuf<uint2> fpairs, fsorted;
+    DevBuf<uint2> fpairs, fsorted, hit_tmp;
     uint32_t large_cap = 0, ntiles = 4, fb_cap = 0, tlx = 0, tly = 0;
     // colouring of global edge lists (joints at upload, the fallback list every tick)
     DevBuf<unsigned long long> used, claim;
@@ -382,7 +382,7 @@ int broadphase(sfx_world* w, float dt) {
                          w->sorted_aabb.p, w->sorted_cell.p, w->ctr); }
     PairArrays P;
     P.slot_cnt = w->slot_cnt.p; P.tile_cnt = w->tile_cnt; P.tile_fill = w->tile_fill; P.tile_flag = w->tile_flag;
-    P.rawp = w->rawp.p; P.fpairs = w->fpairs.p; P.max_pairs = w->max_pairs; P.fb_cap = w->fb_cap;
+    P.rawp = w->rawp.p; P.fpairs = w->fpairs.p; P.hit_tmp = w->hit_tmp.p; P.max_pairs = w->max_pairs; P.fb_cap = w->fb_cap;
     // one 8-lane group per slot: 32 slots per block
     const uint32_t gp = std::min(std::max(cdiv(n + 1, kBlock / kGroup), 1u), 8192u);
     { Prof p(w, SFX_K_PAIR_COUNT, n);
@@ -549,7 +549,7 @@ void sfx_destroy(sfx_world* w) {
     w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release();
     w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
     w->active.release(); w->big_tiles.release(); w->batches.release(); w->torder.release(); w->done.release(); w->rawp.release(); w->tpair.release();
-    w->fpairs.release(); w->fsorted.release();
+    w->fpairs.release(); w->fsorted.release(); w->hit_tmp.release();
     w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->scan_sums.release();
     w->cellxy.release(); w->sorted_cell.release();
     w->used.release(); w->claim.release(); w->left_list.release();
@@ -600,7 +600,7 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
         ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
         ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
         ALLOC(w, w->bucket, c); ALLOC(w, w->tmp_id, c); ALLOC(w, w->sorted_id, c); ALLOC(w, w->large_tmp, c);
-        ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
+        ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->hit_tmp, kHitTmp * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
         ALLOC(w, w->used, c); ALLOC(w, w->claim, c * kClaim);
         w->large_cap = n;
     }

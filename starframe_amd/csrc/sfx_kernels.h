@@ -345,8 +345,11 @@ struct PairArrays {
     const uint32_t* tile_flag;  // != 0: tile hands its pairs to the fallback list
     uint4* rawp;             // tile-ordered pairs (id a, id b, slot a, slot b)
     uint2* fpairs;           // fallback list (id a, id b)
+    uint2* hit_tmp;          // [kHitTmp * (n + 1)] per slot: the count pass's hits (id, slot) of stream 0 from the front
+                             // and of stream 1 from the back, so that the fill pass copies instead of testing again
     uint32_t max_pairs, fb_cap;
 };
+constexpr uint32_t kHitTmp = 16;  // a slot with more tile pairs (or any fallback pair) is tested again by the fill pass
 
 // The eight slot groups of a wave usually belong to one or two tiles (slots are sorted
 // tile-major): the groups that name the same counter index add up, the first of them does one
@@ -421,6 +424,14 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
             to_fb[0] = f0; to_fb[1] = f1;
         }
         uint32_t cnt[3] = {0u, 0u, 0u};
+        // fill pass: a slot whose hits the count pass kept is copied, not tested again
+        bool copy = false;
+        uint32_t cc0 = 0, cc1 = 0;
+        if (FILL && live) {
+            cc0 = P.slot_cnt[3 * p]; cc1 = P.slot_cnt[3 * p + 1];
+            copy = P.slot_cnt[3 * p + 2] == 0u && cc0 + cc1 <= kHitTmp;
+        }
+        const bool test = live && !copy;
         // six candidate ranges per slot, walked in lockstep by the eight groups of the wave
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
@@ -428,7 +439,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
             int32_t ncx = 0, ncy = 0;
             bool check_cell = true;
             int stream = 0;
-            if (live && p < ns) {
+            if (test && p < ns) {
                 if (r == 0) {
                     ncx = c.x; ncy = c.y;
                     qs = p + 1; qe = cell_start[bucket_of(ncx, ncy, g) + 1];
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                 } else {
                     qs = ns; qe = nact; check_cell = false;
                 }
-            } else if (live && r == 5) {
+            } else if (test && r == 5) {
                 qs = p + 1; qe = nact; check_cell = false; stream = 2;  // large slot: later larges only
             }
             for (uint32_t q0 = qs; __any(q0 < qe); q0 += kGroup) {
@@ -464,6 +475,10 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                 for (int s3 = 0; s3 < 3; ++s3) {
                     const bool mine = hit && st == s3;
                     const uint64_t bal = (__ballot(mine) >> gshift) & ((1ull << kGroup) - 1ull);
+                    if (!FILL && mine && s3 < 2) {
+                        const uint32_t idx = cnt[s3] + (uint32_t)__popcll(bal & below);
+                        if (idx < kHitTmp) P.hit_tmp[(size_t)p * kHitTmp + (s3 == 0 ? idx : kHitTmp - 1u - idx)] = make_uint2(j, q);
+                    }
                     if (FILL && mine) {
                         const uint32_t dst = base[s3] + cnt[s3] + (uint32_t)__popcll(bal & below);
                         const bool swap = j < i;
@@ -474,6 +489,22 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                         }
                     }
                     cnt[s3] += (uint32_t)__popcll(bal);
+                }
+            }
+        }
+        if (FILL && copy) {
+#pragma unroll
+            for (int s3 = 0; s3 < 2; ++s3) {
+                const uint32_t c = s3 == 0 ? cc0 : cc1;
+                for (uint32_t h = (uint32_t)gl; h < c; h += kGroup) {
+                    const uint2 e = P.hit_tmp[(size_t)p * kHitTmp + (s3 == 0 ? h : kHitTmp - 1u - h)];
+                    const uint32_t j = e.x, q = e.y, dst = base[s3] + h;
+                    const bool swap = j < i;
+                    if (to_fb[s3]) {
+                        if (dst < P.fb_cap) P.fpairs[dst] = make_uint2(swap ? j : i, swap ? i : j);
+                    } else if (dst < P.max_pairs) {
+                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, swap ? p : q);
+                    }
                 }
             }
         }
