@@ -15,10 +15,10 @@ N > 1 : weak scaling, one process per GPU: a pile N times as wide (N x 100k bodi
         device buffers.  value = all bodies x substeps x K / max-over-ranks seconds.
 
 The JSON line also carries
-  roofline     : the dominant kernel (k_tile_pos: narrowphase + XPBD manifold block solves of one
-                 phase of solver tiles, bodies in LDS), algorithmic bytes per launch / mean launch
-                 time from HIP events recorded by libsfx on its own stream, against the 8 TB/s
-                 HBM peak;
+  roofline     : the kernel the tick spends most time in (one of the contact-sweep kernels k_narrow,
+                 k_tile_pos, k_tile_vel): algorithmic bytes per launch / mean launch time from HIP
+                 events recorded by libsfx on its own stream, against the 8 TB/s HBM peak; the other
+                 two under roofline.other_kernels;
   cpu_baseline : this repository's single-threaded CPU restatement (oracle/, kind "port")
                  timed on this host on a bounded number of frames of the same settled scene.
                  It is NOT starframe's Rust tick, which was unavailable.
@@ -55,23 +55,37 @@ def settle(scene, device, frames=600, damping=3.3, angular=1.0):
     return scene.with_state(pos, rot, name=scene.name + "_settled")
 
 
-def solve_pos_bytes(st):
-    """Algorithmic (compulsory) bytes of the four k_tile_pos launches of ONE substep.
-    DESIGN.md "Kernels": per candidate pair 16 B pair record + 2 x (16 B pose + 16 B shape) read
-    + 8 B count written; per touching pair additionally 2 x (8 B mass + 16 B velocity) read,
-    48 B record + 16 B lambdas + 2 x 16 B pose written; 16 B more for a second contact point."""
-    return st.n_pairs * 88.0 + st.n_manifolds * 144.0 + st.n_manifolds2 * 16.0
+def kernel_bytes(st):
+    """Algorithmic (compulsory) bytes of ONE launch of each contact-sweep kernel (one launch per substep),
+    from the tick's measured counts.  DESIGN.md "Kernels": P = solver pairs, M = touching pairs (manifolds),
+    M2 = of which with two points.
+      k_narrow   : P x (4 order + 16 pair + 2 x (16 pose + 16 shape) read, 8 count written)
+                   + M x (2 x 16 velocity read; 16 normal/friction + 16 anchors + 8 lambda + 8 pre-velocity written) + M2 x 16
+      k_tile_pos : P x (16 pair + 8 count read) + M x (32 record + 2 x (16 pose + 8 mass) read; 8 lambda + 2 x 16 pose written) + M2 x 16
+      k_tile_vel : P x (16 + 8 read) + M x (48 record + 2 x (16 pose + 16 velocity + 8 mass) read; 2 x 16 velocity written) + M2 x 16"""
+    P, M, M2 = float(st.n_solver_pairs), float(st.n_manifolds), float(st.n_manifolds2)
+    return {
+        "narrow": P * 92.0 + M * 80.0 + M2 * 16.0,
+        "solve_pos": P * 24.0 + M * 120.0 + M2 * 16.0,
+        "solve_vel": P * 24.0 + M * 160.0 + M2 * 16.0,
+    }
+
+
+KERNEL_NAMES = {
+    "narrow": "k_narrow (manifolds of all solver pairs, one pair per lane)",
+    "solve_pos": "k_tile_pos (XPBD manifold block solves, all tile phases in one launch, bodies in LDS)",
+    "solve_vel": "k_tile_vel (restitution + friction per manifold, all tile phases in one launch, bodies in LDS)",
+}
 
 
 def tick_bytes_per_body_substep(st, n_dyn, substeps):
     """SURVEY.md 8d accounting for the whole tick, from measured pair / contact counts."""
-    p, m, m2 = st.n_pairs / n_dyn, st.n_manifolds / n_dyn, st.n_manifolds2 / n_dyn
+    kb = kernel_bytes(st)
     integrate = 16 + 16 + 8 + 16 + 16 + 16          # pose, vel, mass read; prev, pose, vel written
     derive = 16 + 16 + 8 + 16
-    pos = p * 88 + m * 144 + m2 * 16
-    vel = p * (16 + 8) + m * (64 + 2 * (16 + 16 + 8) + 2 * 16) + m2 * 16
-    broad = (16 + 16 + 16 + 16 + 4 + 8 + 4 + 4 + 28 + 16 * 5 + p * (8 + 8 + 2 + 16)) / substeps
-    return integrate + derive + pos + vel + broad
+    p = st.n_pairs / n_dyn
+    broad = (16 + 16 + 16 + 16 + 4 + 8 + 4 + 4 + 28 + 16 * 5 + p * (8 + 8 + 2 + 16 + 16)) / substeps
+    return integrate + derive + sum(kb.values()) / n_dyn + broad
 
 
 def cpu_baseline(scene, budget_s=15.0):
@@ -101,12 +115,13 @@ def cpu_baseline(scene, budget_s=15.0):
     }
 
 
-def load_traffic():
-    """HBM bytes per k_solve_pos launch from the committed rocprofv3 --pmc passes, if any."""
-    p = os.path.join(ROOT, "profiles", "pmc_solve_pos.json")
+def load_traffic(cls):
+    """HBM bytes per launch of a contact-sweep kernel from the committed rocprofv3 --pmc passes
+    (profiles/pmc_solve.json, written by scripts/pmc_report.py), or None."""
+    p = os.path.join(ROOT, "profiles", "pmc_solve.json")
     try:
         with open(p) as f:
-            return json.load(f).get("hbm_bytes_per_launch")
+            return json.load(f)[cls]["hbm_bytes_per_launch"]
     except Exception:
         return None
 
@@ -200,11 +215,19 @@ def main():
     kt = w.kernel_times()
     w.set_profiling(False)
     st2 = w.stats()
-    sp = kt["solve_pos"]
-    launches_per_substep = sp["launches"] / (prof_frames * scene.substeps)
-    dur_s = 1e-3 * sp["total_ms"] / max(sp["launches"], 1)
-    bytes_per_launch = solve_pos_bytes(st2) / max(launches_per_substep, 1)
-    achieved = bytes_per_launch / dur_s / 1e9
+    kb = kernel_bytes(st2)
+    per_kernel = {}
+    for cls, nbytes in kb.items():
+        k = kt[cls]
+        if not k["launches"]:
+            continue
+        per_launch = k["launches"] / (prof_frames * scene.substeps)   # 1 when fused; tile phases when not
+        dur = 1e-3 * k["total_ms"] / k["launches"]
+        per_kernel[cls] = {"bytes_per_launch": nbytes / per_launch, "launch_us": dur * 1e6,
+                           "achieved": nbytes / per_launch / dur / 1e9, "ms_per_step": k["total_ms"] / prof_frames}
+    dom = max(per_kernel, key=lambda c: per_kernel[c]["ms_per_step"])   # the kernel the tick spends most time in
+    sp = per_kernel[dom]
+    achieved = sp["achieved"]
     kernel_ms = {k: round(v["total_ms"] / prof_frames, 4) for k, v in kt.items() if v["launches"]}
     value = n_dyn * scene.substeps * args.steps / elapsed
     n_rank = slab.plan.n_owned if slab is not None else n_dyn
@@ -238,21 +261,25 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "k_tile_pos (narrowphase + XPBD manifold block solves of one tile phase, bodies in LDS; "
-                      "4 launches per substep)",
+            "kernel": KERNEL_NAMES[dom],
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": load_traffic(),
-            "bytes_per_launch": bytes_per_launch,
-            "launch_us": dur_s * 1e6,
-            "launches_per_step": sp["launches"] / prof_frames,
+            "traffic": load_traffic(dom),
+            "bytes_per_launch": sp["bytes_per_launch"],
+            "launch_us": sp["launch_us"],
+            "launches_per_step": kt[dom]["launches"] / prof_frames,
+            "other_kernels": {KERNEL_NAMES[c].split(" ")[0]: {"achieved": round(v["achieved"], 1), "frac": round(v["achieved"] / HBM_PEAK_GBS, 4),
+                                                                "launch_us": round(v["launch_us"], 2), "bytes_per_launch": v["bytes_per_launch"],
+                                                                "traffic": load_traffic(c)}
+                              for c, v in per_kernel.items() if c != dom},
             "tick_bytes_per_body_substep": bpbs,
             "tick_frac": (value / world) * bpbs / (HBM_PEAK_GBS * 1e9),
             "kernel_ms_per_step": kernel_ms,
             "note": "launch time from hipEvents recorded by libsfx around every launch on its own stream, "
-                    f"over {prof_frames} further ticks after the timed region",
+                    f"over {prof_frames} further ticks after the timed region; traffic = 2 x FETCH_SIZE + WRITE_SIZE from "
+                    "rocprofv3 --pmc passes of the native driver on the same settled scene (profiles/)",
         },
     }
     if dist is not None:

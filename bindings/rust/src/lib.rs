@@ -68,6 +68,16 @@ pub const SFX_ABI_VERSION: u32 = 5;
 pub const SFX_OK: c_int = 0;
 pub const SFX_WORLD_BODY: u32 = 0xFFFF_FFFF;
 
+pub const SFX_NO_BODY: u32 = 0xFFFF_FFFF;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct sfx_ray_hit {
+    pub body: u32,
+    pub t: f32,
+    pub normal: [f32; 2],
+}
+
 extern "C" {
     pub fn sfx_default_config(cfg: *mut sfx_config);
     pub fn sfx_create(cfg: *const sfx_config, out: *mut *mut sfx_world) -> c_int;
@@ -95,6 +105,12 @@ extern "C" {
     pub fn sfx_download_poses(w: *mut sfx_world, pos: *mut f32, rot: *mut f32) -> c_int;
     pub fn sfx_download_velocities(w: *mut sfx_world, vel: *mut f32, angvel: *mut f32) -> c_int;
     pub fn sfx_last_error(w: *mut sfx_world) -> *const c_char;
+    // spatial queries at the current poses (include/sfx.h "spatial queries")
+    pub fn sfx_query_points(w: *mut sfx_world, n: u32, points: *const f32, mask: u32, body: *mut u32, count: *mut u32) -> c_int;
+    pub fn sfx_query_aabbs(w: *mut sfx_world, n: u32, boxes: *const f32, mask: u32, hits: *mut u64, cap: usize,
+                           n_hits: *mut usize) -> c_int;
+    pub fn sfx_query_rays(w: *mut sfx_world, n: u32, rays: *const f32, max_t: *const f32, mask: u32,
+                          hits: *mut sfx_ray_hit) -> c_int;
 }
 
 /// Owning handle; `Drop` calls `sfx_destroy`.  A starframe-side `Physics::tick(&mut self, dt)` marshals

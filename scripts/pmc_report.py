@@ -1,5 +1,5 @@
 """Per-kernel summary of the rocprofv3 --pmc passes written by scripts/gpu_pmc.sh:
-   python scripts/pmc_report.py gpurun_out/pmc_pile profiles/r01/pmc_pile100k.json [profiles/pmc_solve_pos.json]
+   python scripts/pmc_report.py gpurun_out/pmc_pile profiles/r01/pmc_pile100k.json [profiles/pmc_solve.json]
 Mean counter value per dispatch over the last ticks of the run (the settled pile).  Units and corrections
 as /opt/skills/guides/MI355X_MICROARCH.md prescribes: FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE
 reports half the bytes of 16-byte-per-lane reads (checked here on k_integrate, a streaming kernel of known
@@ -66,8 +66,15 @@ for k, v in agg.items():
 json.dump(rep, open(out, "w"), indent=1, sort_keys=True)
 print("wrote", out, len(rep), "kernels")
 if solve_out:
-    k = [x for x in rep if "k_tile_pos" in x][0]
-    json.dump({"kernel": k, "hbm_bytes_per_launch": rep[k]["hbm_bytes"], "source": out,
-               "note": "2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes), mean per k_tile_pos dispatch, rocprofv3 --pmc in separate passes"},
-              open(solve_out, "w"), indent=1)
+    res = {}
+    for cls, key in (("narrow", "k_narrow"), ("solve_pos", "k_tile_pos"), ("solve_vel", "k_tile_vel")):
+        ks = [x for x in rep if key in x and "hbm_bytes" in rep[x]]
+        if ks:
+            k = max(ks, key=lambda x: rep[x]["dispatches_per_pass"])
+            res[cls] = {"kernel": k, "hbm_bytes_per_launch": rep[k]["hbm_bytes"], "hbm_read_bytes": rep[k]["hbm_read_bytes"],
+                        "hbm_write_bytes": rep[k]["hbm_write_bytes"]}
+    res["source"] = out
+    res["note"] = ("2 * FETCH_SIZE + WRITE_SIZE (KiB -> bytes), mean per dispatch, rocprofv3 --pmc in separate passes; "
+                   "the factor 2 is the guide's gfx950 correction, checked on k_integrate in the same run")
+    json.dump(res, open(solve_out, "w"), indent=1)
     print("wrote", solve_out)
