@@ -53,6 +53,14 @@ for _ in range(k):
     w.step(bench.DT)
 kt = w.kernel_times()
 print("per tick, us:", {a: round(1e3 * v["total_ms"] / k, 1) for a, v in kt.items() if v["launches"]})
+st = w.stats()
+kb = bench.kernel_bytes(st)
+for cls, nbytes in kb.items():
+    v = kt[cls]
+    if v["launches"]:
+        dur = 1e-3 * v["total_ms"] / v["launches"]
+        per = nbytes * k * s.substeps / v["launches"]
+        print(f"  {cls}: {1e6 * dur:.1f} us/launch, {per / 1e6:.1f} MB algorithmic, {per / dur / 1e9:.0f} GB/s = {100 * per / dur / 8e12:.1f} % of 8 TB/s")
 print("launches per tick:", {a: v["launches"] // k for a, v in kt.items() if v["launches"]})
 pos, rot = w.poses()
 print("finite", bool(np.isfinite(pos).all() and np.isfinite(rot).all()), "y range", float(pos[:, 1].min()), float(pos[:, 1].max()))

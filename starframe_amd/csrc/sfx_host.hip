@@ -318,10 +318,10 @@ ContactArrays contact_arrays(sfx_world* w) {
     return C;
 }
 
-// exclusive scan of data[0..count) in place (count <= 4096 * 4096); copy receives the result too
+// exclusive scan of data[0..count) in place (count <= 8192 * 4096); copy receives the result too
 int scan_u32(sfx_world* w, uint32_t* data, uint32_t count, uint32_t* copy) {
     const uint32_t nb = cdiv(count, kScanTile);
-    if (nb > 4096) return fail(w, SFX_ERR_UNSUPPORTED, "scan of %u items exceeds 16M", count);
+    if (nb > 1024u * kSumItems) return fail(w, SFX_ERR_UNSUPPORTED, "scan of %u items exceeds 32M", count);
     if (nb <= 1) {
         Prof p(w, SFX_K_SCAN, count);
         hipLaunchKernelGGL(k_scan_local, dim3(1), dim3(kBlock), 0, w->stream, data, count, w->scan_sums.p, copy, 1);
@@ -529,7 +529,7 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
         return SFX_ERR_DEVICE;
     }
     w->stream = w->own_stream_handle;
-    if (w->jctr.alloc(1) || w->scan_sums.alloc(4096) || w->left_list.alloc(kLeftCap) ||
+    if (w->jctr.alloc(1) || w->scan_sums.alloc(1024 * kSumItems) || w->left_list.alloc(kLeftCap) ||
         w->j_count_dev.alloc(1)) {
         fail(nullptr, SFX_ERR_NOMEM, "hipMalloc failed");
         sfx_destroy(w);

@@ -240,20 +240,21 @@ __global__ __launch_bounds__(kBlock) void k_scan_local(uint32_t* __restrict__ da
     }
 }
 
-// exclusive scan of up to 4096 tile totals by one block of 1024 threads
+// exclusive scan of up to 8192 tile totals by one block of 1024 threads
+constexpr int kSumItems = 8;
 __global__ __launch_bounds__(1024) void k_scan_sums(uint32_t* __restrict__ sums, uint32_t nsums) {
     __shared__ uint32_t lds[1024 / 64 + 1];
-    uint32_t v[4];
-    const uint32_t base = threadIdx.x * 4;
+    uint32_t v[kSumItems];
+    const uint32_t base = threadIdx.x * kSumItems;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = (base + k < nsums) ? sums[base + k] : 0u;
+    for (int k = 0; k < kSumItems; ++k) v[k] = (base + k < nsums) ? sums[base + k] : 0u;
     uint32_t sum = 0;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { uint32_t t = v[k]; v[k] = sum; sum += t; }
+    for (int k = 0; k < kSumItems; ++k) { uint32_t t = v[k]; v[k] = sum; sum += t; }
     uint32_t total;
     const uint32_t pre = block_exclusive_scan<1024>(sum, lds, &total);
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < kSumItems; ++k)
         if (base + k < nsums) sums[base + k] = v[k] + pre;
 }
 

@@ -230,3 +230,14 @@ def test_pair_capacity_overflow_reported():
         w.sync()
         w.step(DT)
         w.sync()
+
+
+def test_largest_grid_scans():
+    """4096 x 4096 buckets (what a 4 M-body scene resolves to): the cell scan takes 2^24 + 1 items."""
+    s = scenes.random_soup(400, seed=9, extent=5.0)
+    g, o = make_pair(s, grid_log2=(12, 12))
+    g.broadphase(DT)
+    o.broadphase(DT)
+    assert np.array_equal(g.pairs(), o.pairs())
+    g.step(DT)
+    assert g.stats().overflow == 0

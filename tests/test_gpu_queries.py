@@ -99,3 +99,24 @@ def test_box_query_capacity_is_reported():
     rc = g.lib.sfx_query_aabbs(g.handle, 1, fptr(box), 0xFFFFFFFF, vptr(hits), 8, C.byref(n))
     assert rc == SFX_ERR_CAPACITY and n.value == len(full)
     assert np.array_equal(g.query_aabbs(box), full)
+
+
+def test_empty_and_degenerate_queries():
+    from starframe_amd.scenes import SceneBuilder
+
+    s = scenes.random_soup(50, seed=3, extent=2.0)
+    g, o = make_pair(s)
+    b, c = g.query_points(np.zeros((0, 2), np.float32))
+    assert len(b) == 0 and len(c) == 0
+    assert len(g.query_aabbs(np.zeros((0, 4), np.float32))) == 0
+    assert len(g.query_rays(np.zeros((0, 4), np.float32), np.zeros(0, np.float32))) == 0
+    # a world whose colliders are all large (one static box) and bodies without colliders
+    bld = SceneBuilder("big", substeps=1)
+    bld.static_rect((0.0, 0.0), 50.0, 1.0)
+    bld.particle((0.0, 5.0))
+    g2, o2 = make_pair(bld.build())
+    rays = np.array([[0, 10, 0, -1], [0, 10, 0, 1], [100, 0.5, -1, 0], [0, 0.5, 1, 0]], np.float32)
+    gh, oh = g2.query_rays(rays, np.inf), o2.query_rays(rays, np.inf)
+    assert np.array_equal(gh["body"], oh["body"]) and np.array_equal(gh["t"], oh["t"])
+    assert gh["body"].tolist() == [0, NO_BODY, 0, 0] and gh["t"][0] == 9.0 and gh["t"][3] == 0.0
+    assert np.array_equal(g2.query_points([[0, 0], [0, 5]])[0], o2.query_points([[0, 0], [0, 5]])[0])
