@@ -317,5 +317,26 @@ class DistSlab:
             pos[i], rot[i], vel[i], ang[i] = a, b, c, d
         return pos, rot, vel, ang
 
+    def global_stats(self):
+        """Whole-scene reporting figures on every rank (SURVEY.md 8e "all-reduce (stats)"): kinetic energy of
+        the owned bodies and pair / manifold counts summed, deepest penetration maximised -- two all-reduces
+        of a few bytes.  Pairs between an owned and a ghost body are counted on both sides."""
+        t = self.torch
+        ids, _, _, lv, la = self.owned_state()
+        im, ii = np.asarray(self.scene.inv_mass)[ids], np.asarray(self.scene.inv_inertia)[ids]
+        m = np.where(im > 0, 1.0 / np.where(im > 0, im, 1.0), 0.0)
+        inertia = np.where(ii > 0, 1.0 / np.where(ii > 0, ii, 1.0), 0.0)
+        ke = float((0.5 * m * (lv.astype(np.float64) ** 2).sum(1)).sum() + (0.5 * inertia * la.astype(np.float64) ** 2).sum())
+        st = self.world.stats()
+        dev = t.device("cuda", t.cuda.current_device()) if self.on_device else t.device("cpu")
+        sums = t.tensor([ke, float(st.n_pairs), float(st.n_manifolds), float(st.n_contacts), float(len(ids))],
+                        dtype=t.float64, device=dev)
+        mx = t.tensor([float(st.max_depth), float(st.n_colors)], dtype=t.float64, device=dev)
+        self.dist.all_reduce(sums, op=self.dist.ReduceOp.SUM)
+        self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX)
+        sums, mx = sums.cpu().numpy(), mx.cpu().numpy()
+        return {"kinetic_energy": float(sums[0]), "pairs": int(sums[1]), "manifolds": int(sums[2]), "contacts": int(sums[3]),
+                "bodies": int(sums[4]), "max_depth": float(mx[0]), "colors": int(mx[1])}
+
     def close(self):
         self.world.close()

@@ -24,8 +24,10 @@ def main():
     for _ in range(ticks):
         slab.step(1.0 / 60.0)
     pos, rot, vel, ang = slab.gather()
+    gs = slab.global_stats()
     if dist.get_rank() == 0:
-        np.savez(out, pos=pos, rot=rot, vel=vel, ang=ang)
+        np.savez(out, pos=pos, rot=rot, vel=vel, ang=ang, ke=gs["kinetic_energy"], bodies=gs["bodies"],
+                 manifolds=gs["manifolds"], max_depth=gs["max_depth"])
     dist.barrier()
     dist.destroy_process_group()
 

@@ -125,6 +125,15 @@ def test_two_ranks_over_gloo_equal_logical_slabs(tmp_path):
     assert np.array_equal(z["pos"].view(np.uint32), pos.view(np.uint32))
     assert np.array_equal(z["vel"].view(np.uint32), vel.view(np.uint32))
     assert (L.worlds[0].stats().n_manifolds + L.worlds[1].stats().n_manifolds) > 100
+    # the all-reduced reporting figures: every dynamic body counted once, energy of the gathered state
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    assert int(z["bodies"]) == int(dyn.sum())
+    m = np.where(s.inv_mass > 0, 1.0 / np.where(s.inv_mass > 0, s.inv_mass, 1.0), 0.0)
+    inertia = np.where(s.inv_inertia > 0, 1.0 / np.where(s.inv_inertia > 0, s.inv_inertia, 1.0), 0.0)
+    ke = (0.5 * m * (vel.astype(np.float64) ** 2).sum(1)).sum() + (0.5 * inertia * ang.astype(np.float64) ** 2).sum()
+    assert float(z["ke"]) == pytest.approx(ke, rel=1e-9)
+    assert int(z["manifolds"]) == L.worlds[0].stats().n_manifolds + L.worlds[1].stats().n_manifolds
+    assert float(z["max_depth"]) == pytest.approx(max(w.stats().max_depth for w in L.worlds), rel=1e-6)
 
 
 @pytest.mark.gpu
