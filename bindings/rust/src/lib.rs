@@ -57,6 +57,8 @@ pub struct sfx_distance_constraint {
     pub anchor_b: [f32; 2],
     pub rest_length: f32,
     pub compliance: f32,
+    pub limit: u32,    // SFX_LIMIT_*: 0 both ways, 1 rope (only pulls), 2 strut (only pushes)
+    pub reserved: u32,
 }
 
 #[repr(C)]

@@ -110,7 +110,11 @@ typedef struct sfx_material {
     float dynamic_friction;
 } sfx_material;
 
-/* distance constraint between two anchors (BASELINE.json:10 "distance-constrained links") */
+/* distance constraint between two anchors (BASELINE.json:10 "distance-constrained links").
+ * limit makes it one-sided (SURVEY.md section 8f rank 2 "limits"; a rope link only pulls) */
+#define SFX_LIMIT_NONE 0u   /* holds the rest length both ways                           */
+#define SFX_LIMIT_ROPE 1u   /* acts only while the anchors are further apart than rest   */
+#define SFX_LIMIT_STRUT 2u  /* acts only while they are closer than rest                 */
 typedef struct sfx_distance_constraint {
     uint32_t body_a;     /* body index or SFX_WORLD_BODY                         */
     uint32_t body_b;
@@ -118,6 +122,8 @@ typedef struct sfx_distance_constraint {
     float anchor_b[2];
     float rest_length;
     float compliance;    /* XPBD alpha (m/N); 0 = rigid                           */
+    uint32_t limit;      /* SFX_LIMIT_*                                           */
+    uint32_t reserved;   /* 0                                                     */
 } sfx_distance_constraint;
 
 /* one narrowphase manifold, as returned by sfx_debug_contacts */

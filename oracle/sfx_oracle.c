@@ -1468,6 +1468,9 @@ static void solve_joint(sfo_world* w, const sfx_distance_constraint* j, float in
     if (!(len > EPS_LEN)) return;
     float nx = dx / len, ny = dy / len;
     float C = len - j->rest_length;
+    /* one-sided links (sfx.h SFX_LIMIT_*): a rope only pulls, a strut only pushes */
+    if (j->limit == SFX_LIMIT_ROPE && !(C > 0.0f)) return;
+    if (j->limit == SFX_LIMIT_STRUT && !(C < 0.0f)) return;
     float wsum = j->compliance * inv_h2;
     if (a != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(w, a, rax, ray, nx, ny);
     if (b != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(w, b, rbx, rby, nx, ny);

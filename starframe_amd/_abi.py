@@ -27,6 +27,7 @@ TILE_MAX_PAIRS = 2048
 TILE_MAX_BODIES = 1024
 FALLBACK_TILE = 0xFFFFFFFF
 
+LIMIT_NONE, LIMIT_ROPE, LIMIT_STRUT = 0, 1, 2
 CFG_USE_GRAPH = 1
 CFG_NO_FRICTION = 2
 
@@ -107,6 +108,8 @@ constraint_dtype = np.dtype(
         ("anchor_b", "<f4", (2,)),
         ("rest_length", "<f4"),
         ("compliance", "<f4"),
+        ("limit", "<u4"),
+        ("reserved", "<u4"),
     ]
 )
 contact_dtype = np.dtype(
@@ -122,7 +125,7 @@ contact_dtype = np.dtype(
 )
 assert collider_dtype.itemsize == 40
 assert material_dtype.itemsize == 12
-assert constraint_dtype.itemsize == 32
+assert constraint_dtype.itemsize == 40
 ray_hit_dtype = np.dtype([("body", "<u4"), ("t", "<f4"), ("normal", "<f4", (2,))])
 assert contact_dtype.itemsize == 60
 assert ray_hit_dtype.itemsize == 16

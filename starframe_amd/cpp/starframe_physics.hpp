@@ -151,8 +151,9 @@ public:
     BodyKey add_particle(const Body& body, const Pose& pose) { Collider none; none.raw_.type = SFX_SHAPE_NONE; return add(body, none, pose); }
 
     // distance constraint between body-local anchors (world position for WORLD)
-    void add_distance_constraint(BodyKey a, Vec2 anchor_a, BodyKey b, Vec2 anchor_b, float rest_length, float compliance = 0) {
-        sfx_distance_constraint c{a, b, {anchor_a.x, anchor_a.y}, {anchor_b.x, anchor_b.y}, rest_length, compliance};
+    void add_distance_constraint(BodyKey a, Vec2 anchor_a, BodyKey b, Vec2 anchor_b, float rest_length, float compliance = 0,
+                                 uint32_t limit = SFX_LIMIT_NONE) {
+        sfx_distance_constraint c{a, b, {anchor_a.x, anchor_a.y}, {anchor_b.x, anchor_b.y}, rest_length, compliance, limit, 0u};
         joints_.push_back(c);
         dirty_ = true;
     }

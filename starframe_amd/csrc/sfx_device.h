@@ -799,7 +799,7 @@ __device__ __forceinline__ int solve_vel_rec(const PairRec& r, float4& pa, float
 struct JointArrays {
     const uint2* bodies;    // (a, b), SFX_WORLD_BODY for the world
     const float4* anchors;  // (a.x, a.y, b.x, b.y)
-    const float2* params;   // (rest_length, compliance)
+    const float4* params;   // (rest_length, compliance, limit as bits, 0)
 };
 
 __device__ __forceinline__ void apply_pos(float4& pose, const float2& w, float rx, float ry, float px, float py, float sign) {
@@ -821,7 +821,7 @@ __device__ __forceinline__ float gen_inv_mass(const float2& w, float rx, float r
 __device__ __forceinline__ void solve_joint(const BodyArrays& B, const JointArrays& J, uint32_t k, float inv_h2) {
     const uint2 ab = J.bodies[k];
     const float4 an = J.anchors[k];
-    const float2 pr = J.params[k];
+    const float4 pr = J.params[k];
     const uint32_t a = ab.x, b = ab.y;
     float rax = 0.0f, ray = 0.0f, rbx = 0.0f, rby = 0.0f, pax, pay, pbx, pby;
     float4 pa = make_float4(0, 0, 1, 0), pb = make_float4(0, 0, 1, 0);
@@ -841,6 +841,9 @@ __device__ __forceinline__ void solve_joint(const BodyArrays& B, const JointArra
     if (!(len > SFX_EPS_LEN)) return;
     float nx = dx / len, ny = dy / len;
     float Cc = len - pr.x;
+    const uint32_t limit = __float_as_uint(pr.z);  // one-sided links: a rope only pulls, a strut only pushes
+    if (limit == SFX_LIMIT_ROPE && !(Cc > 0.0f)) return;
+    if (limit == SFX_LIMIT_STRUT && !(Cc < 0.0f)) return;
     float wsum = pr.y * inv_h2;
     if (a != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(wa, rax, ray, nx, ny);
     if (b != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(wb, rbx, rby, nx, ny);

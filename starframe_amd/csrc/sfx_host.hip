@@ -111,7 +111,7 @@ struct sfx_world {
     // joints (colour-sorted)
     DevBuf<uint2> j_bodies;
     DevBuf<float4> j_anchors;
-    DevBuf<float2> j_params;
+    DevBuf<float4> j_params;
     DevBuf<uint32_t> j_count_dev;
     std::vector<uint32_t> joint_perm;
     std::vector<uint8_t> joint_color_sorted;
@@ -724,6 +724,8 @@ int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constrai
     for (uint32_t k = 0; k < m; ++k)
         if ((c[k].body_a != SFX_WORLD_BODY && c[k].body_a >= w->n) || (c[k].body_b != SFX_WORLD_BODY && c[k].body_b >= w->n))
             return fail(w, SFX_ERR_INVALID, "constraint %u: body index out of range", k);
+    for (uint32_t k = 0; k < m; ++k)
+        if (c[k].limit > SFX_LIMIT_STRUT) return fail(w, SFX_ERR_INVALID, "constraint %u: unknown limit %u", k, c[k].limit);
     w->m = m;
     w->joint_perm.assign(m, 0);
     w->joint_color_sorted.assign(m, 0);
@@ -768,17 +770,18 @@ int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constrai
     }
     std::vector<uint2> hb(m);
     std::vector<float4> ha(m);
-    std::vector<float2> hp(m);
+    std::vector<float4> hp(m);
     for (uint32_t d = 0; d < m; ++d) {
         const sfx_distance_constraint& j = c[w->joint_perm[d]];
         hb[d] = make_uint2(j.body_a, j.body_b);
         ha[d] = make_float4(j.anchor_a[0], j.anchor_a[1], j.anchor_b[0], j.anchor_b[1]);
-        hp[d] = make_float2(j.rest_length, j.compliance);
+        hp[d] = make_float4(j.rest_length, j.compliance, 0.0f, 0.0f);
+        memcpy(&hp[d].z, &j.limit, 4);
     }
     ALLOC(w, w->j_bodies, m); ALLOC(w, w->j_anchors, m); ALLOC(w, w->j_params, m);
     HIPCHK(w, hipMemcpy(w->j_bodies.p, hb.data(), sizeof(uint2) * m, hipMemcpyHostToDevice));
     HIPCHK(w, hipMemcpy(w->j_anchors.p, ha.data(), sizeof(float4) * m, hipMemcpyHostToDevice));
-    HIPCHK(w, hipMemcpy(w->j_params.p, hp.data(), sizeof(float2) * m, hipMemcpyHostToDevice));
+    HIPCHK(w, hipMemcpy(w->j_params.p, hp.data(), sizeof(float4) * m, hipMemcpyHostToDevice));
     return SFX_OK;
 }
 

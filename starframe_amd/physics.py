@@ -105,9 +105,11 @@ class Physics:
             return self._b.poly(position, collider.verts, rounding=collider.r, **dyn, **kw)
         raise ValueError(collider.kind)
 
-    def add_distance_constraint(self, a, b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), rest_length=None, compliance=0.0):
+    def add_distance_constraint(self, a, b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), rest_length=None, compliance=0.0,
+                                limit=0):
+        """limit: 0 holds the length both ways, 1 (rope) only pulls, 2 (strut) only pushes."""
         self._b.distance(WORLD_BODY if a is None else a, WORLD_BODY if b is None else b, anchor_a, anchor_b,
-                         rest_length, compliance)
+                         rest_length, compliance, limit)
 
     def tick(self, frame_dt):
         """The per-frame tick entry point: asynchronous, one sfx_step."""

@@ -143,12 +143,12 @@ class SceneBuilder:
     def static_rect(self, pos, hw, hh, angle=0.0, **kw):
         return self._add(pos, angle, (0, 0), 0.0, 0.0, 0.0, self._col(SHAPE_RECT, (hw, hh, 0.0), **kw))
 
-    def distance(self, a, b, anchor_a=(0, 0), anchor_b=(0, 0), rest=None, compliance=0.0):
+    def distance(self, a, b, anchor_a=(0, 0), anchor_b=(0, 0), rest=None, compliance=0.0, limit=0):
         if rest is None:
             pa = np.asarray(anchor_a, float) if a == WORLD_BODY else np.asarray(self.pos[a], float)
             pb = np.asarray(anchor_b, float) if b == WORLD_BODY else np.asarray(self.pos[b], float)
             rest = float(np.linalg.norm(pb - pa))
-        self.constraints.append((a, b, tuple(anchor_a), tuple(anchor_b), rest, compliance))
+        self.constraints.append((a, b, tuple(anchor_a), tuple(anchor_b), rest, compliance, limit, 0))
 
     def build(self):
         n = len(self.pos)

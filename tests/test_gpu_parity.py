@@ -198,6 +198,30 @@ def test_chains_joint_colouring_and_tick():
     assert abs(gp[tips, 1].mean() - op[tips, 1].mean()) < 0.1
 
 
+def test_rope_links_match_oracle():
+    """One-sided links (SFX_LIMIT_ROPE / _STRUT): chains of rope links that start slack, one tick within
+    1e-5 and the tips' sag after 120 ticks."""
+    from oracle.oracle import ORDER_COLORED
+
+    s = scenes.chains(n_chains=12, links=25)
+    s.constraints["rest_length"] = 0.14                    # bodies 0.12 apart: every rope link starts slack
+    s.constraints["limit"] = 1
+    s.constraints["limit"][::7] = 2                        # a few struts among them
+    s.constraints["limit"][::11] = 0
+    g, o = make_pair(s)
+    g.step(DT)
+    o.step(DT, ORDER_COLORED)
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= TOL
+    assert rel_err(g.velocities()[0], o.velocities()[0], floor=1.0) <= 1e-4
+    for _ in range(120):
+        g.step(DT)
+        o.step(DT, ORDER_COLORED)
+    gp, op = g.poses()[0], o.poses()[0]
+    assert np.isfinite(gp).all()
+    tips = np.arange(12) * 25 + 24
+    assert abs(gp[tips, 1].mean() - op[tips, 1].mean()) < 0.1
+
+
 def test_empty_and_tiny_worlds():
     from starframe_amd.scenes import SceneBuilder
     from starframe_amd.world import World

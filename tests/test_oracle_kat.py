@@ -179,6 +179,40 @@ def test_distance_constraint_single_step_closed_form(compliance):
         np.testing.assert_allclose(pos[1, 0] - pos[0, 0], 1.0, rtol=1e-5)
 
 
+@pytest.mark.parametrize("limit,apart,acts", [(1, 1.5, True), (1, 0.6, False), (2, 0.6, True), (2, 1.5, False), (0, 0.6, True)])
+def test_one_sided_links_only_act_on_their_side(limit, apart, acts):
+    """SFX_LIMIT_ROPE pulls when stretched and is slack when short; SFX_LIMIT_STRUT the other way round."""
+    b = SceneBuilder("limit", substeps=1)
+    b.circle((0.0, 0.0), 0.05)
+    b.circle((apart, 0.0), 0.05)
+    b.distance(0, 1, rest=1.0, limit=limit)
+    w = OracleWorld.from_scene(b.build(), gravity=(0.0, 0.0))
+    w.step(DT, ORDER_SEQUENTIAL)
+    pos, _ = w.poses()
+    d = float(pos[1, 0] - pos[0, 0])
+    if acts:
+        np.testing.assert_allclose(d, 1.0, rtol=1e-5)
+    else:
+        assert d == np.float32(apart)
+
+
+def test_rope_hangs_slack_then_catches():
+    """A body on a rope link falls freely until the rope is taut, then swings like a pendulum."""
+    b = SceneBuilder("rope", substeps=8)
+    b.circle((0.3, 0.0), 0.05)
+    b.distance(WORLD_BODY, 0, anchor_a=(0.0, 0.0), rest=1.0, limit=1)
+    w = world(b)
+    w.step(DT)
+    pos, _ = w.poses()
+    assert pos[0, 0] == np.float32(0.3) and pos[0, 1] < 0.0      # slack: plain free fall
+    far = 0.0
+    for _ in range(240):
+        w.step(DT)
+        pos, _ = w.poses()
+        far = max(far, float(np.hypot(*pos[0])))
+    assert 0.99 < far < 1.003                                    # caught at the rope's length, never beyond
+
+
 def test_pendulum_keeps_length_and_swings():
     b = SceneBuilder("pend", substeps=8)
     b.circle((1.0, 0.0), 0.05)
