@@ -406,7 +406,7 @@ int broadphase(sfx_world* w, float dt) {
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
       hipLaunchKernelGGL((k_batch_color<kBatchP, false>), dim3(w->color_grid, 4), dim3(512), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
-                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->max_pairs, w->cfg.color_rounds, w->ctr); }
+                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
     return SFX_OK;
@@ -1358,10 +1358,10 @@ int sfx_kernel_times(sfx_world* w, sfx_kernel_time* out, int reset) {
 // batches, colours, wait, write-back]; k_tile_vel: [8 wait, 9 load, 10 colour loop, 11 write-back, 12 whole batch, 13 batches]
 int sfx_debug_tile_timing(sfx_world* w, unsigned long long* out, int reset) {
     if (!w) return SFX_ERR_INVALID;
-    if (!w->dbg.p) { if (w->dbg.alloc(16)) return SFX_ERR_NOMEM; (void)hipMemset(w->dbg.p, 0, 128); }
+    if (!w->dbg.p) { if (w->dbg.alloc(128)) return SFX_ERR_NOMEM; (void)hipMemset(w->dbg.p, 0, 1024); }
     (void)hipStreamSynchronize(w->stream);
-    if (out) (void)hipMemcpy(out, w->dbg.p, 128, hipMemcpyDeviceToHost);
-    if (reset) (void)hipMemset(w->dbg.p, 0, 128);
+    if (out) (void)hipMemcpy(out, w->dbg.p, 1024, hipMemcpyDeviceToHost);
+    if (reset) (void)hipMemset(w->dbg.p, 0, 1024);
     return SFX_OK;
 }
 #endif

@@ -37,6 +37,17 @@ constexpr int kScanTile = kBlock * kScanItems;      // 4096 items per block
 constexpr uint32_t kLeftCap = 4096;                 // leftover edges the serial finish takes
 constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u, kOvfFallback = 16u, kOvfStall = 32u;
 
+// stage timing of the tile kernels and the colouring (development builds with -DSFX_TILE_TIMING; `T.dbg` or `dbg` in scope)
+#ifdef SFX_TILE_TIMING
+#define SFX_TT(var) const unsigned long long var = wall_clock64()
+#define SFX_TT_ADD(slot, a, b) if (threadIdx.x == 0 && T.dbg) atomicAdd(&T.dbg[slot], (b) - (a))
+#define SFX_TT_MAX(slot, a, b) if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[slot], (b) - (a))
+#else
+#define SFX_TT(var)
+#define SFX_TT_ADD(slot, a, b)
+#define SFX_TT_MAX(slot, a, b)
+#endif
+
 // device-resident counters of one tick (one allocation, zeroed at the start of every tick)
 struct Counters {
     uint32_t n_small;       // written by k_finalize_slots
@@ -717,7 +728,10 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                                                          uint4* __restrict__ tpair, BatchDesc* __restrict__ batches,
                                                          const float4* __restrict__ shape, uint32_t* __restrict__ torder,
                                                          uint32_t* __restrict__ tile_batch,
-                                                         uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr) {
+                                                         uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr,
+                                                         unsigned long long* __restrict__ dbg) {
+    struct { unsigned long long* dbg; } T = {dbg};  // for the stage-timing macros
+    (void)T;
     constexpr uint32_t MB = kMaxB;
     constexpr uint32_t kBlock = 512;  // shadows the file-level constant: this kernel runs 512 threads
     __shared__ unsigned long long s_used[MB];
@@ -773,6 +787,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
         const uint32_t nbat = s_nbat;
         for (uint32_t bi = 0; bi < nbat; ++bi) {
             const uint32_t f = s_bfirst[bi], c = s_bfirst[bi + 1] - f;
+            SFX_TT(tc0);
             batch_ranges(lst + e0 + f, c, g, cell_start, S);
             if (tid == 0) {
                 uint32_t run = 0;
@@ -804,8 +819,10 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 if (!keep) atomicAdd(&s_npruned, 1u);
             }
             __syncthreads();
+            SFX_TT(tc1);
 #define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
             for (uint32_t r = 0; r < rounds; ++r) {
+                SFX_TT_ADD(98, 0ull, 1ull);
                 int open_edges = 0;
                 for (uint32_t e = tid; e < np; e += kBlock) open_edges |= (s_col[e] == SFX_NO_COLOR) ? 1 : 0;
                 if (!__syncthreads_or(open_edges)) break;  // everything coloured: later rounds would do nothing
@@ -841,6 +858,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 }
                 __syncthreads();
             }
+            SFX_TT(tc2);
             // serial first-fit finish over the leftovers, ascending key
             for (uint32_t e = tid; e < np; e += kBlock)
                 if (s_col[e] == SFX_NO_COLOR) s_left[atomicAdd(&s_nleft, 1u)] = (uint16_t)e;
@@ -874,6 +892,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 __syncthreads();
             }
 #undef TDYN
+            SFX_TT(tc3);
             // colour-major order inside the batch (uncoloured pairs last)
             for (uint32_t e = tid; e < np; e += kBlock) {
                 const uint32_t cc = s_col[e];
@@ -937,6 +956,9 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
             }
             for (uint32_t e = s_ptail_first + tid; e < np; e += kBlock) torder[bstart + e] = kNoPair;  // pruned pairs: no narrowphase
             __syncthreads();
+            SFX_TT(tc4);
+            SFX_TT_ADD(96, tc0, tc1); SFX_TT_ADD(97, tc1, tc2); SFX_TT_ADD(99, tc2, tc3); SFX_TT_ADD(100, tc3, tc4);
+            SFX_TT_ADD(101, 0ull, 1ull); SFX_TT_ADD(102, tc0, tc4); SFX_TT_MAX(103, tc0, tc4);
         }
     }
 }
@@ -1126,13 +1148,6 @@ struct TileArrays {
     unsigned long long* dbg;      // stage timing (builds with -DSFX_TILE_TIMING only), else unused
 };
 
-#ifdef SFX_TILE_TIMING
-#define SFX_TT(var) const unsigned long long var = wall_clock64()
-#define SFX_TT_ADD(slot, a, b) if (threadIdx.x == 0 && T.dbg) atomicAdd(&T.dbg[slot], (b) - (a))
-#else
-#define SFX_TT(var)
-#define SFX_TT_ADD(slot, a, b)
-#endif
 
 __device__ __forceinline__ void store_record(const ContactArrays& C, uint32_t slot, const PairRec& r) {
     C.misc[slot] = make_float2(r.rest, __uint_as_float((uint32_t)r.count));
@@ -1534,7 +1549,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
             __syncthreads();
         }
         SFX_TT(tt4);
-        SFX_TT_ADD(0, ttw, tt1); SFX_TT_ADD(3, tt0, tt4); SFX_TT_ADD(4, 0ull, 1ull); SFX_TT_ADD(7, tt3, tt4);
+        SFX_TT_ADD(0, ttw, tt1); SFX_TT_ADD(3, tt0, tt4); SFX_TT_ADD(4, 0ull, 1ull); SFX_TT_ADD(7, tt3, tt4); SFX_TT_MAX(15, ttw, tt4);
     }
     if (with_fallback && last_workgroup(ctr)) fallback_pos(T, ctr, B, C, max_corr);
 }
@@ -1551,6 +1566,9 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
     __shared__ uint32_t s_shift;
     __shared__ BatchRanges S;
     const uint32_t tid = threadIdx.x;
+#ifdef SFX_TILE_TIMING
+    if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[48 + 2 * (epoch & 15u)], ~wall_clock64());   // earliest kernel entry
+#endif
     const __amdgpu_buffer_rsrc_t pose_rs = record_rsrc(B.pose), vel_rs = record_rsrc(B.vel);
     const uint32_t nitems = phase_total(ctr, ph0, nph);
     for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
@@ -1632,9 +1650,18 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         }
         SFX_TT(tv3);
         SFX_TT_ADD(8, tv0, tvw); SFX_TT_ADD(9, tvw, tv1); SFX_TT_ADD(10, tv1, tv2); SFX_TT_ADD(11, tv2, tv3);
-        SFX_TT_ADD(12, tv0, tv3); SFX_TT_ADD(13, 0ull, 1ull);
+        SFX_TT_ADD(12, tv0, tv3); SFX_TT_ADD(13, 0ull, 1ull); SFX_TT_MAX(14, tvw, tv3);
+#ifdef SFX_TILE_TIMING
+        if (threadIdx.x == 0 && T.dbg) {
+            atomicMax(&T.dbg[16 + 2 * (epoch & 15u)], ~tv0);       // earliest batch start of this launch
+            atomicMax(&T.dbg[17 + 2 * (epoch & 15u)], tv3);        // latest batch end
+        }
+#endif
     }
     if (with_fallback && last_workgroup(ctr)) fallback_vel(T, ctr, B, C, sp);
+#ifdef SFX_TILE_TIMING
+    if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[49 + 2 * (epoch & 15u)], wall_clock64());    // latest kernel exit
+#endif
 }
 
 __global__ __launch_bounds__(kBlock) void k_solve_joints(uint32_t start, uint32_t cnt, BodyArrays B, JointArrays J,
