@@ -535,15 +535,14 @@ __device__ __forceinline__ void manifold(const float4& pa, const float4& sa, con
 }
 
 // ---- per-manifold solver records -----------------------------------------------------
-// What the position solve leaves for the velocity pass, one record per candidate pair slot
-// (colour-sorted order), split into 16/8-byte arrays so a wave's accesses are contiguous.
+// What the narrowphase leaves for the solves, one record per solver pair slot (colour-sorted order): a
+// whole 64-byte line per slot, so that the narrowphase (which visits the slots in class order, i.e.
+// scattered) writes full lines and the colour loops (consecutive lanes, consecutive slots) read them
+// coalesced.
 struct ContactArrays {
-    float4* hdr;     // (nx, ny, mu_s, mu_d)
-    float2* misc;    // (restitution, count as bits)
-    float4* anc0;    // point 0: (ra.x, ra.y, rb.x, rb.y) body-local
-    float4* anc1;    // point 1
-    float2* lam;     // (lambda0, lambda1) of this substep
-    float2* vpre;    // (vn_pre0, vn_pre1): normal relative velocities before the position solve
+    float4* rec;     // one 64-byte line per slot: [4k] (nx, ny, mu_s, mu_d), [4k+1] point 0 anchors (ra.x, ra.y, rb.x, rb.y)
+                     // body-local, [4k+2] point 1 anchors, [4k+3] (restitution, count as bits, vn_pre0, vn_pre1)
+    float2* lam;     // (lambda0, lambda1) of this substep: written by the position solve, read by the velocity pass
 };
 
 __device__ __forceinline__ void anchor_world(const float4& pose, float lx, float ly, float& rx, float& ry) {

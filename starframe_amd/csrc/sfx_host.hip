@@ -105,9 +105,8 @@ struct sfx_world {
     hipStream_t own_stream_handle = nullptr;
     DevBuf<unsigned long long> dbg;  // -DSFX_TILE_TIMING builds: stage timing of k_tile_pos
     // contact records
-    DevBuf<float4> c_hdr, c_anc0, c_anc1;
-    DevBuf<float2> c_lam, c_vpre;
-    DevBuf<float2> c_misc;
+    DevBuf<float4> c_rec;   // 4 per slot: one 64-byte line
+    DevBuf<float2> c_lam;
     // joints (colour-sorted)
     DevBuf<uint2> j_bodies;
     DevBuf<float4> j_anchors;
@@ -314,7 +313,7 @@ BodyArrays body_arrays(sfx_world* w) {
 
 ContactArrays contact_arrays(sfx_world* w) {
     ContactArrays C;
-    C.hdr = w->c_hdr.p; C.misc = w->c_misc.p; C.anc0 = w->c_anc0.p; C.anc1 = w->c_anc1.p; C.lam = w->c_lam.p; C.vpre = w->c_vpre.p;
+    C.rec = w->c_rec.p; C.lam = w->c_lam.p;
     return C;
 }
 
@@ -558,7 +557,7 @@ void sfx_destroy(sfx_world* w) {
     w->q_zero.release(); w->q_bucket.release(); w->q_cell_fill.release(); w->q_tmp_id.release(); w->q_sorted_id.release();
     w->q_large_tmp.release(); w->q_bounds.release(); w->q_nhits.release(); w->q_aabb.release(); w->q_sorted_aabb.release();
     w->q_cellxy.release(); w->q_sorted_cell.release();
-    w->c_hdr.release(); w->c_anc0.release(); w->c_anc1.release(); w->c_lam.release(); w->c_vpre.release(); w->c_misc.release();
+    w->c_rec.release(); w->c_lam.release();
     w->j_bodies.release(); w->j_anchors.release(); w->j_params.release(); w->j_count_dev.release();
     if (w->h_ctr) (void)hipHostFree(w->h_ctr);
     if (w->ev_ctr) (void)hipEventDestroy(w->ev_ctr);
@@ -707,8 +706,8 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     const size_t mc = std::max<size_t>(w->fb_cap, w->m);
     ALLOC(w, w->pcolor, mc); ALLOC(w, w->prop, mc);
     const size_t mp = (size_t)w->max_pairs + w->fb_cap;  // record slots: tile pairs, then the fallback list
-    ALLOC(w, w->c_hdr, mp); ALLOC(w, w->c_misc, mp); ALLOC(w, w->c_anc0, mp); ALLOC(w, w->c_anc1, mp); ALLOC(w, w->c_lam, mp); ALLOC(w, w->c_vpre, mp);
-    HIPCHK(w, hipMemset(w->c_misc.p, 0, sizeof(float2) * mp));
+    ALLOC(w, w->c_rec, 4 * mp); ALLOC(w, w->c_lam, mp);
+    HIPCHK(w, hipMemset(w->c_rec.p, 0, sizeof(float4) * 4 * mp));
     HIPCHK(w, hipMemset(w->zero.p, 0, w->zero_bytes));
     w->ctr_valid = false; w->ctr_pending = false;
     w->ticked = false;

@@ -1150,32 +1150,32 @@ struct TileArrays {
 
 
 __device__ __forceinline__ void store_record(const ContactArrays& C, uint32_t slot, const PairRec& r) {
-    C.misc[slot] = make_float2(r.rest, __uint_as_float((uint32_t)r.count));
+    float4* line = C.rec + 4u * (size_t)slot;
+    line[3] = make_float4(r.rest, __uint_as_float((uint32_t)r.count), r.vpre[0], r.vpre[1]);
     if (r.count == 0) return;
-    C.lam[slot] = make_float2(0.0f, 0.0f);
-    C.vpre[slot] = make_float2(r.vpre[0], r.vpre[1]);
-    C.hdr[slot] = make_float4(r.nx, r.ny, r.mu_s, r.mu_d);
-    C.anc0[slot] = make_float4(r.la[0][0], r.la[0][1], r.lb[0][0], r.lb[0][1]);
-    if (r.count == 2) C.anc1[slot] = make_float4(r.la[1][0], r.la[1][1], r.lb[1][0], r.lb[1][1]);
+    line[0] = make_float4(r.nx, r.ny, r.mu_s, r.mu_d);
+    line[1] = make_float4(r.la[0][0], r.la[0][1], r.lb[0][0], r.lb[0][1]);
+    line[2] = make_float4(r.la[1][0], r.la[1][1], r.lb[1][0], r.lb[1][1]);  // zeros for a one-point manifold: the line is written whole
 }
 
 __device__ __forceinline__ void load_record(const ContactArrays& C, uint32_t slot, PairRec& r) {
-    const float2 misc = C.misc[slot];
-    r.count = (int)__float_as_uint(misc.y);
-    r.rest = misc.x;
+    const float4* line = C.rec + 4u * (size_t)slot;
+    const float4 m = line[3];
+    r.count = (int)__float_as_uint(m.y);
+    r.rest = m.x;
     r.nx = r.ny = r.mu_s = r.mu_d = 0.0f;
     r.la[0][0] = r.la[0][1] = r.lb[0][0] = r.lb[0][1] = 0.0f;
     r.la[1][0] = r.la[1][1] = r.lb[1][0] = r.lb[1][1] = 0.0f;
     r.vpre[0] = r.vpre[1] = 0.0f; r.l0 = r.l1 = 0.0f;
     if (r.count == 0) return;
-    const float2 lam = C.lam[slot], vp = C.vpre[slot];
-    r.l0 = lam.x; r.l1 = lam.y; r.vpre[0] = vp.x; r.vpre[1] = vp.y;
-    const float4 hdr = C.hdr[slot];
+    const float2 lam = C.lam[slot];
+    r.l0 = lam.x; r.l1 = lam.y; r.vpre[0] = m.z; r.vpre[1] = m.w;
+    const float4 hdr = line[0];
     r.nx = hdr.x; r.ny = hdr.y; r.mu_s = hdr.z; r.mu_d = hdr.w;
-    const float4 a0 = C.anc0[slot];
+    const float4 a0 = line[1];
     r.la[0][0] = a0.x; r.la[0][1] = a0.y; r.lb[0][0] = a0.z; r.lb[0][1] = a0.w;
     if (r.count == 2) {
-        const float4 a1 = C.anc1[slot];
+        const float4 a1 = line[2];
         r.la[1][0] = a1.x; r.la[1][1] = a1.y; r.lb[1][0] = a1.z; r.lb[1][1] = a1.w;
     }
 }
@@ -1301,7 +1301,8 @@ struct PairSlot {
 // no load waits for another, nothing branches on loaded data), decoded only when the pair's colour
 // comes up -- so the loads of colour c + 1 are in flight while colour c is solved.
 struct RawSlot {
-    float2 misc, lam, vp;
+    float4 m;        // (restitution, count as bits, vn_pre0, vn_pre1)
+    float2 lam;
     uint4 pr;
     float4 hdr, a0, a1;
     bool in_range;
@@ -1311,16 +1312,17 @@ template <bool VEL>
 __device__ __forceinline__ void fetch_raw(const TileArrays& T, const ContactArrays& C, uint32_t slot, bool in_range,
                                           RawSlot& q) {
     q.in_range = in_range;
-    q.misc = make_float2(0.0f, 0.0f); q.lam = q.misc; q.vp = q.misc;
+    q.lam = make_float2(0.0f, 0.0f);
     q.pr = make_uint4(0, 0, 0, SFX_NO_COLOR);
-    q.hdr = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q.a0 = q.hdr; q.a1 = q.hdr;
+    q.hdr = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q.a0 = q.hdr; q.a1 = q.hdr; q.m = q.hdr;
     if (!in_range) return;
-    q.misc = C.misc[slot];
+    const float4* line = C.rec + 4u * (size_t)slot;
     q.pr = T.tpair[slot];
-    q.hdr = C.hdr[slot];
-    q.a0 = C.anc0[slot];
-    q.a1 = C.anc1[slot];
-    if (VEL) { q.lam = C.lam[slot]; q.vp = C.vpre[slot]; }
+    q.m = line[3];
+    q.hdr = line[0];
+    q.a0 = line[1];
+    q.a1 = line[2];
+    if (VEL) q.lam = C.lam[slot];
 }
 
 template <bool VEL>
@@ -1328,12 +1330,12 @@ __device__ __forceinline__ void decode_raw(const RawSlot& q, PairSlot& p) {
     p.valid = false;
     p.r.count = 0;
     p.e = pair_ends(q.pr);
-    const int count = (int)__float_as_uint(q.misc.y);
+    const int count = (int)__float_as_uint(q.m.y);
     if (!q.in_range || count == 0) return;
     if (VEL && !(q.lam.x + q.lam.y > 0.0f)) return;  // nothing was pushed: nothing to do in the velocity pass
     PairRec& r = p.r;
-    r.count = count; r.rest = q.misc.x;
-    r.l0 = q.lam.x; r.l1 = q.lam.y; r.vpre[0] = q.vp.x; r.vpre[1] = q.vp.y;
+    r.count = count; r.rest = q.m.x;
+    r.l0 = q.lam.x; r.l1 = q.lam.y; r.vpre[0] = q.m.z; r.vpre[1] = q.m.w;
     r.nx = q.hdr.x; r.ny = q.hdr.y; r.mu_s = q.hdr.z; r.mu_d = q.hdr.w;
     r.la[0][0] = q.a0.x; r.la[0][1] = q.a0.y; r.lb[0][0] = q.a0.z; r.lb[0][1] = q.a0.w;
     const bool two = count == 2;
@@ -1734,7 +1736,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restri
         Manifold m;
         manifold(B.pose[a], B.shape[a], B.pose[b], B.shape[b], B.poly, sm, m);
         for (int q = 0; q < m.count; ++q) md = fmaxf(md, m.depth[q]);
-        const uint32_t cnt = __float_as_uint(C.misc[slot].y);
+        const uint32_t cnt = __float_as_uint(C.rec[4u * (size_t)slot + 3u].y);
         if (cnt) {
             mf += 1u;
             mf2 += (cnt == 2) ? 1u : 0u;
