@@ -23,5 +23,11 @@ int main() {
     const sfx_frame_stats st = physics.stats();
     std::printf("pyramid: %zu bodies, top at %.3f (ideal %.1f), KE %.2e, %u pairs, %u colours\n", physics.body_count(), top,
                 base - 0.5f, st.kinetic_energy, st.n_pairs, st.n_colors);
-    return top > base - 0.6f ? 0 : 1;
+    // pick the apex from above with a ray, and the ground with a point query
+    const sfx_ray_hit hit = physics.raycast({0.0f, base + 5.0f}, {0.0f, -1.0f}, 100.0f);
+    const sf::BodyKey under = physics.query_point({30.0f, -0.5f});
+    std::printf("ray from above hits body %u at t = %.3f (normal %.2f, %.2f); body under (30, -0.5): %u\n", hit.body, hit.t,
+                hit.normal[0], hit.normal[1], under);
+    const bool ray_ok = hit.body != SFX_NO_BODY && hit.normal[1] > 0.9f && under == (sf::BodyKey)(physics.body_count() - 1);
+    return top > base - 0.6f && ray_ok ? 0 : 1;
 }

@@ -170,6 +170,37 @@ public:
         check(sfx_download_poses(world_, pos.data(), rot.data()), "sfx_download_poses");
     }
     sfx_frame_stats stats() { sfx_frame_stats s; check(sfx_stats(world_, &s), "sfx_stats"); return s; }
+
+    // ---- spatial queries at the current poses (the reference's mouse-pick / ray-cast API; include/sfx.h)
+    // body under a point (lowest key if several; WORLD = none)
+    BodyKey query_point(Vec2 p, uint32_t layer_mask = 0xFFFFFFFFu) {
+        if (dirty_) upload();
+        uint32_t body = SFX_NO_BODY;
+        const float xy[2] = {p.x, p.y};
+        check(sfx_query_points(world_, 1, xy, layer_mask, &body, nullptr), "sfx_query_points");
+        return body;
+    }
+    // bodies whose collider's bounding box overlaps [lo, hi]
+    std::vector<BodyKey> query_aabb(Vec2 lo, Vec2 hi, uint32_t layer_mask = 0xFFFFFFFFu) {
+        if (dirty_) upload();
+        const float box[4] = {lo.x, lo.y, hi.x, hi.y};
+        std::vector<uint64_t> hits(64);
+        size_t n = 0;
+        int rc = sfx_query_aabbs(world_, 1, box, layer_mask, hits.data(), hits.size(), &n);
+        if (rc == SFX_ERR_CAPACITY) { hits.resize(n); rc = sfx_query_aabbs(world_, 1, box, layer_mask, hits.data(), hits.size(), &n); }
+        check(rc, "sfx_query_aabbs");
+        std::vector<BodyKey> out(n);
+        for (size_t k = 0; k < n; ++k) out[k] = (BodyKey)(hits[k] & 0xFFFFFFFFu);
+        return out;
+    }
+    // closest hit of origin + t * dir, 0 <= t <= max_t; hit.body == SFX_NO_BODY when nothing is hit
+    sfx_ray_hit raycast(Vec2 origin, Vec2 dir, float max_t, uint32_t layer_mask = 0xFFFFFFFFu) {
+        if (dirty_) upload();
+        const float ray[4] = {origin.x, origin.y, dir.x, dir.y};
+        sfx_ray_hit hit;
+        check(sfx_query_rays(world_, 1, ray, &max_t, layer_mask, &hit), "sfx_query_rays");
+        return hit;
+    }
     size_t body_count() const { return inv_mass_.size(); }
 
 private:

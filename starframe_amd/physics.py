@@ -111,8 +111,7 @@ class Physics:
         self._b.distance(WORLD_BODY if a is None else a, WORLD_BODY if b is None else b, anchor_a, anchor_b,
                          rest_length, compliance, limit)
 
-    def tick(self, frame_dt):
-        """The per-frame tick entry point: asynchronous, one sfx_step."""
+    def _ensure_world(self):
         if self._world is None:
             if not self._b.materials:
                 self._mat(Material())
@@ -120,7 +119,27 @@ class Physics:
             self._world = World.from_scene(self._b.build(), substeps=c.substeps, gravity=c.gravity,
                                            aabb_margin=c.aabb_margin, device=c.device,
                                            max_depenetration_velocity=c.max_depenetration_velocity)
-        self._world.step(frame_dt)
+        return self._world
+
+    def tick(self, frame_dt):
+        """The per-frame tick entry point: asynchronous, one sfx_step."""
+        self._ensure_world().step(frame_dt)
+
+    # ---- spatial queries at the current poses (the reference's mouse-pick / ray-cast API)
+    def query_point(self, point, layer_mask=0xFFFFFFFF):
+        """Body under a point (lowest id if several), or None."""
+        body, _ = self._ensure_world().query_points([point], layer_mask)
+        return None if body[0] == 0xFFFFFFFF else int(body[0])
+
+    def query_aabb(self, lo, hi, layer_mask=0xFFFFFFFF):
+        """Bodies whose collider's bounding box overlaps [lo, hi]."""
+        hits = self._ensure_world().query_aabbs([[lo[0], lo[1], hi[0], hi[1]]], layer_mask)
+        return [int(h & 0xFFFFFFFF) for h in hits]
+
+    def raycast(self, origin, direction, max_t=float("inf"), layer_mask=0xFFFFFFFF):
+        """Closest hit of origin + t * direction: (body, t, normal) or None."""
+        h = self._ensure_world().query_rays([[origin[0], origin[1], direction[0], direction[1]]], max_t, layer_mask)[0]
+        return None if h["body"] == 0xFFFFFFFF else (int(h["body"]), float(h["t"]), (float(h["normal"][0]), float(h["normal"][1])))
 
     def poses(self):
         pos, rot = self._world.poses()

@@ -1,0 +1,50 @@
+"""GPU tests of the host-side mirrors of the reference's physics API (config / body / collider / material /
+tick / queries): the Python one (starframe_amd/physics.py) and the C++ one (starframe_amd/cpp), both over the
+C ABI.  Checked against closed-form answers (the oracle parity of the same calls is in the other GPU tests)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_python_physics_api_tick_and_queries():
+    from starframe_amd.physics import Body, Collider, Material, Physics, PhysicsConfig
+
+    ph = Physics(PhysicsConfig(substeps=8))
+    ground = ph.add(Body.static(), Collider.rect(40.0, 1.0), (0.0, -0.5))
+    box = ph.add(Body.dynamic(), Collider.rect(1.0, 1.0, material=Material(0.0, 0.6, 0.5)), (0.0, 0.52))
+    ball = ph.add(Body.dynamic(), Collider.circle(0.25), (3.0, 0.27))
+    bob = ph.add(Body.dynamic(), Collider.circle(0.1), (6.0, 3.0))
+    ph.add_distance_constraint(None, bob, anchor_a=(6.0, 4.0), rest_length=1.0, limit=1)   # a rope from a world point
+    for _ in range(120):
+        ph.tick(1.0 / 60.0)
+    pos, ang = ph.poses()
+    assert abs(pos[box, 1] - 0.5) < 5e-3 and abs(pos[ball, 1] - 0.25) < 5e-3       # resting on the ground
+    assert abs(np.hypot(pos[bob, 0] - 6.0, pos[bob, 1] - 4.0) - 1.0) < 5e-3        # hanging on the taut rope
+    assert ph.query_point((0.0, 0.5)) == box and ph.query_point((3.0, 0.3)) == ball
+    assert ph.query_point((1.5, 2.0)) is None and ph.query_point((10.0, -0.5)) == ground
+    assert sorted(ph.query_aabb((-1.0, 0.1), (3.5, 0.2))) == [box, ball]
+    hit = ph.raycast((0.0, 5.0), (0.0, -1.0))
+    assert hit[0] == box and abs(hit[1] - (5.0 - pos[box, 1] - 0.5)) < 1e-3 and hit[2][1] > 0.99
+    assert ph.raycast((-10.0, 10.0), (1.0, 0.0), max_t=100.0) is None
+    assert ph.raycast((-10.0, 0.25), (1.0, 0.0))[0] == box                          # the box is in front of the ball
+
+
+def test_cpp_host_api_example_builds_and_runs(tmp_path):
+    """starframe_amd/cpp/example_pyramid.cpp over starframe_physics.hpp: a 20-row pyramid stands, a ray from above
+    finds its apex, a point query finds the ground (the program's exit status)."""
+    exe = str(tmp_path / "example_pyramid")
+    csrc = os.path.join(ROOT, "starframe_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "starframe_amd", "cpp", "example_pyramid.cpp"),
+                           "-L", csrc, "-lsfx", "-Wl,-rpath," + csrc, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    sys.stdout.write(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ray from above hits body" in out.stdout
