@@ -88,7 +88,7 @@ typedef struct sfx_config {
     uint32_t flags;         /* SFX_CFG_* */
 } sfx_config;
 
-#define SFX_CFG_USE_GRAPH 1u     /* replay the tick from a captured hipGraph        */
+#define SFX_CFG_RESERVED 1u      /* not used: the tick is not launch-bound (host enqueue 0.08 ms of a 1 ms tick) */
 #define SFX_CFG_NO_FRICTION 2u   /* skip static + dynamic friction (debug)          */
 
 /* collider component (BASELINE.json:5 "body/collider/material components").

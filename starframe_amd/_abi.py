@@ -28,7 +28,6 @@ TILE_MAX_BODIES = 1024
 FALLBACK_TILE = 0xFFFFFFFF
 
 LIMIT_NONE, LIMIT_ROPE, LIMIT_STRUT = 0, 1, 2
-CFG_USE_GRAPH = 1
 CFG_NO_FRICTION = 2
 
 

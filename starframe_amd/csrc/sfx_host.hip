@@ -69,7 +69,7 @@ struct sfx_world {
     Counters* ctr = nullptr;
     uint32_t *cell_start = nullptr, *tile_cnt = nullptr, *tile_fill = nullptr, *tile_flag = nullptr, *tile_batch = nullptr;
     size_t zero_bytes = 0;
-    DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, scan_sums, active, big_tiles;
+    DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, scan_sums, active;
     DevBuf<BatchDesc> batches;
     DevBuf<uint32_t> torder, done;
     uint32_t epoch = 0;            // one per fused multi-phase launch; never reset, so T.done needs no clearing
@@ -121,7 +121,7 @@ struct sfx_world {
     bool ctr_pending = false, ctr_valid = false;
     Counters stale{};
     uint32_t launches = 0;
-    uint32_t color_grid = 1024, big_grid = 64, tile_grid[4] = {1024, 1024, 1024, 1024}, tile_grid_max = 8192;
+    uint32_t color_grid = 1024, tile_grid[4] = {1024, 1024, 1024, 1024}, tile_grid_max = 8192;
     uint32_t group = 4;  // tiles a colouring workgroup cuts into batches (from the pair density of an earlier tick)
     bool ticked = false;
     // profiling
@@ -340,7 +340,7 @@ uint32_t edge_grid(uint32_t cap) { return std::min(std::max(cdiv(cap, kBlock), 1
 TileArrays tile_arrays(sfx_world* w) {
     TileArrays T;
     T.cell_start = w->cell_start; T.sorted_id = w->sorted_id.p; T.tile_start = w->tile_cnt;
-    T.active = w->active.p; T.big = w->big_tiles.p; T.batches = w->batches.p; T.tpair = w->tpair.p; T.torder = w->torder.p; T.tile_batch = w->tile_batch; T.done = w->done.p; T.fsorted = w->fsorted.p;
+    T.active = w->active.p; T.batches = w->batches.p; T.tpair = w->tpair.p; T.torder = w->torder.p; T.tile_batch = w->tile_batch; T.done = w->done.p; T.fsorted = w->fsorted.p;
     T.max_pairs = w->max_pairs; T.fb_cap = w->fb_cap;
     T.dbg = w->dbg.p;
     return T;
@@ -389,7 +389,7 @@ int broadphase(sfx_world* w, float dt) {
                          w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }
     { Prof p(w, SFX_K_TILE_LIST, w->ntiles);
       hipLaunchKernelGGL(k_tile_list, dim3(cdiv(w->ntiles, kBlock)), dim3(kBlock), 0, w->stream, g, w->cell_start,
-                         w->tile_cnt, w->tile_flag, w->active.p, w->big_tiles.p, w->ctr); }
+                         w->tile_cnt, w->tile_flag, w->active.p, w->ctr); }
     rc = scan_u32(w, w->tile_cnt, w->ntiles + 1, nullptr);
     if (rc) return rc;
     { Prof p(w, SFX_K_PAIR_FILL, n);
@@ -403,7 +403,7 @@ int broadphase(sfx_world* w, float dt) {
       hipLaunchKernelGGL(k_reach, dim3(cdiv(std::min(est, w->max_pairs), kBlock)), dim3(kBlock), 0, w->stream, w->tile_cnt,
                          w->ntiles, w->max_pairs, w->rawp.p, w->shape.p, RP); }
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
-      hipLaunchKernelGGL((k_batch_color<kBatchP, false>), dim3(w->color_grid, 4), dim3(512), 0, w->stream, g, w->group,
+      hipLaunchKernelGGL(k_batch_color<kBatchP>, dim3(w->color_grid, 4), dim3(512), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
                          w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
@@ -434,7 +434,6 @@ void poll_counters(sfx_world* w) {
             groups = std::max(groups, cdiv(w->stale.n_listed[ph], w->group));
         }
         w->color_grid = std::min(std::max(groups + groups / 8u + 4u, 1u), 8192u);
-        w->big_grid = std::min(std::max(w->stale.n_big + w->stale.n_big / 8u + 4u, 1u), 1024u);
     }
 }
 
@@ -547,7 +546,7 @@ void sfx_destroy(sfx_world* w) {
     w->pose.release(); w->prev.release(); w->vel.release(); w->shape.release(); w->poly.release();
     w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release();
     w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
-    w->active.release(); w->big_tiles.release(); w->batches.release(); w->torder.release(); w->done.release(); w->rawp.release(); w->tpair.release();
+    w->active.release(); w->batches.release(); w->torder.release(); w->done.release(); w->rawp.release(); w->tpair.release();
     w->fpairs.release(); w->fsorted.release(); w->hit_tmp.release();
     w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->scan_sums.release();
     w->cellxy.release(); w->sorted_cell.release();
@@ -698,7 +697,7 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     w->tile_flag = w->tile_fill + w->ntiles;
     w->tile_batch = w->tile_flag + w->ntiles;
     ALLOC(w, w->cell_fill, (size_t)w->ncell + 1 + pad);
-    ALLOC(w, w->active, 2 * (size_t)w->ntiles); ALLOC(w, w->big_tiles, w->ntiles); ALLOC(w, w->batches, 2 * (size_t)w->ntiles);
+    ALLOC(w, w->active, 2 * (size_t)w->ntiles); ALLOC(w, w->batches, 2 * (size_t)w->ntiles);
     ALLOC(w, w->rawp, w->max_pairs); ALLOC(w, w->tpair, w->max_pairs); ALLOC(w, w->torder, w->max_pairs);
     ALLOC(w, w->done, 2 * (size_t)w->ntiles);
     HIPCHK(w, hipMemset(w->done.p, 0, sizeof(uint32_t) * 2 * (size_t)w->ntiles));

@@ -67,10 +67,10 @@ struct Counters {
     uint32_t n_active[4];   // [0]: tiles that own pairs (statistic), rest unused
     uint32_t ticket;        // last-workgroup detection of the phase-3 kernels
     uint32_t n_over_tiles;  // tiles that handed their pairs to the fallback list
-    uint32_t n_big;         // tiles with more than kBatchP pairs: batches of their own
+    uint32_t pad4;
     uint32_t tp_cursor;     // pairs written to the batch-ordered pair list
     uint32_t n_batches[4];  // batches per phase
-    uint32_t n_listed[4];   // tiles on the per-phase lists (all but the big ones)
+    uint32_t n_listed[4];   // tiles on the per-phase lists
     uint32_t color_count[SFX_MAX_COLORS];
     uint32_t fb_start[SFX_MAX_COLORS + 1];  // colour-major offsets into the sorted fallback list
     uint32_t n_kept;        // tile pairs within reach (the solves' pairs; the fallback list is not tested)
@@ -568,48 +568,45 @@ __device__ __forceinline__ uint32_t block_slot(const BlockRanges& R, uint32_t l)
 }
 
 // One thread per tile, after the count pass: tiles over capacity are flagged (their pair count
-// is zeroed so that the scan skips them); tiles with more pairs than a batch holds are listed as
-// "big" (each is a batch of its own), the others per phase.
+// is zeroed so that the scan skips them), the others listed per phase.
 __global__ __launch_bounds__(kBlock) void k_tile_list(GridParams g, const uint32_t* __restrict__ cell_start,
                                                        uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_flag,
-                                                       uint32_t* __restrict__ active, uint32_t* __restrict__ big,
-                                                       Counters* __restrict__ ctr) {
+                                                       uint32_t* __restrict__ active, Counters* __restrict__ ctr) {
     const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t cnt = t < g.ntiles ? tile_cnt[t] : 0u;
-    // 0..3: listed under that phase, 4: big, 5: over capacity, 6: nothing to do
-    uint32_t kind = 6u, nb = 0u;
+    // 0..3: listed under that phase, 4: over capacity, 5: nothing to do
+    uint32_t kind = 5u, nb = 0u;
     if (cnt) {
         BlockRanges R;
         block_ranges(t, g, cell_start, R);
         nb = R.off[4];
         const uint32_t lx = g.gxl - g.tlx;
-        if (cnt > kMaxP || nb > kMaxB) kind = 5u;
+        if (cnt > kMaxP || nb > kMaxB) kind = 4u;
         else kind = (t & 1u) | (((t >> lx) & 1u) << 1);
     }
-    if (!__any(kind != 6u)) return;
+    if (!__any(kind != 5u)) return;
     // one atomic per wave and list: the lanes of a kind take consecutive entries
     const int lane = threadIdx.x & 63;
     const uint64_t below = (1ull << lane) - 1ull;
 #pragma unroll
-    for (uint32_t k = 0; k < 6; ++k) {
+    for (uint32_t k = 0; k < 5; ++k) {
         const uint64_t bal = __ballot(kind == k);
         if (!bal) continue;
         uint32_t base = 0;
         const int leader = __builtin_ctzll(bal);
         if (lane == leader) {
             const uint32_t c = (uint32_t)__popcll(bal);
-            base = atomicAdd(k < 4 ? &ctr->n_listed[k] : k == 4 ? &ctr->n_big : &ctr->n_over_tiles, c);
+            base = atomicAdd(k < 4 ? &ctr->n_listed[k] : &ctr->n_over_tiles, c);
         }
         base = __shfl(base, leader, 64);
         if (kind == k) {
             const uint32_t idx = base + (uint32_t)__popcll(bal & below);
             if (k < 4) active[k * g.pstride + idx] = t;
-            else if (k == 4) big[idx] = t;
             else { tile_flag[t] = 1u; tile_cnt[t] = 0u; }
         }
     }
     // statistics: wave maxima, one atomic each
-    uint32_t mp = (kind < 5u) ? cnt : 0u, mb = (kind < 5u) ? nb : 0u;
+    uint32_t mp = (kind < 4u) ? cnt : 0u, mb = (kind < 4u) ? nb : 0u;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         mp = max(mp, (uint32_t)__shfl_xor((int)mp, off, 64));
@@ -630,7 +627,7 @@ __device__ __forceinline__ void tile_pair_range(uint32_t t, const uint32_t* __re
 // runs colour c of all its tiles in the same step).  Batching is scheduling only: results do
 // not depend on which tiles share a batch.
 struct BatchDesc {
-    uint32_t first;    // index of the first tile on the phase's list (bit 31: on the big list)
+    uint32_t first;    // index of the first tile on the phase's list
     uint32_t count;    // tiles
     uint32_t bstart;   // first pair in tpair / first record slot
     uint32_t np;       // pairs within reach: the ones the solves take (the others follow them in tpair)
@@ -716,10 +713,9 @@ __global__ __launch_bounds__(kBlock) void k_reach(const uint32_t* __restrict__ t
 // Forms the batches and edge-colours every tile's pair graph, all state in LDS (DESIGN.md
 // "Contract / colouring").  Pairs that failed the reach test are not coloured; they are listed
 // behind the batch's pairs with SFX_PRUNED_COLOR.  A workgroup takes `group` consecutive tiles of a phase's list and
-// cuts them greedily into batches of at most kBatchP pairs and kMaxB bodies (BIG: one tile of
-// the big list per batch, up to kMaxP pairs).  Per batch it writes the pairs colour-major as
+// cuts them greedily into batches of at most kBatchP pairs and kMaxB bodies.  Per batch it writes the pairs colour-major as
 // (id a, id b, local a | local b << 16, colour | tile << 8) and a BatchDesc on the phase's table.
-template <uint32_t MP, bool BIG>
+template <uint32_t MP>
 __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t group, const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ sorted_id,
                                                          const uint4* __restrict__ filt,
@@ -753,10 +749,9 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
     __shared__ uint32_t s_tile[kMaxGroup], s_tnb[kMaxGroup], s_tnp[kMaxGroup], s_tstart[kMaxGroup];
     __shared__ uint32_t s_bfirst[kMaxGroup + 1], s_poff[kMaxGroup + 1];
     const uint32_t tid = threadIdx.x;
-    const uint32_t ph_list = BIG ? 0u : blockIdx.y;
-    const uint32_t nlist = BIG ? ctr->n_big : ctr->n_listed[ph_list];
-    const uint32_t* lst = BIG ? list : list + ph_list * g.pstride;
-    if (BIG) group = 1u;
+    const uint32_t ph_list = blockIdx.y;
+    const uint32_t nlist = ctr->n_listed[ph_list];
+    const uint32_t* lst = list + ph_list * g.pstride;
     group = min(max(group, 1u), (uint32_t)kMaxGroup);
     const uint32_t ngroups = (nlist + group - 1u) / group;
     for (uint32_t gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
@@ -775,7 +770,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
             uint32_t nbat = 0, nb = 0, np = 0;
             s_bfirst[0] = 0;
             for (uint32_t j = 0; j < cnt; ++j) {
-                if (j > s_bfirst[nbat] && (nb + s_tnb[j] > kMaxB || np + s_tnp[j] > (BIG ? MP : kBatchP))) {
+                if (j > s_bfirst[nbat] && (nb + s_tnb[j] > kMaxB || np + s_tnp[j] > kBatchP)) {
                     s_bfirst[++nbat] = j; nb = 0; np = 0;
                 }
                 nb += s_tnb[j]; np += s_tnp[j];
@@ -917,7 +912,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 const uint32_t lx = g.gxl - g.tlx;
                 const uint32_t ph = (t0 & 1u) | (((t0 >> lx) & 1u) << 1);
                 BatchDesc d;
-                d.first = BIG ? ((e0 + f) | 0x80000000u) : (e0 + f);
+                d.first = e0 + f;
                 d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nb; d.pad[0] = d.pad[1] = 0u;
                 const uint32_t bidx = atomicAdd(&ctr->n_batches[ph], 1u);
                 batches[ph * g.pstride + bidx] = d;
@@ -1006,7 +1001,7 @@ __global__ __launch_bounds__(kGlobalColorBlock) void k_color_global(GlobalColor 
         A.ctr->n_tile_pairs = total;
         A.ctr->n_pairs = total + ne;
         A.ctr->n_fb = ne;
-        A.ctr->n_active[0] = A.ctr->n_listed[0] + A.ctr->n_listed[1] + A.ctr->n_listed[2] + A.ctr->n_listed[3] + A.ctr->n_big;
+        A.ctr->n_active[0] = A.ctr->n_listed[0] + A.ctr->n_listed[1] + A.ctr->n_listed[2] + A.ctr->n_listed[3];
     }
     if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
     if (tid == 0) s_nleft = 0u;
@@ -1136,7 +1131,6 @@ struct TileArrays {
     const uint32_t* sorted_id;
     const uint32_t* tile_start;   // scanned pair counts
     const uint32_t* active;       // per phase tile lists
-    const uint32_t* big;          // tiles that are batches of their own
     const BatchDesc* batches;     // per phase batch tables
     const uint4* tpair;           // colour-major per batch
     const uint32_t* torder;       // narrowphase order: positions in tpair, per batch grouped by shape-pair class (kNoPair: skip)
