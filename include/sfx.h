@@ -243,8 +243,8 @@ int sfx_download_velocities(sfx_world* w, float* vel, float* angvel);
  * contract is DESIGN.md "Contract / spatial queries") -------------------------------------------
  * Queries see the colliders at their CURRENT poses.  The first query after a tick or an upload
  * sorts the colliders' tight AABBs (no margin, no velocity pad) into a grid index of its own
- * (same cell size as the tick's broadphase; allocated at the first query), later queries reuse
- * it.  A collider takes part when (category & mask) != 0.  Not allowed between sfx_tick_begin
+ * (same cell size as the tick's broadphase; allocated at the first query, like the transfer
+ * buffers, which grow on demand), later queries reuse it.  A collider takes part when (category & mask) != 0.  Not allowed between sfx_tick_begin
  * and the tick's last sfx_tick_substep.  Arrays are caller-owned host memory; the calls
  * synchronise. */
 /* point query: per point the lowest id of the bodies whose collider contains it (boundary

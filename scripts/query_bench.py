@@ -58,3 +58,18 @@ ob, oc = o.query_points(pts[:k])
 oh = o.query_rays(rays[:k], max_t[:k])
 print("sample parity: points", bool(np.array_equal(ob, body[:k]) and np.array_equal(oc, cnt[:k])),
       "rays", bool(np.array_equal(oh["body"], hits["body"][:k]) and np.array_equal(oh["t"], hits["t"][:k])))
+t0 = time.perf_counter()
+for k in range(200):
+    w.query_points(pts[k:k + 1])
+print(f"one point per call: {1e6 * (time.perf_counter() - t0) / 200:.1f} us per call (index already built)")
+t0 = time.perf_counter()
+for k in range(200):
+    w.step(bench.DT)
+    w.query_rays(rays[k:k + 1], max_t[k:k + 1])
+w.sync()
+t1 = time.perf_counter()
+for k in range(200):
+    w.step(bench.DT)
+    w.sync()
+t2 = time.perf_counter()
+print(f"one ray per tick (index rebuilt every time): {1e6 * ((t1 - t0) - (t2 - t1)) / 200:.1f} us on top of a synchronised tick")

@@ -93,6 +93,7 @@ struct sfx_world {
     uint32_t n_halo_send = 0, n_halo_recv = 0;
     // spatial query index (allocated at the first query; DESIGN.md "Contract / spatial queries")
     DevBuf<uint32_t> q_zero, q_bucket, q_cell_fill, q_tmp_id, q_sorted_id, q_large_tmp, q_bounds, q_nhits;
+    DevBuf<unsigned char> q_in, q_out;   // query transfer buffers, grown on demand and kept
     DevBuf<float4> q_aabb, q_sorted_aabb;
     DevBuf<int2> q_cellxy, q_sorted_cell;
     size_t q_zero_bytes = 0;
@@ -555,7 +556,7 @@ void sfx_destroy(sfx_world* w) {
     w->halo_send_idx.release(); w->halo_recv_idx.release(); w->halo_send.release(); w->halo_recv.release();
     w->q_zero.release(); w->q_bucket.release(); w->q_cell_fill.release(); w->q_tmp_id.release(); w->q_sorted_id.release();
     w->q_large_tmp.release(); w->q_bounds.release(); w->q_nhits.release(); w->q_aabb.release(); w->q_sorted_aabb.release();
-    w->q_cellxy.release(); w->q_sorted_cell.release();
+    w->q_cellxy.release(); w->q_sorted_cell.release(); w->q_in.release(); w->q_out.release();
     w->c_rec.release(); w->c_lam.release();
     w->j_bodies.release(); w->j_anchors.release(); w->j_params.release(); w->j_count_dev.release();
     if (w->h_ctr) (void)hipHostFree(w->h_ctr);
@@ -1071,6 +1072,13 @@ int ensure_query_index(sfx_world* w) {
     return SFX_OK;
 }
 
+// transfer buffers of the queries: grown when a call needs more, never shrunk
+int query_buffers(sfx_world* w, size_t in_bytes, size_t out_bytes) {
+    if (w->q_in.n < in_bytes) ALLOC(w, w->q_in, in_bytes + in_bytes / 2);
+    if (w->q_out.n < out_bytes) ALLOC(w, w->q_out, out_bytes + out_bytes / 2);
+    return SFX_OK;
+}
+
 QueryIndex query_index(sfx_world* w) {
     QueryIndex Q;
     Q.cell_start = w->q_zero.p + sizeof(Counters) / 4;
@@ -1088,17 +1096,17 @@ int sfx_query_points(sfx_world* w, uint32_t n, const float* points, uint32_t mas
     if (!w || (n && (!points || !body))) return fail(w, SFX_ERR_INVALID, "null argument");
     int rc = ensure_query_index(w);
     if (rc || n == 0) return rc;
-    DevBuf<float2> d_pts;
-    DevBuf<uint32_t> d_out;
-    ALLOC(w, d_pts, n); ALLOC(w, d_out, 2 * (size_t)n);
-    HIPCHK(w, hipMemcpyAsync(d_pts.p, points, sizeof(float2) * n, hipMemcpyHostToDevice, w->stream));
+    rc = query_buffers(w, sizeof(float2) * n, 2 * sizeof(uint32_t) * (size_t)n);
+    if (rc) return rc;
+    float2* d_pts = reinterpret_cast<float2*>(w->q_in.p);
+    uint32_t* d_out = reinterpret_cast<uint32_t*>(w->q_out.p);
+    HIPCHK(w, hipMemcpyAsync(d_pts, points, sizeof(float2) * n, hipMemcpyHostToDevice, w->stream));
     { Prof p(w, SFX_K_QUERY, n);
-      hipLaunchKernelGGL(k_query_points, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, w->stream, n, d_pts.p, mask, query_index(w),
-                         body_arrays(w), d_out.p, d_out.p + n); }
-    hipError_t e = hipMemcpyAsync(body, d_out.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, w->stream);
-    if (e == hipSuccess && count) e = hipMemcpyAsync(count, d_out.p + n, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, w->stream);
+      hipLaunchKernelGGL(k_query_points, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, w->stream, n, d_pts, mask, query_index(w),
+                         body_arrays(w), d_out, d_out + n); }
+    hipError_t e = hipMemcpyAsync(body, d_out, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, w->stream);
+    if (e == hipSuccess && count) e = hipMemcpyAsync(count, d_out + n, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, w->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
-    d_pts.release(); d_out.release();
     if (e != hipSuccess) return fail(w, SFX_ERR_DEVICE, "point query failed: %s", hipGetErrorString(e));
     return w->profiling ? collect_profile(w) : SFX_OK;
 }
@@ -1109,20 +1117,20 @@ int sfx_query_aabbs(sfx_world* w, uint32_t n, const float* boxes, uint32_t mask,
     int rc = ensure_query_index(w);
     if (rc || n == 0) return rc;
     const uint32_t dcap = (uint32_t)std::min<size_t>(cap, 0xFFFFFFF0u);
-    DevBuf<float4> d_box;
-    DevBuf<unsigned long long> d_hits;
-    ALLOC(w, d_box, n); ALLOC(w, d_hits, std::max<size_t>(dcap, 1));
-    HIPCHK(w, hipMemcpyAsync(d_box.p, boxes, sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
+    rc = query_buffers(w, sizeof(float4) * n, sizeof(unsigned long long) * std::max<size_t>(dcap, 1));
+    if (rc) return rc;
+    float4* d_box = reinterpret_cast<float4*>(w->q_in.p);
+    unsigned long long* d_hits = reinterpret_cast<unsigned long long*>(w->q_out.p);
+    HIPCHK(w, hipMemcpyAsync(d_box, boxes, sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
     HIPCHK(w, hipMemsetAsync(w->q_nhits.p, 0, sizeof(uint32_t), w->stream));
     { Prof p(w, SFX_K_QUERY, n);
-      hipLaunchKernelGGL(k_query_aabbs, dim3(std::min(cdiv(n, kBlock / 64), 4096u)), dim3(kBlock), 0, w->stream, n, d_box.p, mask,
-                         query_index(w), body_arrays(w), d_hits.p, dcap, w->q_nhits.p); }
+      hipLaunchKernelGGL(k_query_aabbs, dim3(std::min(cdiv(n, kBlock / 64), 4096u)), dim3(kBlock), 0, w->stream, n, d_box, mask,
+                         query_index(w), body_arrays(w), d_hits, dcap, w->q_nhits.p); }
     uint32_t total = 0;
     hipError_t e = hipMemcpyAsync(&total, w->q_nhits.p, sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
     const size_t got = std::min<size_t>(total, dcap);
-    if (e == hipSuccess && got) e = hipMemcpy(hits, d_hits.p, sizeof(uint64_t) * got, hipMemcpyDeviceToHost);
-    d_box.release(); d_hits.release();
+    if (e == hipSuccess && got) e = hipMemcpy(hits, d_hits, sizeof(uint64_t) * got, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(w, SFX_ERR_DEVICE, "box query failed: %s", hipGetErrorString(e));
     std::sort(hits, hits + got);
     *n_hits = total;
@@ -1135,18 +1143,18 @@ int sfx_query_rays(sfx_world* w, uint32_t n, const float* rays, const float* max
     if (!w || (n && (!rays || !max_t || !hits))) return fail(w, SFX_ERR_INVALID, "null argument");
     int rc = ensure_query_index(w);
     if (rc || n == 0) return rc;
-    DevBuf<float4> d_rays;
-    DevBuf<float> d_mt;
-    DevBuf<sfx_ray_hit> d_out;
-    ALLOC(w, d_rays, n); ALLOC(w, d_mt, n); ALLOC(w, d_out, n);
-    HIPCHK(w, hipMemcpyAsync(d_rays.p, rays, sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
-    HIPCHK(w, hipMemcpyAsync(d_mt.p, max_t, sizeof(float) * n, hipMemcpyHostToDevice, w->stream));
+    rc = query_buffers(w, (sizeof(float4) + sizeof(float)) * (size_t)n, sizeof(sfx_ray_hit) * (size_t)n);
+    if (rc) return rc;
+    float4* d_rays = reinterpret_cast<float4*>(w->q_in.p);
+    float* d_mt = reinterpret_cast<float*>(d_rays + n);
+    sfx_ray_hit* d_out = reinterpret_cast<sfx_ray_hit*>(w->q_out.p);
+    HIPCHK(w, hipMemcpyAsync(d_rays, rays, sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipMemcpyAsync(d_mt, max_t, sizeof(float) * n, hipMemcpyHostToDevice, w->stream));
     { Prof p(w, SFX_K_QUERY, n);
-      hipLaunchKernelGGL(k_query_rays, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, w->stream, n, d_rays.p, d_mt.p, mask, query_index(w),
-                         body_arrays(w), d_out.p); }
-    hipError_t e = hipMemcpyAsync(hits, d_out.p, sizeof(sfx_ray_hit) * n, hipMemcpyDeviceToHost, w->stream);
+      hipLaunchKernelGGL(k_query_rays, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, w->stream, n, d_rays, d_mt, mask, query_index(w),
+                         body_arrays(w), d_out); }
+    hipError_t e = hipMemcpyAsync(hits, d_out, sizeof(sfx_ray_hit) * n, hipMemcpyDeviceToHost, w->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
-    d_rays.release(); d_mt.release(); d_out.release();
     if (e != hipSuccess) return fail(w, SFX_ERR_DEVICE, "ray query failed: %s", hipGetErrorString(e));
     return w->profiling ? collect_profile(w) : SFX_OK;
 }
