@@ -67,7 +67,7 @@ struct Counters {
     uint32_t n_active[4];   // [0]: tiles that own pairs (statistic), rest unused
     uint32_t ticket;        // last-workgroup detection of the phase-3 kernels
     uint32_t n_over_tiles;  // tiles that handed their pairs to the fallback list
-    uint32_t pad4;
+    uint32_t body_cursor;   // entries written to the batches' body lists
     uint32_t tp_cursor;     // pairs written to the batch-ordered pair list
     uint32_t n_batches[4];  // batches per phase
     uint32_t n_listed[4];   // tiles on the per-phase lists
@@ -633,7 +633,8 @@ struct BatchDesc {
     uint32_t np;       // pairs within reach: the ones the solves take (the others follow them in tpair)
     uint32_t ncol;     // most colours of any of its tiles
     uint32_t nb;       // bodies of all its blocks
-    uint32_t pad[2];
+    uint32_t boff;     // first entry of its body list (body ids in local-index order)
+    uint32_t pad;
 };
 
 // body ranges of a batch in LDS: range r = 4 * (tile in batch) + (block tile 0..3)
@@ -724,6 +725,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                                                          uint4* __restrict__ tpair, BatchDesc* __restrict__ batches,
                                                          const float4* __restrict__ shape, uint32_t* __restrict__ torder,
                                                          uint32_t* __restrict__ tile_batch,
+                                                         uint32_t* __restrict__ bbody, uint32_t bbody_cap,
                                                          uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr,
                                                          unsigned long long* __restrict__ dbg) {
     struct { unsigned long long* dbg; } T = {dbg};  // for the stage-timing macros
@@ -744,7 +746,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
     __shared__ uint32_t s_hist[SFX_MAX_COLORS], s_base[SFX_MAX_COLORS];
     __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat, s_npruned, s_ptail, s_ptail_first;
     __shared__ uint32_t s_cls[4];
-    __shared__ uint32_t s_bidx;
+    __shared__ uint32_t s_bidx, s_boff;
     __shared__ BatchRanges S;
     __shared__ uint32_t s_tile[kMaxGroup], s_tnb[kMaxGroup], s_tnp[kMaxGroup], s_tstart[kMaxGroup];
     __shared__ uint32_t s_bfirst[kMaxGroup + 1], s_poff[kMaxGroup + 1];
@@ -789,6 +791,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 for (uint32_t j = 0; j < c; ++j) { s_poff[j] = run; run += s_tnp[f + j]; }
                 s_poff[c] = run;
                 s_nleft = 0u; s_ovf = 0u; s_npruned = 0u;
+                s_boff = atomicAdd(&ctr->body_cursor, min(S.off[4u * c], MB));  // the batch's body list (never more than 4 per collider in all)
             }
             if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
             if (tid < 4) s_cls[tid] = 0u;
@@ -796,11 +799,13 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
             const uint32_t nb = min(S.off[4u * c], MB), np = min(s_poff[c], MP);
             for (uint32_t l = tid; l < nb; l += kBlock) {
                 const uint32_t gid = sorted_id[batch_slot(S, 4u * c, l)];
+                if (s_boff + l < bbody_cap) bbody[s_boff + l] = gid;  // the tile solves load their bodies from this list
                 s_dyn[l] = (uint8_t)(filt[gid].w != 0u);
                 s_used[l] = 0ull;
 #pragma unroll
                 for (int k = 0; k < kClaim; ++k) s_claim[l * kClaim + k] = ~0ull;
             }
+            int open_edges = 0;
             for (uint32_t e = tid; e < np; e += kBlock) {
                 uint32_t j = 0;
                 while (j + 1 < c && s_poff[j + 1] <= e) ++j;
@@ -812,15 +817,13 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 const bool keep = !(rp.z & kOutOfReach);
                 s_col[e] = keep ? SFX_NO_COLOR : SFX_PRUNED_COLOR;
                 if (!keep) atomicAdd(&s_npruned, 1u);
+                open_edges |= keep ? 1 : 0;
             }
-            __syncthreads();
+            int any_open = __syncthreads_or(open_edges);
             SFX_TT(tc1);
 #define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
-            for (uint32_t r = 0; r < rounds; ++r) {
+            for (uint32_t r = 0; r < rounds && any_open; ++r) {  // everything coloured: later rounds would do nothing
                 SFX_TT_ADD(98, 0ull, 1ull);
-                int open_edges = 0;
-                for (uint32_t e = tid; e < np; e += kBlock) open_edges |= (s_col[e] == SFX_NO_COLOR) ? 1 : 0;
-                if (!__syncthreads_or(open_edges)) break;  // everything coloured: later rounds would do nothing
                 for (uint32_t e = tid; e < np; e += kBlock) {  // propose
                     if (s_col[e] != SFX_NO_COLOR) continue;
                     const uint32_t la = s_la[e], lb = s_lb[e];
@@ -835,10 +838,11 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                     if (db) atomicMin(&s_claim[lb * kClaim + (cc & (kClaim - 1u))], p);
                 }
                 __syncthreads();
+                open_edges = 0;
                 for (uint32_t e = tid; e < np; e += kBlock) {  // resolve
                     if (s_col[e] != SFX_NO_COLOR) continue;
                     const uint32_t cc = s_prop[e];
-                    if (cc == SFX_NO_COLOR) continue;
+                    if (cc == SFX_NO_COLOR) { open_edges = 1; continue; }
                     const uint32_t la = s_la[e], lb = s_lb[e];
                     const bool da = TDYN(la), db = TDYN(lb);
                     const uint32_t h = edge_hash(s_a[e], s_b[e], r);
@@ -849,9 +853,11 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                         s_col[e] = (uint8_t)cc;
                         if (da) atomicOr(&s_used[la], 1ull << cc);
                         if (db) atomicOr(&s_used[lb], 1ull << cc);
+                    } else {
+                        open_edges = 1;
                     }
                 }
-                __syncthreads();
+                any_open = __syncthreads_or(open_edges);
             }
             SFX_TT(tc2);
             // serial first-fit finish over the leftovers, ascending key
@@ -894,13 +900,15 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 if (cc < SFX_MAX_COLORS) atomicAdd(&s_hist[cc], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                uint32_t run = 0, nc = 0;
-                for (uint32_t cc = 0; cc < SFX_MAX_COLORS; ++cc) {
-                    s_base[cc] = run;
-                    if (s_hist[cc]) nc = cc + 1;
-                    run += s_hist[cc];
-                }
+            if (tid < 64u) {  // the first wave: exclusive scan of the colour histogram with shuffles
+                static_assert(SFX_MAX_COLORS == 64, "one lane per colour");
+                const uint32_t hc = s_hist[tid];
+                const uint32_t inc = wave_inclusive_scan(hc);
+                s_base[tid] = inc - hc;
+                const uint64_t usedc = __ballot(hc != 0u);
+                const uint32_t nc = usedc ? 64u - (uint32_t)__builtin_clzll(usedc) : 0u;
+                const uint32_t run = (uint32_t)__shfl((int)inc, 63, 64);
+              if (tid == 0) {
                 s_nleft = run;  // reused: cursor of the uncoloured tail
                 const uint32_t kept = np - s_npruned;
                 s_ptail = kept;  // cursor of the pruned pairs behind them
@@ -913,12 +921,13 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 const uint32_t ph = (t0 & 1u) | (((t0 >> lx) & 1u) << 1);
                 BatchDesc d;
                 d.first = e0 + f;
-                d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nb; d.pad[0] = d.pad[1] = 0u;
+                d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nb; d.boff = s_boff; d.pad = 0u;
                 const uint32_t bidx = atomicAdd(&ctr->n_batches[ph], 1u);
                 batches[ph * g.pstride + bidx] = d;
                 s_bidx = bidx;
                 atomicMax(&ctr->n_colors, nc);
                 if (s_ovf) atomicOr(&ctr->overflow, kOvfColors);
+              }
             }
             if (tid < SFX_MAX_COLORS && s_hist[tid]) atomicAdd(&ctr->color_count[tid], s_hist[tid]);
             __syncthreads();
@@ -1134,6 +1143,7 @@ struct TileArrays {
     const BatchDesc* batches;     // per phase batch tables
     const uint4* tpair;           // colour-major per batch
     const uint32_t* torder;       // narrowphase order: positions in tpair, per batch grouped by shape-pair class (kNoPair: skip)
+    const uint32_t* bbody;        // per batch (BatchDesc.boff): body ids in local-index order
     const uint32_t* tile_batch;   // per tile: 1 + index of its batch on its phase's table (0: none this tick)
     uint32_t* done;               // per batch slot: epoch of the last fused launch that finished it
     const uint2* fsorted;         // fallback list, colour-major
@@ -1469,7 +1479,6 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
     __shared__ float2 s_mass[kMaxB];
     __shared__ uint32_t s_gid[kMaxB];
     __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
-    __shared__ BatchRanges S;
     const uint32_t tid = threadIdx.x;
     const __amdgpu_buffer_rsrc_t pose_rs = record_rsrc(B.pose);
     const uint32_t nitems = phase_total(ctr, ph0, nph);
@@ -1482,10 +1491,10 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
         SFX_TT(ttw);
         SFX_TT_ADD(6, tt0, ttw);
-        batch_ranges(tiles, d.count, g, T.cell_start, S);
         const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
+        __syncthreads();  // the previous batch's write-back has read the LDS arrays
         for (uint32_t l = tid; l < nb; l += NT) {
-            const uint32_t gid = T.sorted_id[batch_slot(S, 4u * d.count, l)];
+            const uint32_t gid = T.bbody[d.boff + l];
             s_gid[l] = gid;
             s_pose[l] = B.pose[gid];
             s_mass[l] = B.mass[gid];
@@ -1560,7 +1569,6 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
     __shared__ uint32_t s_gid[kMaxB];
     __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
     __shared__ uint32_t s_shift;
-    __shared__ BatchRanges S;
     const uint32_t tid = threadIdx.x;
 #ifdef SFX_TILE_TIMING
     if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[48 + 2 * (epoch & 15u)], ~wall_clock64());   // earliest kernel entry
@@ -1575,12 +1583,12 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         SFX_TT(tv0);
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
         SFX_TT(tvw);
-        batch_ranges(tiles, d.count, g, T.cell_start, S);
         const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
+        __syncthreads();  // the previous batch's write-back has read the LDS arrays
         if (tid == 0) s_shift = 0u;
         if (tid < SFX_MAX_COLORS) { s_cs[tid] = 0u; s_ce[tid] = 0u; }
         for (uint32_t l = tid; l < nb; l += NT) {
-            const uint32_t gid = T.sorted_id[batch_slot(S, 4u * d.count, l)];
+            const uint32_t gid = T.bbody[d.boff + l];
             s_gid[l] = gid;
             s_pose[l] = B.pose[gid];
             s_vel[l] = B.vel[gid];
