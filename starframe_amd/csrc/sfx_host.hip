@@ -71,7 +71,7 @@ struct sfx_world {
     size_t zero_bytes = 0;
     DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, scan_sums, active;
     DevBuf<BatchDesc> batches;
-    DevBuf<uint32_t> torder, done, bbody;
+    DevBuf<uint32_t> torder, done, bbody, bruns;
     uint32_t epoch = 0;            // one per fused multi-phase launch; never reset, so T.done needs no clearing
     // workgroups of the solve kernels the device holds at once, per workgroup size variant (512, 256 threads)
     uint32_t resident_pos_v[2] = {0, 0}, resident_vel_v[2] = {0, 0};
@@ -341,7 +341,7 @@ uint32_t edge_grid(uint32_t cap) { return std::min(std::max(cdiv(cap, kBlock), 1
 TileArrays tile_arrays(sfx_world* w) {
     TileArrays T;
     T.cell_start = w->cell_start; T.sorted_id = w->sorted_id.p; T.tile_start = w->tile_cnt;
-    T.active = w->active.p; T.batches = w->batches.p; T.tpair = w->tpair.p; T.torder = w->torder.p; T.bbody = w->bbody.p; T.tile_batch = w->tile_batch; T.done = w->done.p; T.fsorted = w->fsorted.p;
+    T.active = w->active.p; T.batches = w->batches.p; T.tpair = w->tpair.p; T.torder = w->torder.p; T.bbody = w->bbody.p; T.bruns = w->bruns.p; T.tile_batch = w->tile_batch; T.done = w->done.p; T.fsorted = w->fsorted.p;
     T.max_pairs = w->max_pairs; T.fb_cap = w->fb_cap;
     T.dbg = w->dbg.p;
     return T;
@@ -406,7 +406,7 @@ int broadphase(sfx_world* w, float dt) {
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
       hipLaunchKernelGGL(k_batch_color<kBatchP>, dim3(w->color_grid, 4), dim3(512), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
-                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->bbody.p, (uint32_t)w->bbody.n, w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
+                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->bbody.p, (uint32_t)w->bbody.n, w->bruns.p, w->ntiles, w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
     return SFX_OK;
@@ -547,7 +547,7 @@ void sfx_destroy(sfx_world* w) {
     w->pose.release(); w->prev.release(); w->vel.release(); w->shape.release(); w->poly.release();
     w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release();
     w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
-    w->active.release(); w->batches.release(); w->torder.release(); w->done.release(); w->bbody.release(); w->rawp.release(); w->tpair.release();
+    w->active.release(); w->batches.release(); w->torder.release(); w->done.release(); w->bbody.release(); w->bruns.release(); w->rawp.release(); w->tpair.release();
     w->fpairs.release(); w->fsorted.release(); w->hit_tmp.release();
     w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->scan_sums.release();
     w->cellxy.release(); w->sorted_cell.release();
@@ -701,6 +701,7 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     ALLOC(w, w->active, 2 * (size_t)w->ntiles); ALLOC(w, w->batches, 2 * (size_t)w->ntiles);
     ALLOC(w, w->rawp, w->max_pairs); ALLOC(w, w->tpair, w->max_pairs); ALLOC(w, w->torder, w->max_pairs);
     ALLOC(w, w->done, 2 * (size_t)w->ntiles);
+    ALLOC(w, w->bruns, 64 * (size_t)w->ntiles);  // a batch holds at least one tile
     ALLOC(w, w->bbody, 4 * (size_t)n + 16);  // a collider lies in at most four tile blocks
     HIPCHK(w, hipMemset(w->done.p, 0, sizeof(uint32_t) * 2 * (size_t)w->ntiles));
     ALLOC(w, w->fpairs, w->fb_cap); ALLOC(w, w->fsorted, w->fb_cap);

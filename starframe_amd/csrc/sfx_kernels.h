@@ -74,7 +74,8 @@ struct Counters {
     uint32_t color_count[SFX_MAX_COLORS];
     uint32_t fb_start[SFX_MAX_COLORS + 1];  // colour-major offsets into the sorted fallback list
     uint32_t n_kept;        // tile pairs within reach (the solves' pairs; the fallback list is not tested)
-    uint32_t pad3[2];
+    uint32_t run_cursor;    // batches that have written their colour run table
+    uint32_t pad3[1];
 };
 static_assert(sizeof(Counters) % 16 == 0, "the per-tick block is cleared in 16-byte units");
 
@@ -634,7 +635,7 @@ struct BatchDesc {
     uint32_t ncol;     // most colours of any of its tiles
     uint32_t nb;       // bodies of all its blocks
     uint32_t boff;     // first entry of its body list (body ids in local-index order)
-    uint32_t pad;
+    uint32_t roff;     // its colour run table: bruns[64 * roff + c] = first | end << 16 of colour c in its pair list
 };
 
 // body ranges of a batch in LDS: range r = 4 * (tile in batch) + (block tile 0..3)
@@ -726,6 +727,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                                                          const float4* __restrict__ shape, uint32_t* __restrict__ torder,
                                                          uint32_t* __restrict__ tile_batch,
                                                          uint32_t* __restrict__ bbody, uint32_t bbody_cap,
+                                                         uint32_t* __restrict__ bruns, uint32_t bruns_cap,
                                                          uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr,
                                                          unsigned long long* __restrict__ dbg) {
     struct { unsigned long long* dbg; } T = {dbg};  // for the stage-timing macros
@@ -908,6 +910,10 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 const uint64_t usedc = __ballot(hc != 0u);
                 const uint32_t nc = usedc ? 64u - (uint32_t)__builtin_clzll(usedc) : 0u;
                 const uint32_t run = (uint32_t)__shfl((int)inc, 63, 64);
+                uint32_t roff = 0u;
+                if (tid == 0) roff = atomicAdd(&ctr->run_cursor, 1u);
+                roff = (uint32_t)__shfl((int)roff, 0, 64);
+                if (roff < bruns_cap) bruns[64u * roff + tid] = (inc - hc) | (inc << 16);  // what the tile solves loop over
               if (tid == 0) {
                 s_nleft = run;  // reused: cursor of the uncoloured tail
                 const uint32_t kept = np - s_npruned;
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
                 const uint32_t ph = (t0 & 1u) | (((t0 >> lx) & 1u) << 1);
                 BatchDesc d;
                 d.first = e0 + f;
-                d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nb; d.boff = s_boff; d.pad = 0u;
+                d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nb; d.boff = s_boff; d.roff = roff;
                 const uint32_t bidx = atomicAdd(&ctr->n_batches[ph], 1u);
                 batches[ph * g.pstride + bidx] = d;
                 s_bidx = bidx;
@@ -1144,6 +1150,7 @@ struct TileArrays {
     const uint4* tpair;           // colour-major per batch
     const uint32_t* torder;       // narrowphase order: positions in tpair, per batch grouped by shape-pair class (kNoPair: skip)
     const uint32_t* bbody;        // per batch (BatchDesc.boff): body ids in local-index order
+    const uint32_t* bruns;        // per batch (BatchDesc.roff): 64 colour runs, first | end << 16
     const uint32_t* tile_batch;   // per tile: 1 + index of its batch on its phase's table (0: none this tick)
     uint32_t* done;               // per batch slot: epoch of the last fused launch that finished it
     const uint2* fsorted;         // fallback list, colour-major
@@ -1363,18 +1370,6 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// runs of equal colour in the colour-sorted pair list of a batch -> s_cs / s_ce (LDS, zeroed)
-template <int NT>
-__device__ __forceinline__ void colour_runs(const uint4* __restrict__ tpair, uint32_t start, uint32_t np,
-                                            uint32_t* s_cs, uint32_t* s_ce) {
-    for (uint32_t k = threadIdx.x; k < np; k += NT) {
-        const uint32_t c = tpair[start + k].w & 0xFFu;
-        if (c >= SFX_MAX_COLORS) continue;
-        if (k == 0 || (tpair[start + k - 1].w & 0xFFu) != c) s_cs[c] = k;
-        if (k + 1 == np || (tpair[start + k + 1].w & 0xFFu) != c) s_ce[c] = k + 1;
-    }
-}
-
 // Several phases in ONE launch (nph > 1): the workgroups take the batches of the phases
 // ph0 .. ph0 + nph - 1 in that order (item I = batches of the earlier phases + index); a batch
 // of a later phase waits until the batches of earlier phases whose blocks overlap its own have
@@ -1491,7 +1486,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
         SFX_TT(ttw);
         SFX_TT_ADD(6, tt0, ttw);
-        const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
+        const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, ncol = d.ncol;
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
         for (uint32_t l = tid; l < nb; l += NT) {
             const uint32_t gid = T.bbody[d.boff + l];
@@ -1499,11 +1494,12 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
             s_pose[l] = B.pose[gid];
             s_mass[l] = B.mass[gid];
         }
-        if (tid < SFX_MAX_COLORS) { s_cs[tid] = 0u; s_ce[tid] = 0u; }
+        if (tid < SFX_MAX_COLORS) {  // the colour runs of the batch's pair list, tabulated by k_batch_color
+            const uint32_t v = T.bruns[64u * d.roff + tid];
+            s_cs[tid] = v & 0xFFFFu; s_ce[tid] = v >> 16;
+        }
         __syncthreads();
         SFX_TT(tt1);
-        colour_runs<NT>(T.tpair, start, np, s_cs, s_ce);
-        __syncthreads();
         SFX_TT(tt2);
         auto solve = [&](uint32_t slot, PairSlot& p) {
             const PairEnds& e = p.e;
@@ -1583,10 +1579,13 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         SFX_TT(tv0);
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
         SFX_TT(tvw);
-        const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, np = d.np, ncol = d.ncol;
+        const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, ncol = d.ncol;
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
         if (tid == 0) s_shift = 0u;
-        if (tid < SFX_MAX_COLORS) { s_cs[tid] = 0u; s_ce[tid] = 0u; }
+        if (tid < SFX_MAX_COLORS) {
+            const uint32_t v = T.bruns[64u * d.roff + tid];
+            s_cs[tid] = v & 0xFFFFu; s_ce[tid] = v >> 16;
+        }
         for (uint32_t l = tid; l < nb; l += NT) {
             const uint32_t gid = T.bbody[d.boff + l];
             s_gid[l] = gid;
@@ -1594,8 +1593,6 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
             s_vel[l] = B.vel[gid];
             s_mass[l] = B.mass[gid];
         }
-        __syncthreads();
-        colour_runs<NT>(T.tpair, start, np, s_cs, s_ce);
         __syncthreads();
         SFX_TT(tv1);
         auto solve = [&](const PairSlot& p) {
