@@ -784,7 +784,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
         }
         __syncthreads();
         const uint32_t nbat = s_nbat;
-        for (uint32_t bi = 0; bi < nbat; ++bi) {
+        for (uint32_t bi = blockIdx.z; bi < nbat; bi += gridDim.z) {  // the batches of a group are coloured side by side
             const uint32_t f = s_bfirst[bi], c = s_bfirst[bi + 1] - f;
             SFX_TT(tc0);
             batch_ranges(lst + e0 + f, c, g, cell_start, S);
