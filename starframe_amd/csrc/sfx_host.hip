@@ -404,7 +404,7 @@ int broadphase(sfx_world* w, float dt) {
       hipLaunchKernelGGL(k_reach, dim3(cdiv(std::min(est, w->max_pairs), kBlock)), dim3(kBlock), 0, w->stream, w->tile_cnt,
                          w->ntiles, w->max_pairs, w->rawp.p, w->shape.p, RP); }
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
-      hipLaunchKernelGGL(k_batch_color<kBatchP>, dim3(w->color_grid, (w->tly == w->gyl) ? 2u : 4u, w->group > 1u ? 2u : 1u), dim3(512), 0, w->stream, g, w->group,
+      hipLaunchKernelGGL(k_batch_color<kBatchP>, dim3(w->color_grid, (w->tly == w->gyl) ? 2u : 4u, w->group > 1u ? 2u : 1u), dim3(kColorThreads), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
                          w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->bbody.p, (uint32_t)w->bbody.n, w->bruns.p, w->ntiles, w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);

@@ -717,8 +717,12 @@ __global__ __launch_bounds__(kBlock) void k_reach(const uint32_t* __restrict__ t
 // behind the batch's pairs with SFX_PRUNED_COLOR.  A workgroup takes `group` consecutive tiles of a phase's list and
 // cuts them greedily into batches of at most kBatchP pairs and kMaxB bodies.  Per batch it writes the pairs colour-major as
 // (id a, id b, local a | local b << 16, colour | tile << 8) and a BatchDesc on the phase's table.
+#ifndef SFX_COLOR_THREADS
+#define SFX_COLOR_THREADS 512
+#endif
+constexpr int kColorThreads = SFX_COLOR_THREADS;
 template <uint32_t MP>
-__global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t group, const uint32_t* __restrict__ cell_start,
+__global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uint32_t group, const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ sorted_id,
                                                          const uint4* __restrict__ filt,
                                                          const uint32_t* __restrict__ tile_start,
@@ -733,7 +737,7 @@ __global__ __launch_bounds__(512) void k_batch_color(GridParams g, uint32_t grou
     struct { unsigned long long* dbg; } T = {dbg};  // for the stage-timing macros
     (void)T;
     constexpr uint32_t MB = kMaxB;
-    constexpr uint32_t kBlock = 512;  // shadows the file-level constant: this kernel runs 512 threads
+    constexpr uint32_t kBlock = kColorThreads;  // shadows the file-level constant
     __shared__ unsigned long long s_used[MB];
     __shared__ unsigned long long s_claim[MB * kClaim];
     __shared__ uint8_t s_dyn[MB];
