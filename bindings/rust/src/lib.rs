@@ -58,7 +58,18 @@ pub struct sfx_distance_constraint {
     pub rest_length: f32,
     pub compliance: f32,
     pub limit: u32,    // SFX_LIMIT_*: 0 both ways, 1 rope (only pulls), 2 strut (only pushes)
-    pub reserved: u32,
+    pub damping: f32,  // 1/s, two-sided constraints only
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct sfx_angle_constraint {
+    pub body_a: u32,
+    pub body_b: u32,
+    pub min_angle: f32, // -pi < min <= max < pi, relative angle b - a
+    pub max_angle: f32,
+    pub compliance: f32,
+    pub damping: f32,
 }
 
 #[repr(C)]
@@ -66,7 +77,7 @@ pub struct sfx_world {
     _private: [u8; 0],
 }
 
-pub const SFX_ABI_VERSION: u32 = 5;
+pub const SFX_ABI_VERSION: u32 = 7;
 pub const SFX_OK: c_int = 0;
 pub const SFX_WORLD_BODY: u32 = 0xFFFF_FFFF;
 
@@ -90,6 +101,9 @@ extern "C" {
                                 n_poly_verts: u32) -> c_int;
     pub fn sfx_upload_materials(w: *mut sfx_world, n: u32, m: *const sfx_material) -> c_int;
     pub fn sfx_upload_constraints(w: *mut sfx_world, m: u32, c: *const sfx_distance_constraint) -> c_int;
+    pub fn sfx_readback_begin(w: *mut sfx_world) -> c_int;
+    pub fn sfx_readback_wait(w: *mut sfx_world, poses: *mut *const f32, n: *mut u32) -> c_int;
+    pub fn sfx_upload_angle_constraints(w: *mut sfx_world, m: u32, c: *const sfx_angle_constraint) -> c_int;
     pub fn sfx_step(w: *mut sfx_world, frame_dt: f32) -> c_int;
     pub fn sfx_sync(w: *mut sfx_world) -> c_int;
     pub fn sfx_abi_version() -> u32;

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 6u
+#define SFX_ABI_VERSION 7u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -110,8 +110,10 @@ typedef struct sfx_material {
     float dynamic_friction;
 } sfx_material;
 
-/* distance constraint between two anchors (BASELINE.json:10 "distance-constrained links").
- * limit makes it one-sided (SURVEY.md section 8f rank 2 "limits"; a rope link only pulls) */
+/* distance constraint between two anchors (BASELINE.json:10 "distance-constrained links";
+ * SURVEY.md section 8f rank 2 "attachment with offset anchors, compliance + damping, limits").
+ * rest_length = 0 makes it an attachment (the two anchors are held together: a pin / revolute
+ * joint).  limit makes it one-sided (a rope link only pulls). */
 #define SFX_LIMIT_NONE 0u   /* holds the rest length both ways                           */
 #define SFX_LIMIT_ROPE 1u   /* acts only while the anchors are further apart than rest   */
 #define SFX_LIMIT_STRUT 2u  /* acts only while they are closer than rest                 */
@@ -123,8 +125,26 @@ typedef struct sfx_distance_constraint {
     float rest_length;
     float compliance;    /* XPBD alpha (m/N); 0 = rigid                           */
     uint32_t limit;      /* SFX_LIMIT_*                                           */
-    uint32_t reserved;   /* 0                                                     */
+    float damping;       /* 1/s, >= 0: every substep the velocity pass removes the fraction
+                            min(damping * h, 1) of the anchors' relative velocity -- along the
+                            link for a link, all of it for an attachment (rest_length == 0)
+                            (Mueller et al. 2020 sec. 3.3.1).  Two-sided constraints only:
+                            must be 0 with SFX_LIMIT_ROPE / SFX_LIMIT_STRUT               */
 } sfx_distance_constraint;
+
+/* angle constraint (SURVEY.md section 8f rank 2 "angular limits"): keeps the relative angle
+ * phi = angle(b) - angle(a), measured in (-pi, pi], inside [min_angle, max_angle].  min == max
+ * holds one relative angle (with compliance: a torsion spring); together with an attachment it
+ * makes a hinge with stops.  damping acts on the relative angular velocity at all times (a hinge
+ * damper). */
+typedef struct sfx_angle_constraint {
+    uint32_t body_a;     /* body index or SFX_WORLD_BODY (angle 0)                */
+    uint32_t body_b;
+    float min_angle;     /* radians, -pi < min_angle <= max_angle < pi            */
+    float max_angle;
+    float compliance;    /* rad / (N m); 0 = rigid                                */
+    float damping;       /* 1/s, >= 0                                             */
+} sfx_angle_constraint;
 
 /* one narrowphase manifold, as returned by sfx_debug_contacts */
 typedef struct sfx_contact {
@@ -201,7 +221,11 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
 int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* colliders,
                          const float* poly_verts, uint32_t n_poly_verts);
 int sfx_upload_materials(sfx_world* w, uint32_t n, const sfx_material* materials);
+/* the two constraint arrays are independent: uploading one keeps the other.  Together they form
+ * one joint list (distance constraints first, then angle constraints), coloured at upload and
+ * solved colour by colour before the contacts of every substep */
 int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constraint* c);
+int sfx_upload_angle_constraints(sfx_world* w, uint32_t m, const sfx_angle_constraint* c);
 
 /* ---- the tick (BASELINE.json:5 "the per-frame tick entry point") ---------- */
 /* One frame: broadphase + colouring once, then `substeps` x (integrate, narrowphase, position
@@ -237,6 +261,18 @@ int sfx_halo_copy(sfx_world* dst, uint32_t dst_first, sfx_world* src, uint32_t s
 
 int sfx_download_poses(sfx_world* w, float* pos, float* rot);
 int sfx_download_velocities(sfx_world* w, float* vel, float* angvel);
+
+/* ---- pose read-back for rendering ("double-buffered async D2H so the
+ * sandbox can draw GPU-simulated scenes"; the reference draws from its own CPU state, so there is no
+ * counterpart to cite) ------------------------------------------------------------------------------
+ * sfx_readback_begin snapshots the poses as they are after everything enqueued so far (a device copy in
+ * stream order) and starts their transfer into library-owned pinned host memory on a second stream; it
+ * returns at once, and the next sfx_step overlaps the transfer.  sfx_readback_wait blocks until the OLDEST
+ * read-back begun has landed and returns it: poses = [n][4] floats (x, y, cos, sin), valid until the
+ * second sfx_readback_begin after the one it belongs to (the two slots alternate).  At most two read-backs are in flight (a frame loop is
+ * begin(k); step(k+1); wait(k); draw).  Buffers are allocated at the first begin. */
+int sfx_readback_begin(sfx_world* w);
+int sfx_readback_wait(sfx_world* w, const float** poses, uint32_t* n);
 
 /* ---- spatial queries over the device grid ("ray cast,
  * point/AABB query -- upstream's mouse-pick/raycast API"; the reference source is absent, so the
@@ -274,7 +310,8 @@ int sfx_debug_pair_colors(sfx_world* w, uint64_t* keys, uint8_t* colors, uint32_
 int sfx_debug_broadphase(sfx_world* w, float frame_dt);
 /* narrowphase of every candidate pair at the current poses, in sfx_debug_pairs order */
 int sfx_debug_contacts(sfx_world* w, sfx_contact* out, size_t cap, size_t* n);
-/* joint order after colouring: perm[k] = index into the uploaded constraint array */
+/* joint order after colouring: perm[k] = index into the joint list (distance constraints, then
+ * angle constraints) */
 int sfx_debug_joint_order(sfx_world* w, uint32_t* perm, uint8_t* colors, size_t cap, size_t* n);
 
 /* ---- reporting ------------------------------------------------------------ */

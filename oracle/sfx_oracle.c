@@ -58,7 +58,9 @@ struct sfo_world {
     uint32_t n_mats;
     /* joints */
     uint32_t m;
-    sfx_distance_constraint* joints;
+    sfx_distance_constraint* joints; /* m_dist of them; the joint list is these, then the angle constraints */
+    sfx_angle_constraint* angles;
+    uint32_t m_dist, m_angle;
     uint32_t* joint_perm; /* colour-major order */
     uint8_t* joint_color;
     uint32_t n_joint_colors;
@@ -118,7 +120,7 @@ void sfo_destroy(sfo_world* w) {
     if (!w) return;
     free(w->pos); free(w->rot); free(w->vel); free(w->angvel); free(w->inv_mass);
     free(w->inv_inertia); free(w->prev_pos); free(w->prev_rot); free(w->col); free(w->poly);
-    free(w->poly_nrm); free(w->mats); free(w->joints); free(w->joint_perm); free(w->joint_color);
+    free(w->poly_nrm); free(w->mats); free(w->joints); free(w->angles); free(w->joint_perm); free(w->joint_color);
     free(w->aabb); free(w->pa); free(w->pb); free(w->color); free(w->order); free(w->rec);
     free(w->ccx); free(w->ccy); free(w->is_small); free(w->owner); free(w->batch_end);
     free(w);
@@ -417,11 +419,12 @@ static uint32_t color_edges(color_scratch* cs, uint32_t ne, const uint32_t* idx,
     return nc;
 }
 
-int sfo_upload_constraints(sfo_world* w, uint32_t m, const sfx_distance_constraint* c) {
-    free(w->joints); free(w->joint_perm); free(w->joint_color);
+/* colours the joint list = distance constraints, then angle constraints (sfx.h), keyed by the
+ * index in that list */
+static int rebuild_joints(sfo_world* w) {
+    uint32_t md = w->m_dist, m = md + w->m_angle;
+    free(w->joint_perm); free(w->joint_color);
     w->m = m;
-    w->joints = (sfx_distance_constraint*)malloc((m ? m : 1) * sizeof(*c));
-    memcpy(w->joints, c, m * sizeof(*c));
     w->joint_perm = (uint32_t*)malloc((m ? m : 1) * sizeof(uint32_t));
     w->joint_color = (uint8_t*)malloc(m ? m : 1);
     uint32_t* ea = (uint32_t*)malloc((m ? m : 1) * sizeof(uint32_t));
@@ -431,12 +434,9 @@ int sfo_upload_constraints(sfo_world* w, uint32_t m, const sfx_distance_constrai
     uint8_t* dyn = (uint8_t*)malloc(w->n ? w->n : 1);
     for (uint32_t i = 0; i < w->n; ++i) dyn[i] = (uint8_t)is_dynamic(w, i);
     for (uint32_t k = 0; k < m; ++k) {
-        ea[k] = c[k].body_a; eb[k] = c[k].body_b;
+        ea[k] = k < md ? w->joints[k].body_a : w->angles[k - md].body_a;
+        eb[k] = k < md ? w->joints[k].body_b : w->angles[k - md].body_b;
         ku[k] = k >> 24; kv[k] = k & 0xFFFFFFu; /* joints are keyed by their index */
-        if ((ea[k] != SFX_WORLD_BODY && ea[k] >= w->n) || (eb[k] != SFX_WORLD_BODY && eb[k] >= w->n)) {
-            free(ea); free(eb); free(ku); free(kv); free(dyn);
-            return SFX_ERR_INVALID;
-        }
     }
     uint32_t left = 0, ovf = 0;
     color_scratch cs;
@@ -452,6 +452,34 @@ int sfo_upload_constraints(sfo_world* w, uint32_t m, const sfx_distance_constrai
         if (w->joint_color[k] == NO_COLOR) w->joint_perm[pos++] = k;
     free(ea); free(eb); free(ku); free(kv); free(dyn);
     return ovf ? SFX_ERR_CAPACITY : SFX_OK;
+}
+
+static int body_ok(const sfo_world* w, uint32_t b) { return b == SFX_WORLD_BODY || b < w->n; }
+
+int sfo_upload_constraints(sfo_world* w, uint32_t m, const sfx_distance_constraint* c) {
+    for (uint32_t k = 0; k < m; ++k) {
+        if (!body_ok(w, c[k].body_a) || !body_ok(w, c[k].body_b) || c[k].limit > SFX_LIMIT_STRUT) return SFX_ERR_INVALID;
+        if (!(c[k].damping >= 0.0f) || (c[k].damping > 0.0f && c[k].limit != SFX_LIMIT_NONE)) return SFX_ERR_INVALID;
+    }
+    free(w->joints);
+    w->m_dist = m;
+    w->joints = (sfx_distance_constraint*)malloc((m ? m : 1) * sizeof(*c));
+    memcpy(w->joints, c, m * sizeof(*c));
+    return rebuild_joints(w);
+}
+
+int sfo_upload_angle_constraints(sfo_world* w, uint32_t m, const sfx_angle_constraint* c) {
+    const float pi = 3.14159265358979323846f;
+    for (uint32_t k = 0; k < m; ++k) {
+        if (!body_ok(w, c[k].body_a) || !body_ok(w, c[k].body_b)) return SFX_ERR_INVALID;
+        if (!(c[k].min_angle > -pi && c[k].min_angle <= c[k].max_angle && c[k].max_angle < pi)) return SFX_ERR_INVALID;
+        if (!(c[k].damping >= 0.0f) || !(c[k].compliance >= 0.0f)) return SFX_ERR_INVALID;
+    }
+    free(w->angles);
+    w->m_angle = m;
+    w->angles = (sfx_angle_constraint*)malloc((m ? m : 1) * sizeof(*c));
+    memcpy(w->angles, c, m * sizeof(*c));
+    return rebuild_joints(w);
 }
 
 /* ------------------------------------------------------------------ AABB
@@ -1480,6 +1508,108 @@ static void solve_joint(sfo_world* w, const sfx_distance_constraint* j, float in
     if (b != SFX_WORLD_BODY) apply_pos(w, b, rbx, rby, nx * corr, ny * corr, -1.0f);
 }
 
+/* atan2 from two range reductions and the Cephes atanf polynomial (about 2 ulp): the same
+ * operations as the device code, so both sides get the same bits */
+static float atan_pos(float x) {
+    float y = 0.0f;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    float z = x * x;
+    float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z;
+    return y + (p * x + x);
+}
+
+static float atan2_det(float y, float x) {
+    if (x == 0.0f && y == 0.0f) return 0.0f;
+    float ax = fabsf(x), ay = fabsf(y), r;
+    if (ax >= ay) r = atan_pos(ay / ax);
+    else r = 1.5707963267948966f - atan_pos(ax / ay);
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    return y < 0.0f ? -r : r;
+}
+
+float sfo_debug_atan2(float y, float x) { return atan2_det(y, x); } /* test hook */
+
+/* [XPBD-RB] sec. 3.4.1 joint limits, in 2D a scalar: the relative angle of b against a is pushed
+ * back into [min, max]; XPBD compliance as for the distance constraint */
+static void solve_angle(sfo_world* w, const sfx_angle_constraint* j, float inv_h2) {
+    uint32_t a = j->body_a, b = j->body_b;
+    float ca = 1.0f, sa = 0.0f, cb = 1.0f, sb = 0.0f, iia = 0.0f, iib = 0.0f;
+    if (a != SFX_WORLD_BODY) { ca = w->rot[2 * a]; sa = w->rot[2 * a + 1]; iia = w->inv_inertia[a]; }
+    if (b != SFX_WORLD_BODY) { cb = w->rot[2 * b]; sb = w->rot[2 * b + 1]; iib = w->inv_inertia[b]; }
+    float qc = cb * ca + sb * sa, qs = sb * ca - cb * sa;
+    float phi = atan2_det(qs, qc);
+    float C = phi - fminf(fmaxf(phi, j->min_angle), j->max_angle);
+    if (C == 0.0f) return;
+    float wsum = (iia + iib) + j->compliance * inv_h2;
+    if (!(wsum > 0.0f)) return;
+    float dl = C / wsum;
+    if (iia > 0.0f) rotate_by(&w->rot[2 * a], &w->rot[2 * a + 1], iia * dl);
+    if (iib > 0.0f) rotate_by(&w->rot[2 * b], &w->rot[2 * b + 1], -(iib * dl));
+}
+
+/* [XPBD-RB] sec. 3.3.1 / 3.6 joint damping in the velocity pass: the fraction min(damping h, 1) of
+ * the relative velocity the joint sees is removed by a pair of opposite impulses */
+static void damp_angle(sfo_world* w, const sfx_angle_constraint* j, float h) {
+    if (!(j->damping > 0.0f)) return;
+    uint32_t a = j->body_a, b = j->body_b;
+    float frac = fminf(j->damping * h, 1.0f);
+    float iia = a != SFX_WORLD_BODY ? w->inv_inertia[a] : 0.0f, iib = b != SFX_WORLD_BODY ? w->inv_inertia[b] : 0.0f;
+    float oa = a != SFX_WORLD_BODY ? w->angvel[a] : 0.0f, ob = b != SFX_WORLD_BODY ? w->angvel[b] : 0.0f;
+    float wsum = iia + iib;
+    if (!(wsum > 0.0f)) return;
+    float imp = ((ob - oa) * frac) / wsum;
+    if (iia > 0.0f) w->angvel[a] = oa + iia * imp;
+    if (iib > 0.0f) w->angvel[b] = ob - iib * imp;
+}
+
+static void damp_joint(sfo_world* w, const sfx_distance_constraint* j, float h) {
+    if (!(j->damping > 0.0f)) return;
+    uint32_t a = j->body_a, b = j->body_b;
+    float frac = fminf(j->damping * h, 1.0f);
+    float rax = 0, ray = 0, rbx = 0, rby = 0, pax = j->anchor_a[0], pay = j->anchor_a[1], pbx = j->anchor_b[0], pby = j->anchor_b[1];
+    float vax = 0, vay = 0, oa = 0, vbx = 0, vby = 0, ob = 0;
+    if (a != SFX_WORLD_BODY) {
+        float c = w->rot[2 * a], s = w->rot[2 * a + 1];
+        rax = c * j->anchor_a[0] - s * j->anchor_a[1]; ray = s * j->anchor_a[0] + c * j->anchor_a[1];
+        pax = w->pos[2 * a] + rax; pay = w->pos[2 * a + 1] + ray;
+        vax = w->vel[2 * a]; vay = w->vel[2 * a + 1]; oa = w->angvel[a];
+    }
+    if (b != SFX_WORLD_BODY) {
+        float c = w->rot[2 * b], s = w->rot[2 * b + 1];
+        rbx = c * j->anchor_b[0] - s * j->anchor_b[1]; rby = s * j->anchor_b[0] + c * j->anchor_b[1];
+        pbx = w->pos[2 * b] + rbx; pby = w->pos[2 * b + 1] + rby;
+        vbx = w->vel[2 * b]; vby = w->vel[2 * b + 1]; ob = w->angvel[b];
+    }
+    float dvx = (vbx - ob * rby) - (vax - oa * ray);
+    float dvy = (vby + ob * rbx) - (vay + oa * rax);
+    if (j->rest_length != 0.0f) { /* a link: only the rate of change of its length */
+        float dx = pbx - pax, dy = pby - pay;
+        float len = sqrtf(dx * dx + dy * dy);
+        if (!(len > EPS_LEN)) return;
+        float ux = dx / len, uy = dy / len;
+        float rate = dvx * ux + dvy * uy;
+        dvx = ux * rate; dvy = uy * rate;
+    }
+    float sp = sqrtf(dvx * dvx + dvy * dvy);
+    if (!(sp > EPS_LEN)) return;
+    float nx = dvx / sp, ny = dvy / sp;
+    float wsum = 0.0f;
+    if (a != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(w, a, rax, ray, nx, ny);
+    if (b != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(w, b, rbx, rby, nx, ny);
+    if (!(wsum > 0.0f)) return;
+    float imp = (sp * frac) / wsum;
+    float jx = nx * imp, jy = ny * imp;
+    if (a != SFX_WORLD_BODY && (w->inv_mass[a] > 0.0f || w->inv_inertia[a] > 0.0f)) {
+        w->vel[2 * a] = vax + jx * w->inv_mass[a]; w->vel[2 * a + 1] = vay + jy * w->inv_mass[a];
+        w->angvel[a] = oa + w->inv_inertia[a] * (rax * jy - ray * jx);
+    }
+    if (b != SFX_WORLD_BODY && (w->inv_mass[b] > 0.0f || w->inv_inertia[b] > 0.0f)) {
+        w->vel[2 * b] = vbx - jx * w->inv_mass[b]; w->vel[2 * b + 1] = vby - jy * w->inv_mass[b];
+        w->angvel[b] = ob - w->inv_inertia[b] * (rbx * jy - rby * jx);
+    }
+}
+
 /* the tick in pieces, mirroring sfx_tick_begin / sfx_tick_substep (slab drivers swap halo
  * bodies between substeps) */
 int sfo_tick_begin(sfo_world* w, float frame_dt, int order) {
@@ -1521,7 +1651,8 @@ int sfo_tick_substep(sfo_world* w) {
     for (uint32_t k = 0; k < w->m; ++k) {
         uint32_t jk = order == SFO_ORDER_SEQUENTIAL ? k : w->joint_perm[k];
         if (order != SFO_ORDER_SEQUENTIAL && w->joint_color[jk] == NO_COLOR) continue;
-        solve_joint(w, &w->joints[jk], inv_h2);
+        if (jk < w->m_dist) solve_joint(w, &w->joints[jk], inv_h2);
+        else solve_angle(w, &w->angles[jk - w->m_dist], inv_h2);
     }
     /* [DESIGN] DESIGN.md "Contract / sweep order": the manifolds of ALL solver pairs are computed
      * first, at the poses the substep's integration (and the joints) left -- Mueller et al. 2020
@@ -1530,6 +1661,12 @@ int sfo_tick_substep(sfo_world* w) {
     for (uint32_t k = 0; k < n_ord; ++k) prepare_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]]);
     for (uint32_t k = 0; k < n_ord; ++k) solve_pos_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]], max_corr);
     derive_velocities(w, inv_h);
+    for (uint32_t k = 0; k < w->m; ++k) { /* joint damping, in the joints' solve order */
+        uint32_t jk = order == SFO_ORDER_SEQUENTIAL ? k : w->joint_perm[k];
+        if (order != SFO_ORDER_SEQUENTIAL && w->joint_color[jk] == NO_COLOR) continue;
+        if (jk < w->m_dist) damp_joint(w, &w->joints[jk], h);
+        else damp_angle(w, &w->angles[jk - w->m_dist], h);
+    }
     for (uint32_t bt = 0, k0 = 0; bt < nbatch; ++bt) {
         uint32_t k1 = w->batch_end[bt];
         for (uint32_t k = k0; k < k1; ++k) {

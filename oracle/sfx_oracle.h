@@ -46,6 +46,8 @@ int sfo_upload_colliders(sfo_world* w, uint32_t n, const sfx_collider* colliders
                          const float* poly_verts, uint32_t n_poly_verts);
 int sfo_upload_materials(sfo_world* w, uint32_t n, const sfx_material* materials);
 int sfo_upload_constraints(sfo_world* w, uint32_t m, const sfx_distance_constraint* c);
+int sfo_upload_angle_constraints(sfo_world* w, uint32_t m, const sfx_angle_constraint* c);
+float sfo_debug_atan2(float y, float x); /* the deterministic atan2 of the angle constraint (test hook) */
 
 /* resolved (auto-filled) configuration, for comparison with libsfx */
 void sfo_resolved_config(const sfo_world* w, sfx_config* out);

@@ -108,7 +108,17 @@ constraint_dtype = np.dtype(
         ("rest_length", "<f4"),
         ("compliance", "<f4"),
         ("limit", "<u4"),
-        ("reserved", "<u4"),
+        ("damping", "<f4"),
+    ]
+)
+angle_constraint_dtype = np.dtype(
+    [
+        ("body_a", "<u4"),
+        ("body_b", "<u4"),
+        ("min_angle", "<f4"),
+        ("max_angle", "<f4"),
+        ("compliance", "<f4"),
+        ("damping", "<f4"),
     ]
 )
 contact_dtype = np.dtype(
@@ -125,6 +135,7 @@ contact_dtype = np.dtype(
 assert collider_dtype.itemsize == 40
 assert material_dtype.itemsize == 12
 assert constraint_dtype.itemsize == 40
+assert angle_constraint_dtype.itemsize == 24
 ray_hit_dtype = np.dtype([("body", "<u4"), ("t", "<f4"), ("normal", "<f4", (2,))])
 assert contact_dtype.itemsize == 60
 assert ray_hit_dtype.itemsize == 16
@@ -183,7 +194,9 @@ def vptr(a):
 SFX_SYMBOLS = [
     "sfx_create", "sfx_destroy", "sfx_abi_version", "sfx_default_config",
     "sfx_upload_bodies", "sfx_upload_colliders", "sfx_upload_materials", "sfx_upload_constraints",
+    "sfx_upload_angle_constraints",
     "sfx_step", "sfx_sync", "sfx_download_poses", "sfx_download_velocities",
+    "sfx_readback_begin", "sfx_readback_wait",
     "sfx_tick_begin", "sfx_tick_substep", "sfx_set_stream", "sfx_halo_set", "sfx_halo_pack", "sfx_halo_unpack",
     "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy",
     "sfx_query_points", "sfx_query_aabbs", "sfx_query_rays",
@@ -205,11 +218,12 @@ def bind_world_api(lib, prefix):
     g("upload_colliders").argtypes = [vp, u32, vp, f32p, u32]
     g("upload_materials").argtypes = [vp, u32, vp]
     g("upload_constraints").argtypes = [vp, u32, vp]
+    g("upload_angle_constraints").argtypes = [vp, u32, vp]
     g("download_poses").argtypes = [vp, f32p, f32p]
     g("download_velocities").argtypes = [vp, f32p, f32p]
     g("stats").argtypes = [vp, P(SfxFrameStats)]
     for n in ("upload_bodies", "upload_colliders", "upload_materials", "upload_constraints",
-              "download_poses", "download_velocities", "stats"):
+              "upload_angle_constraints", "download_poses", "download_velocities", "stats"):
         g(n).restype = C.c_int
 
 
@@ -252,6 +266,10 @@ def load_libsfx(path=None):
     for n in ("sfx_tick_begin", "sfx_tick_substep", "sfx_set_stream", "sfx_halo_set", "sfx_halo_pack",
               "sfx_halo_unpack", "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy"):
         getattr(lib, n).restype = C.c_int
+    lib.sfx_readback_begin.argtypes = [vp]
+    lib.sfx_readback_begin.restype = C.c_int
+    lib.sfx_readback_wait.argtypes = [vp, P(P(C.c_float)), P(C.c_uint32)]
+    lib.sfx_readback_wait.restype = C.c_int
     lib.sfx_query_points.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_uint32, vp, vp]
     lib.sfx_query_aabbs.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_uint32, vp, C.c_size_t, P(C.c_size_t)]
     lib.sfx_query_rays.argtypes = [vp, C.c_uint32, P(C.c_float), P(C.c_float), C.c_uint32, vp]

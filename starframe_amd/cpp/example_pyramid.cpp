@@ -29,5 +29,20 @@ int main() {
     std::printf("ray from above hits body %u at t = %.3f (normal %.2f, %.2f); body under (30, -0.5): %u\n", hit.body, hit.t,
                 hit.normal[0], hit.normal[1], under);
     const bool ray_ok = hit.body != SFX_NO_BODY && hit.normal[1] > 0.9f && under == (sf::BodyKey)(physics.body_count() - 1);
-    return top > base - 0.6f && ray_ok ? 0 : 1;
+    // a second world: a rope between two pins and a hinged flap with stops, drawn from the overlapped read-back
+    sf::Physics toys(cfg);
+    const std::vector<sf::BodyKey> rope = toys.add_rope({0.0f, 3.0f}, {2.0f, 3.0f}, 16, 0.04f, 1.0f, true, 0.25f);
+    const sf::Collider flap = sf::Collider::new_rect(1.0f, 0.1f);
+    const sf::BodyKey bar = toys.add(sf::Body::new_dynamic(flap, 1.0f), flap, sf::Pose{{4.5f, 3.0f}, 0.0f});
+    toys.add_attachment(sf::WORLD, {4.0f, 3.0f}, bar, {-0.5f, 0.0f});
+    toys.add_angle_constraint(sf::WORLD, bar, -0.4f, 0.3f, 0.0f, 2.0f);
+    const float* poses = nullptr;
+    uint32_t n = 0;
+    for (int frame = 0; frame < 240; ++frame) poses = toys.tick_and_read(1.0f / 60.0f, &n);
+    float low = 3.0f;
+    for (sf::BodyKey k : rope) low = poses[4 * k + 1] < low ? poses[4 * k + 1] : low;
+    const float flap_angle = std::atan2(poses[4 * bar + 3], poses[4 * bar + 2]);
+    std::printf("rope of %zu links sags to %.3f below its pins; flap rests at %.3f rad (stop at -0.4)\n", rope.size(), 3.0f - low, flap_angle);
+    const bool toys_ok = n == toys.body_count() && low < 2.95f && low > 1.9f && std::fabs(flap_angle + 0.4f) < 0.02f;
+    return top > base - 0.6f && ray_ok && toys_ok ? 0 : 1;
 }

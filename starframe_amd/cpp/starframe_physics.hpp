@@ -151,11 +151,39 @@ public:
     BodyKey add_particle(const Body& body, const Pose& pose) { Collider none; none.raw_.type = SFX_SHAPE_NONE; return add(body, none, pose); }
 
     // distance constraint between body-local anchors (world position for WORLD)
+    // (damping, 1/s: two-sided constraints only)
     void add_distance_constraint(BodyKey a, Vec2 anchor_a, BodyKey b, Vec2 anchor_b, float rest_length, float compliance = 0,
-                                 uint32_t limit = SFX_LIMIT_NONE) {
-        sfx_distance_constraint c{a, b, {anchor_a.x, anchor_a.y}, {anchor_b.x, anchor_b.y}, rest_length, compliance, limit, 0u};
+                                 uint32_t limit = SFX_LIMIT_NONE, float damping = 0) {
+        sfx_distance_constraint c{a, b, {anchor_a.x, anchor_a.y}, {anchor_b.x, anchor_b.y}, rest_length, compliance, limit, damping};
         joints_.push_back(c);
         dirty_ = true;
+    }
+    // pin joint: the two anchors are held together
+    void add_attachment(BodyKey a, Vec2 anchor_a, BodyKey b, Vec2 anchor_b, float compliance = 0, float damping = 0) {
+        add_distance_constraint(a, anchor_a, b, anchor_b, 0.0f, compliance, SFX_LIMIT_NONE, damping);
+    }
+    // keeps angle(b) - angle(a) inside [min_angle, max_angle] (WORLD: angle 0)
+    void add_angle_constraint(BodyKey a, BodyKey b, float min_angle, float max_angle, float compliance = 0, float damping = 0) {
+        angles_.push_back(sfx_angle_constraint{a, b, min_angle, max_angle, compliance, damping});
+        dirty_ = true;
+    }
+    // rope helper: `links` circle bodies from start to end tied by one-sided links, first one tied to the world at start;
+    // slack makes the rope that fraction longer than the distance it spans
+    std::vector<BodyKey> add_rope(Vec2 start, Vec2 end, uint32_t links, float radius = 0.04f, float density = 1.0f, bool pin_end = false,
+                                  float slack = 0.0f) {
+        std::vector<BodyKey> ids;
+        const float dx = (end.x - start.x) / (float)links, dy = (end.y - start.y) / (float)links;
+        const float seg = std::sqrt(dx * dx + dy * dy) * (1.0f + slack);
+        const uint32_t group = 0x52000000u + (uint32_t)inv_mass_.size();
+        for (uint32_t k = 0; k < links; ++k) {
+            Collider c = Collider::new_circle(radius);
+            c.raw_.group = group;
+            ids.push_back(add(Body::new_dynamic(c, density), c, Pose{{start.x + (k + 0.5f) * dx, start.y + (k + 0.5f) * dy}, 0.0f}));
+            if (k) add_distance_constraint(ids[k - 1], {0, 0}, ids[k], {0, 0}, seg, 0, SFX_LIMIT_ROPE);
+        }
+        if (links) add_distance_constraint(WORLD, start, ids[0], {0, 0}, 0.5f * seg, 0, SFX_LIMIT_ROPE);
+        if (links && pin_end) add_distance_constraint(ids[links - 1], {0, 0}, WORLD, end, 0.5f * seg, 0, SFX_LIMIT_ROPE);
+        return ids;
     }
 
     // the per-frame tick entry point
@@ -168,6 +196,16 @@ public:
     void read_poses(std::vector<float>& pos, std::vector<float>& rot) {
         pos.resize(pos_.size()); rot.resize(rot_.size());
         check(sfx_download_poses(world_, pos.data(), rot.data()), "sfx_download_poses");
+    }
+    // render loop: start the read-back of the current poses, run the next tick while they travel, return them
+    // ([n][4] = x, y, cos, sin in library-owned pinned memory, valid until the call after next)
+    const float* tick_and_read(float frame_dt, uint32_t* n = nullptr) {
+        if (dirty_) upload();
+        check(sfx_readback_begin(world_), "sfx_readback_begin");
+        check(sfx_step(world_, frame_dt), "sfx_step");
+        const float* poses = nullptr;
+        check(sfx_readback_wait(world_, &poses, n), "sfx_readback_wait");
+        return poses;
     }
     sfx_frame_stats stats() { sfx_frame_stats s; check(sfx_stats(world_, &s), "sfx_stats"); return s; }
 
@@ -238,6 +276,7 @@ private:
         check(sfx_upload_materials(world_, (uint32_t)mats_.size(), mats_.data()), "sfx_upload_materials");
         check(sfx_upload_colliders(world_, n, colliders_.data(), poly_.data(), (uint32_t)(poly_.size() / 2)), "sfx_upload_colliders");
         check(sfx_upload_constraints(world_, (uint32_t)joints_.size(), joints_.data()), "sfx_upload_constraints");
+        check(sfx_upload_angle_constraints(world_, (uint32_t)angles_.size(), angles_.data()), "sfx_upload_angle_constraints");
         old_count_ = n; dirty_ = false; ticked_ = true;
     }
 
@@ -249,6 +288,7 @@ private:
     std::vector<sfx_collider> colliders_;
     std::vector<sfx_material> mats_;
     std::vector<sfx_distance_constraint> joints_;
+    std::vector<sfx_angle_constraint> angles_;
 };
 
 }  // namespace sf

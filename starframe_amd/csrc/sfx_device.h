@@ -794,12 +794,35 @@ __device__ __forceinline__ int solve_vel_rec(const PairRec& r, float4& pa, float
     return shift ? 3 : 1;
 }
 
-// distance constraint (Mueller et al. 2020 sec. 3.3, XPBD compliance), lambda restarts at 0
+// joints: distance constraints (Mueller et al. 2020 sec. 3.3, XPBD compliance) and angle constraints
+// (sec. 3.4.1 "joint limits", in 2D a scalar), lambda restarts at 0
+#define SFX_JOINT_ANGLE 3u  // kind of an angle constraint (0..2 = SFX_LIMIT_* of a distance constraint)
 struct JointArrays {
     const uint2* bodies;    // (a, b), SFX_WORLD_BODY for the world
-    const float4* anchors;  // (a.x, a.y, b.x, b.y)
-    const float4* params;   // (rest_length, compliance, limit as bits, 0)
+    const float4* anchors;  // distance: (a.x, a.y, b.x, b.y); angle: (min, max, 0, 0)
+    const float4* params;   // (rest_length, compliance, kind as bits, damping)
 };
+
+// atan2 with the same operations on both sides (Cephes atanf: two range reductions and a degree-4
+// polynomial in x^2, ~2 ulp), so that the oracle and the device agree bit for bit
+__device__ __forceinline__ float atan_pos(float x /* >= 0 */) {
+    float y = 0.0f;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    const float z = x * x;
+    const float p = (((8.05374449538e-2f * z - 1.38776856032e-1f) * z + 1.99777106478e-1f) * z - 3.33329491539e-1f) * z;
+    return y + (p * x + x);
+}
+
+__device__ __forceinline__ float atan2_det(float y, float x) {
+    if (x == 0.0f && y == 0.0f) return 0.0f;
+    const float ax = fabsf(x), ay = fabsf(y);
+    float r;
+    if (ax >= ay) r = atan_pos(ay / ax);                       // [0, pi/4]
+    else r = 1.5707963267948966f - atan_pos(ax / ay);          // (pi/4, pi/2]
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    return y < 0.0f ? -r : r;
+}
 
 __device__ __forceinline__ void apply_pos(float4& pose, const float2& w, float rx, float ry, float px, float py, float sign) {
     if (w.x > 0.0f) {
@@ -825,6 +848,21 @@ __device__ __forceinline__ void solve_joint(const BodyArrays& B, const JointArra
     float rax = 0.0f, ray = 0.0f, rbx = 0.0f, rby = 0.0f, pax, pay, pbx, pby;
     float4 pa = make_float4(0, 0, 1, 0), pb = make_float4(0, 0, 1, 0);
     float2 wa = make_float2(0, 0), wb = make_float2(0, 0);
+    if (__float_as_uint(pr.z) == SFX_JOINT_ANGLE) {
+        if (a != SFX_WORLD_BODY) { pa = B.pose[a]; wa = B.mass[a]; }
+        if (b != SFX_WORLD_BODY) { pb = B.pose[b]; wb = B.mass[b]; }
+        // relative rotation b * conj(a) and its angle
+        const float qc = pb.z * pa.z + pb.w * pa.w, qs = pb.w * pa.z - pb.z * pa.w;
+        const float phi = atan2_det(qs, qc);
+        const float Ca = phi - fminf(fmaxf(phi, an.x), an.y);
+        if (Ca == 0.0f) return;
+        const float wsa = (wa.y + wb.y) + pr.y * inv_h2;
+        if (!(wsa > 0.0f)) return;
+        const float dl = Ca / wsa;
+        if (wa.y > 0.0f) { rotate_by(pa.z, pa.w, wa.y * dl); B.pose[a] = pa; }
+        if (wb.y > 0.0f) { rotate_by(pb.z, pb.w, -(wb.y * dl)); B.pose[b] = pb; }
+        return;
+    }
     if (a != SFX_WORLD_BODY) {
         pa = B.pose[a]; wa = B.mass[a];
         anchor_world(pa, an.x, an.y, rax, ray);
@@ -855,6 +893,62 @@ __device__ __forceinline__ void solve_joint(const BodyArrays& B, const JointArra
     if (b != SFX_WORLD_BODY && (wb.x > 0.0f || wb.y > 0.0f)) {
         apply_pos(pb, wb, rbx, rby, nx * corr, ny * corr, -1.0f);
         B.pose[b] = pb;
+    }
+}
+
+// joint damping in the velocity pass (Mueller et al. 2020 sec. 3.3.1 / 3.6): removes the fraction
+// min(damping * h, 1) of the relative velocity the joint sees
+__device__ __forceinline__ void damp_joint(const BodyArrays& B, const JointArrays& J, uint32_t k, float h) {
+    const float4 pr = J.params[k];
+    if (!(pr.w > 0.0f)) return;
+    const uint2 ab = J.bodies[k];
+    const uint32_t a = ab.x, b = ab.y;
+    const float frac = fminf(pr.w * h, 1.0f);
+    float4 pa = make_float4(0, 0, 1, 0), pb = make_float4(0, 0, 1, 0), va = make_float4(0, 0, 0, 0), vb = make_float4(0, 0, 0, 0);
+    float2 wa = make_float2(0, 0), wb = make_float2(0, 0);
+    if (a != SFX_WORLD_BODY) { pa = B.pose[a]; va = B.vel[a]; wa = B.mass[a]; }
+    if (b != SFX_WORLD_BODY) { pb = B.pose[b]; vb = B.vel[b]; wb = B.mass[b]; }
+    if (__float_as_uint(pr.z) == SFX_JOINT_ANGLE) {
+        const float wsa = wa.y + wb.y;
+        if (!(wsa > 0.0f)) return;
+        const float imp = ((vb.z - va.z) * frac) / wsa;
+        if (wa.y > 0.0f) { va.z = va.z + wa.y * imp; B.vel[a] = va; }
+        if (wb.y > 0.0f) { vb.z = vb.z - wb.y * imp; B.vel[b] = vb; }
+        return;
+    }
+    const float4 an = J.anchors[k];
+    float rax = 0.0f, ray = 0.0f, rbx = 0.0f, rby = 0.0f, pax = an.x, pay = an.y, pbx = an.z, pby = an.w;
+    if (a != SFX_WORLD_BODY) { anchor_world(pa, an.x, an.y, rax, ray); pax = pa.x + rax; pay = pa.y + ray; }
+    if (b != SFX_WORLD_BODY) { anchor_world(pb, an.z, an.w, rbx, rby); pbx = pb.x + rbx; pby = pb.y + rby; }
+    // relative velocity of the anchors, b minus a
+    float dvx = (vb.x - vb.z * rby) - (va.x - va.z * ray);
+    float dvy = (vb.y + vb.z * rbx) - (va.y + va.z * rax);
+    if (pr.x != 0.0f) {  // a link: only the rate of change of its length
+        const float dx = pbx - pax, dy = pby - pay;
+        const float len = sqrtf(dx * dx + dy * dy);
+        if (!(len > SFX_EPS_LEN)) return;
+        const float ux = dx / len, uy = dy / len;
+        const float rate = dvx * ux + dvy * uy;
+        dvx = ux * rate; dvy = uy * rate;
+    }
+    const float sp = sqrtf(dvx * dvx + dvy * dvy);
+    if (!(sp > SFX_EPS_LEN)) return;
+    const float nx = dvx / sp, ny = dvy / sp;
+    float wsum = 0.0f;
+    if (a != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(wa, rax, ray, nx, ny);
+    if (b != SFX_WORLD_BODY) wsum = wsum + gen_inv_mass(wb, rbx, rby, nx, ny);
+    if (!(wsum > 0.0f)) return;
+    const float imp = (sp * frac) / wsum;  // along n on a, against it on b
+    const float jx = nx * imp, jy = ny * imp;
+    if (a != SFX_WORLD_BODY && (wa.x > 0.0f || wa.y > 0.0f)) {
+        va.x = va.x + jx * wa.x; va.y = va.y + jy * wa.x;
+        va.z = va.z + wa.y * (rax * jy - ray * jx);
+        B.vel[a] = va;
+    }
+    if (b != SFX_WORLD_BODY && (wb.x > 0.0f || wb.y > 0.0f)) {
+        vb.x = vb.x - jx * wb.x; vb.y = vb.y - jy * wb.x;
+        vb.z = vb.z - wb.y * (rbx * jy - rby * jx);
+        B.vel[b] = vb;
     }
 }
 

@@ -113,9 +113,20 @@ struct sfx_world {
     DevBuf<float4> j_anchors;
     DevBuf<float4> j_params;
     DevBuf<uint32_t> j_count_dev;
+    std::vector<sfx_distance_constraint> h_dist;  // as uploaded: the joint list is h_dist, then h_angle
+    std::vector<sfx_angle_constraint> h_angle;
+    bool joint_damped = false;
     std::vector<uint32_t> joint_perm;
     std::vector<uint8_t> joint_color_sorted;
     std::vector<uint32_t> joint_color_start;  // n_joint_colors + 1
+    // asynchronous pose read-back (sfx_readback_begin / _wait): two slots, each a device snapshot + a pinned host copy
+    hipStream_t rb_stream = nullptr;
+    DevBuf<float4> rb_dev[2];
+    float4* rb_host[2] = {nullptr, nullptr};
+    hipEvent_t rb_snap[2] = {nullptr, nullptr}, rb_done[2] = {nullptr, nullptr};
+    uint32_t rb_count[2] = {0, 0};
+    uint32_t rb_cap = 0;          // bodies the slots hold
+    uint64_t rb_head = 0, rb_tail = 0;
     // async counter read-back (stale by one tick, never waited for inside sfx_step)
     Counters* h_ctr = nullptr;       // pinned
     hipEvent_t ev_ctr = nullptr;
@@ -559,6 +570,14 @@ void sfx_destroy(sfx_world* w) {
     w->q_cellxy.release(); w->q_sorted_cell.release(); w->q_in.release(); w->q_out.release();
     w->c_rec.release(); w->c_lam.release();
     w->j_bodies.release(); w->j_anchors.release(); w->j_params.release(); w->j_count_dev.release();
+    if (w->rb_stream) (void)hipStreamSynchronize(w->rb_stream);
+    for (int k = 0; k < 2; ++k) {
+        w->rb_dev[k].release();
+        if (w->rb_host[k]) (void)hipHostFree(w->rb_host[k]);
+        if (w->rb_snap[k]) (void)hipEventDestroy(w->rb_snap[k]);
+        if (w->rb_done[k]) (void)hipEventDestroy(w->rb_done[k]);
+    }
+    if (w->rb_stream) (void)hipStreamDestroy(w->rb_stream);
     if (w->h_ctr) (void)hipHostFree(w->h_ctr);
     if (w->ev_ctr) (void)hipEventDestroy(w->ev_ctr);
     if (w->t_begin) (void)hipEventDestroy(w->t_begin);
@@ -594,6 +613,7 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
         w->n = n;
         w->have_colliders = false;
         w->m = 0;
+        w->h_dist.clear(); w->h_angle.clear(); w->joint_damped = false;
         w->joint_perm.clear(); w->joint_color_sorted.clear(); w->joint_color_start.assign(1, 0);
         const size_t c = std::max(n, 1u);
         ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
@@ -717,24 +737,21 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     return rebuild_filt(w);
 }
 
-int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constraint* c) {
-    if (!w || (m && !c)) return fail(w, SFX_ERR_INVALID, "null argument");
-    if (!w->have_bodies) return fail(w, SFX_ERR_INVALID, "upload bodies before constraints");
-    HIPCHK(w, hipSetDevice(w->device));
-    HIPCHK(w, hipStreamSynchronize(w->stream));
-    for (uint32_t k = 0; k < m; ++k)
-        if ((c[k].body_a != SFX_WORLD_BODY && c[k].body_a >= w->n) || (c[k].body_b != SFX_WORLD_BODY && c[k].body_b >= w->n))
-            return fail(w, SFX_ERR_INVALID, "constraint %u: body index out of range", k);
-    for (uint32_t k = 0; k < m; ++k)
-        if (c[k].limit > SFX_LIMIT_STRUT) return fail(w, SFX_ERR_INVALID, "constraint %u: unknown limit %u", k, c[k].limit);
+namespace {
+
+// colours the joint list (distance constraints, then angle constraints) and uploads it colour-sorted
+int rebuild_joints(sfx_world* w) {
+    const uint32_t md = (uint32_t)w->h_dist.size(), m = md + (uint32_t)w->h_angle.size();
     w->m = m;
     w->joint_perm.assign(m, 0);
     w->joint_color_sorted.assign(m, 0);
     w->joint_color_start.assign(1, 0);
+    w->joint_damped = false;
     if (m == 0) return SFX_OK;
     // colour the joint graph once, on the device, with the same kernels as the contact graph
     std::vector<uint2> ab(m);
-    for (uint32_t k = 0; k < m; ++k) ab[k] = make_uint2(c[k].body_a, c[k].body_b);
+    for (uint32_t k = 0; k < md; ++k) ab[k] = make_uint2(w->h_dist[k].body_a, w->h_dist[k].body_b);
+    for (uint32_t k = md; k < m; ++k) ab[k] = make_uint2(w->h_angle[k - md].body_a, w->h_angle[k - md].body_b);
     DevBuf<uint2> d_ab;
     DevBuf<uint8_t> color_save, prop_save;
     ALLOC(w, d_ab, m);
@@ -748,7 +765,7 @@ int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constrai
     color_global(w, d_ab.p, w->j_count_dev.p, m, 1, nullptr, nullptr, nullptr, w->jctr.p, 0);
     std::vector<uint8_t> colors(m);
     Counters jc{};
-    if (rc == SFX_OK) {
+    {
         hipError_t e = hipMemcpyAsync(colors.data(), w->pcolor.p, m, hipMemcpyDeviceToHost, w->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(&jc, w->jctr.p, sizeof(Counters), hipMemcpyDeviceToHost, w->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
@@ -773,17 +790,71 @@ int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constrai
     std::vector<float4> ha(m);
     std::vector<float4> hp(m);
     for (uint32_t d = 0; d < m; ++d) {
-        const sfx_distance_constraint& j = c[w->joint_perm[d]];
-        hb[d] = make_uint2(j.body_a, j.body_b);
-        ha[d] = make_float4(j.anchor_a[0], j.anchor_a[1], j.anchor_b[0], j.anchor_b[1]);
-        hp[d] = make_float4(j.rest_length, j.compliance, 0.0f, 0.0f);
-        memcpy(&hp[d].z, &j.limit, 4);
+        const uint32_t k = w->joint_perm[d];
+        hb[d] = ab[k];
+        if (k < md) {
+            const sfx_distance_constraint& j = w->h_dist[k];
+            ha[d] = make_float4(j.anchor_a[0], j.anchor_a[1], j.anchor_b[0], j.anchor_b[1]);
+            hp[d] = make_float4(j.rest_length, j.compliance, 0.0f, j.damping);
+            memcpy(&hp[d].z, &j.limit, 4);
+            if (j.damping > 0.0f) w->joint_damped = true;
+        } else {
+            const sfx_angle_constraint& j = w->h_angle[k - md];
+            const uint32_t kind = SFX_JOINT_ANGLE;
+            ha[d] = make_float4(j.min_angle, j.max_angle, 0.0f, 0.0f);
+            hp[d] = make_float4(0.0f, j.compliance, 0.0f, j.damping);
+            memcpy(&hp[d].z, &kind, 4);
+            if (j.damping > 0.0f) w->joint_damped = true;
+        }
     }
     ALLOC(w, w->j_bodies, m); ALLOC(w, w->j_anchors, m); ALLOC(w, w->j_params, m);
     HIPCHK(w, hipMemcpy(w->j_bodies.p, hb.data(), sizeof(uint2) * m, hipMemcpyHostToDevice));
     HIPCHK(w, hipMemcpy(w->j_anchors.p, ha.data(), sizeof(float4) * m, hipMemcpyHostToDevice));
     HIPCHK(w, hipMemcpy(w->j_params.p, hp.data(), sizeof(float4) * m, hipMemcpyHostToDevice));
     return SFX_OK;
+}
+
+int constraints_ready(sfx_world* w, uint32_t m, const void* c) {
+    if (!w || (m && !c)) return fail(w, SFX_ERR_INVALID, "null argument");
+    if (!w->have_bodies) return fail(w, SFX_ERR_INVALID, "upload bodies before constraints");
+    if (w->tick_open) return fail(w, SFX_ERR_INVALID, "constraints cannot change inside a tick");
+    return SFX_OK;
+}
+
+bool body_ok(const sfx_world* w, uint32_t b) { return b == SFX_WORLD_BODY || b < w->n; }
+
+}  // namespace
+
+int sfx_upload_constraints(sfx_world* w, uint32_t m, const sfx_distance_constraint* c) {
+    int rc = constraints_ready(w, m, c);
+    if (rc) return rc;
+    for (uint32_t k = 0; k < m; ++k) {
+        if (!body_ok(w, c[k].body_a) || !body_ok(w, c[k].body_b)) return fail(w, SFX_ERR_INVALID, "constraint %u: body index out of range", k);
+        if (c[k].limit > SFX_LIMIT_STRUT) return fail(w, SFX_ERR_INVALID, "constraint %u: unknown limit %u", k, c[k].limit);
+        if (!(c[k].damping >= 0.0f)) return fail(w, SFX_ERR_INVALID, "constraint %u: negative damping", k);
+        if (c[k].damping > 0.0f && c[k].limit != SFX_LIMIT_NONE)
+            return fail(w, SFX_ERR_INVALID, "constraint %u: damping needs a two-sided constraint (SFX_LIMIT_NONE)", k);
+    }
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->h_dist.assign(c, c + m);
+    return rebuild_joints(w);
+}
+
+int sfx_upload_angle_constraints(sfx_world* w, uint32_t m, const sfx_angle_constraint* c) {
+    int rc = constraints_ready(w, m, c);
+    if (rc) return rc;
+    const float pi = 3.14159265358979323846f;
+    for (uint32_t k = 0; k < m; ++k) {
+        if (!body_ok(w, c[k].body_a) || !body_ok(w, c[k].body_b)) return fail(w, SFX_ERR_INVALID, "angle constraint %u: body index out of range", k);
+        if (!(c[k].min_angle > -pi && c[k].min_angle <= c[k].max_angle && c[k].max_angle < pi))
+            return fail(w, SFX_ERR_INVALID, "angle constraint %u: needs -pi < min_angle <= max_angle < pi", k);
+        if (!(c[k].damping >= 0.0f) || !(c[k].compliance >= 0.0f)) return fail(w, SFX_ERR_INVALID, "angle constraint %u: negative damping or compliance", k);
+    }
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    w->h_angle.assign(c, c + m);
+    return rebuild_joints(w);
 }
 
 int sfx_debug_broadphase(sfx_world* w, float frame_dt) {
@@ -892,6 +963,12 @@ int sfx_tick_substep(sfx_world* w) {
     }
     { Prof p(w, SFX_K_DERIVE_VEL, n);
       hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
+    for (uint32_t jc = 0; w->joint_damped && jc < njc; ++jc) {
+        const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
+        if (!cnt) continue;
+        Prof p(w, SFX_K_SOLVE_JOINTS, cnt);
+        hipLaunchKernelGGL(k_damp_joints, dim3(cdiv(cnt, kBlock)), dim3(kBlock), 0, w->stream, start, cnt, B, J, sp.h);
+    }
     if (w->fuse_phases) {
         Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_kept : 0);
         launch_vel(std::min(total_grid, res_vel), 0u, nph, ++w->epoch, 1);
@@ -1182,6 +1259,53 @@ int sfx_download_poses(sfx_world* w, float* pos, float* rot) {
         if (pos) { pos[2 * i] = hp[i].x; pos[2 * i + 1] = hp[i].y; }
         if (rot) { rot[2 * i] = hp[i].z; rot[2 * i + 1] = hp[i].w; }
     }
+    return SFX_OK;
+}
+
+// ---- pose read-back for rendering: the copy to the host overlaps the next tick
+int sfx_readback_begin(sfx_world* w) {
+    if (!w || !w->have_bodies) return fail(w, SFX_ERR_INVALID, "no bodies");
+    if (w->tick_open) return fail(w, SFX_ERR_INVALID, "sfx_readback_begin inside a tick");
+    if (w->rb_head - w->rb_tail >= 2) return fail(w, SFX_ERR_INVALID, "two read-backs are already in flight: call sfx_readback_wait first");
+    HIPCHK(w, hipSetDevice(w->device));
+    if (!w->rb_stream) {
+        HIPCHK(w, hipStreamCreateWithFlags(&w->rb_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(w, hipEventCreateWithFlags(&w->rb_snap[k], hipEventDisableTiming));
+            HIPCHK(w, hipEventCreateWithFlags(&w->rb_done[k], hipEventDisableTiming));
+        }
+    }
+    if (w->rb_cap < w->n) {   // first use, or more bodies than before: nothing is in flight in a slot that is free
+        if (w->rb_head != w->rb_tail) return fail(w, SFX_ERR_INVALID, "the body count grew while a read-back is in flight");
+        for (int k = 0; k < 2; ++k) {
+            if (w->rb_host[k]) { HIPCHK(w, hipHostFree(w->rb_host[k])); w->rb_host[k] = nullptr; }
+            ALLOC(w, w->rb_dev[k], w->n);
+            HIPCHK(w, hipHostMalloc((void**)&w->rb_host[k], sizeof(float4) * w->n, hipHostMallocDefault));
+        }
+        w->rb_cap = w->n;
+    }
+    const int k = (int)(w->rb_head & 1u);
+    const size_t bytes = sizeof(float4) * w->n;
+    // snapshot in stream order (the next tick may overwrite the poses), then the transfer on its own stream
+    HIPCHK(w, hipMemcpyAsync(w->rb_dev[k].p, w->pose.p, bytes, hipMemcpyDeviceToDevice, w->stream));
+    HIPCHK(w, hipEventRecord(w->rb_snap[k], w->stream));
+    HIPCHK(w, hipStreamWaitEvent(w->rb_stream, w->rb_snap[k], 0));
+    HIPCHK(w, hipMemcpyAsync(w->rb_host[k], w->rb_dev[k].p, bytes, hipMemcpyDeviceToHost, w->rb_stream));
+    HIPCHK(w, hipEventRecord(w->rb_done[k], w->rb_stream));
+    w->rb_count[k] = w->n;
+    w->rb_head++;
+    return SFX_OK;
+}
+
+int sfx_readback_wait(sfx_world* w, const float** poses, uint32_t* n) {
+    if (!w || !poses) return fail(w, SFX_ERR_INVALID, "null argument");
+    if (w->rb_head == w->rb_tail) return fail(w, SFX_ERR_INVALID, "sfx_readback_wait without sfx_readback_begin");
+    HIPCHK(w, hipSetDevice(w->device));
+    const int k = (int)(w->rb_tail & 1u);
+    HIPCHK(w, hipEventSynchronize(w->rb_done[k]));
+    *poses = reinterpret_cast<const float*>(w->rb_host[k]);
+    if (n) *n = w->rb_count[k];
+    w->rb_tail++;
     return SFX_OK;
 }
 

@@ -1675,6 +1675,12 @@ __global__ __launch_bounds__(kBlock) void k_solve_joints(uint32_t start, uint32_
     if (k < cnt) solve_joint(B, J, start + k, inv_h2);
 }
 
+// joint damping of one colour (velocity pass; launched only when some joint has damping)
+__global__ __launch_bounds__(kBlock) void k_damp_joints(uint32_t start, uint32_t cnt, BodyArrays B, JointArrays J, float h) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < cnt) damp_joint(B, J, start + k, h);
+}
+
 // ---------------------------------------------------------------- slab halos
 // (pose, velocity) of the listed bodies <-> a dense [n][2] float4 buffer
 __global__ __launch_bounds__(kBlock) void k_halo_pack(uint32_t n, const uint32_t* __restrict__ idx,

@@ -106,10 +106,30 @@ class Physics:
         raise ValueError(collider.kind)
 
     def add_distance_constraint(self, a, b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), rest_length=None, compliance=0.0,
-                                limit=0):
-        """limit: 0 holds the length both ways, 1 (rope) only pulls, 2 (strut) only pushes."""
+                                limit=0, damping=0.0):
+        """limit: 0 holds the length both ways, 1 (rope) only pulls, 2 (strut) only pushes.
+        damping (1/s, two-sided constraints only) takes min(damping h, 1) of the rate of change of the length
+        away every substep."""
         self._b.distance(WORLD_BODY if a is None else a, WORLD_BODY if b is None else b, anchor_a, anchor_b,
-                         rest_length, compliance, limit)
+                         rest_length, compliance, limit, damping)
+
+    def add_attachment(self, a, b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), compliance=0.0, damping=0.0):
+        """Pin joint: the two body-local anchors (world position for None) are held together."""
+        self._b.attach(WORLD_BODY if a is None else a, WORLD_BODY if b is None else b, anchor_a, anchor_b, compliance, damping)
+
+    def add_angle_constraint(self, a, b, min_angle, max_angle, compliance=0.0, damping=0.0):
+        """Keeps angle(b) - angle(a) (None: the world, angle 0) inside [min_angle, max_angle];
+        min == max with a compliance is a torsion spring; damping (1/s) is a hinge damper."""
+        self._b.angle(WORLD_BODY if a is None else a, WORLD_BODY if b is None else b, min_angle, max_angle, compliance, damping)
+
+    def add_rope(self, start, end, links, radius=0.04, density=1.0, pin_start=True, pin_end=False, compliance=0.0,
+                 slack=0.0, material=None):
+        """Rope helper (the reference's rope builder): `links` small circle bodies from start to end tied by
+        one-sided links; returns their ids."""
+        if self._world is not None:
+            raise RuntimeError("add bodies before the first tick")
+        return self._b.rope(start, end, links, radius, density, pin_start, pin_end, compliance, slack,
+                            material=self._mat(material or Material()))
 
     def _ensure_world(self):
         if self._world is None:
@@ -140,6 +160,14 @@ class Physics:
         """Closest hit of origin + t * direction: (body, t, normal) or None."""
         h = self._ensure_world().query_rays([[origin[0], origin[1], direction[0], direction[1]]], max_t, layer_mask)[0]
         return None if h["body"] == 0xFFFFFFFF else (int(h["body"]), float(h["t"]), (float(h["normal"][0]), float(h["normal"][1])))
+
+    def tick_and_read(self, frame_dt):
+        """A render loop's frame: starts the read-back of the poses as they are now, runs the next tick while
+        they travel, and returns them as [n][4] = (x, y, cos, sin) (one frame behind the simulation)."""
+        w = self._ensure_world()
+        w.readback_begin()
+        w.step(frame_dt)
+        return w.readback_wait()
 
     def poses(self):
         pos, rot = self._world.poses()

@@ -10,7 +10,7 @@ import numpy as np
 
 from ._abi import (
     SHAPE_CAPSULE, SHAPE_CIRCLE, SHAPE_NONE, SHAPE_POLY, SHAPE_RECT, WORLD_BODY,
-    collider_dtype, constraint_dtype, material_dtype,
+    angle_constraint_dtype, collider_dtype, constraint_dtype, material_dtype,
 )
 
 _M64 = (1 << 64) - 1
@@ -44,6 +44,7 @@ class Scene:
     dt: float = 1.0 / 60.0
     gravity: tuple = (0.0, -9.81)
     aabb_margin: float = 0.01
+    angle_constraints: np.ndarray = field(default_factory=lambda: np.zeros(0, angle_constraint_dtype))
 
     @property
     def n(self):
@@ -85,6 +86,7 @@ class SceneBuilder:
         self.inv_mass, self.inv_inertia, self.col = [], [], []
         self.poly_pool = []
         self.constraints = []
+        self.angle_constraints = []
         self.materials = materials or [(0.1, 0.5, 0.4)]
 
     def _add(self, pos, angle, vel, angvel, mass, inertia, col):
@@ -143,12 +145,39 @@ class SceneBuilder:
     def static_rect(self, pos, hw, hh, angle=0.0, **kw):
         return self._add(pos, angle, (0, 0), 0.0, 0.0, 0.0, self._col(SHAPE_RECT, (hw, hh, 0.0), **kw))
 
-    def distance(self, a, b, anchor_a=(0, 0), anchor_b=(0, 0), rest=None, compliance=0.0, limit=0):
+    def distance(self, a, b, anchor_a=(0, 0), anchor_b=(0, 0), rest=None, compliance=0.0, limit=0, damping=0.0):
         if rest is None:
             pa = np.asarray(anchor_a, float) if a == WORLD_BODY else np.asarray(self.pos[a], float)
             pb = np.asarray(anchor_b, float) if b == WORLD_BODY else np.asarray(self.pos[b], float)
             rest = float(np.linalg.norm(pb - pa))
-        self.constraints.append((a, b, tuple(anchor_a), tuple(anchor_b), rest, compliance, limit, 0))
+        self.constraints.append((a, b, tuple(anchor_a), tuple(anchor_b), rest, compliance, limit, damping))
+
+    def attach(self, a, b, anchor_a=(0, 0), anchor_b=(0, 0), compliance=0.0, damping=0.0):
+        """Pin: holds the two anchors together (a distance constraint of rest length 0)."""
+        self.distance(a, b, anchor_a, anchor_b, rest=0.0, compliance=compliance, damping=damping)
+
+    def angle(self, a, b, min_angle, max_angle, compliance=0.0, damping=0.0):
+        """Keeps angle(b) - angle(a) inside [min_angle, max_angle]."""
+        self.angle_constraints.append((a, b, min_angle, max_angle, compliance, damping))
+
+    def rope(self, start, end, links, radius=0.04, density=1.0, pin_start=True, pin_end=False, compliance=0.0, slack=0.0, **kw):
+        """Rope helper: `links` circle bodies evenly spaced from start to end, neighbours tied by
+        one-sided (rope) distance links of the spacing's length (times 1 + slack); the ends optionally
+        pinned to the world.  Links of one rope do not collide with each other.  Returns the body ids."""
+        start, end = np.asarray(start, float), np.asarray(end, float)
+        group = kw.pop("group", 0x52000000 + len(self.pos))
+        ids = []
+        for k in range(links):
+            t = (k + 0.5) / links
+            ids.append(self.circle(tuple(start + t * (end - start)), radius, density=density, group=group, **kw))
+        seg = float(np.linalg.norm(end - start)) / links * (1.0 + slack)
+        for k in range(links - 1):
+            self.distance(ids[k], ids[k + 1], rest=seg, compliance=compliance, limit=1)
+        if pin_start:
+            self.distance(WORLD_BODY, ids[0], anchor_a=tuple(start), rest=0.5 * seg, compliance=compliance, limit=1)
+        if pin_end:
+            self.distance(ids[-1], WORLD_BODY, anchor_b=tuple(end), rest=0.5 * seg, compliance=compliance, limit=1)
+        return ids
 
     def build(self):
         n = len(self.pos)
@@ -159,6 +188,7 @@ class SceneBuilder:
             np.array(self.col, dtype=collider_dtype), np.array(self.materials, dtype=material_dtype),
             f(self.poly_pool, (len(self.poly_pool), 2)), np.array(self.constraints, dtype=constraint_dtype),
             substeps=self.substeps,
+            angle_constraints=np.array(self.angle_constraints, dtype=angle_constraint_dtype),
         )
 
 

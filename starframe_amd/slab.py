@@ -85,8 +85,8 @@ def default_halo(scene):
 
 def plan_slabs(scene, nranks, halo=None):
     """Cuts `scene` into `nranks` slabs.  Returns (plans, boundaries)."""
-    if scene.constraints is not None and len(scene.constraints):
-        raise ValueError("scenes with distance constraints are not decomposed (chains stay on one GPU)")
+    if (scene.constraints is not None and len(scene.constraints)) or len(getattr(scene, "angle_constraints", ())):
+        raise ValueError("scenes with constraints are not decomposed (chains stay on one GPU)")
     halo = default_halo(scene) if halo is None else float(halo)
     x = scene.pos[:, 0].astype(np.float64)
     dyn = (scene.inv_mass > 0) | (scene.inv_inertia > 0)

@@ -58,6 +58,11 @@ class WorldBase:
         con = np.ascontiguousarray(scene.constraints)
         self.m = len(con)
         self._check(self._f("upload_constraints")(self.handle, len(con), vptr(con)))
+        ang = np.ascontiguousarray(getattr(scene, "angle_constraints", ()))
+        if len(ang) or getattr(self, "m_angle", 0):
+            self._check(self._f("upload_angle_constraints")(self.handle, len(ang), vptr(ang)))
+        self.m_angle = len(ang)
+        self.m += len(ang)
         return self
 
     def set_state(self, pos, rot, vel, angvel, inv_mass, inv_inertia):
@@ -232,6 +237,19 @@ class World(WorldBase):
         n = C.c_size_t()
         self._check(self.lib.sfx_debug_contacts(self.handle, vptr(out), cap, C.byref(n)))
         return out[: min(n.value, cap)]
+
+    # ---- pose read-back that overlaps the next tick (rendering)
+    def readback_begin(self):
+        self._check(self.lib.sfx_readback_begin(self.handle))
+
+    def readback_wait(self, copy=True):
+        """Oldest read-back begun: [n][4] = (x, y, cos, sin).  copy=False returns a view of the library's pinned
+        buffer, valid until the second readback_begin after the one it belongs to."""
+        ptr = C.POINTER(C.c_float)()
+        n = C.c_uint32()
+        self._check(self.lib.sfx_readback_wait(self.handle, C.byref(ptr), C.byref(n)))
+        a = np.ctypeslib.as_array(ptr, shape=(n.value, 4)) if n.value else np.zeros((0, 4), np.float32)
+        return a.copy() if copy else a
 
     def joint_order(self):
         cap = max(self.m, 1)

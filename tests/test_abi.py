@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(libsfx):
     assert sorted(_abi.SFX_SYMBOLS) == syms, "starframe_amd/_abi.py symbol list out of date"
     for s in syms:
         assert hasattr(libsfx, s), f"libsfx.so does not export {s}"
-    assert libsfx.sfx_abi_version() == 6
+    assert libsfx.sfx_abi_version() == 7
 
 
 def test_struct_layouts_match_header():
@@ -37,10 +37,11 @@ def test_struct_layouts_match_header():
 #include <stddef.h>
 #include "sfx.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sfx_config), sizeof(sfx_collider),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sfx_config), sizeof(sfx_collider),
          sizeof(sfx_material), sizeof(sfx_distance_constraint), sizeof(sfx_contact), sizeof(sfx_frame_stats),
          sizeof(sfx_kernel_time), offsetof(sfx_config, flags), offsetof(sfx_frame_stats, color_count),
-         (size_t)SFX_K_CLASSES, sizeof(sfx_ray_hit));
+         (size_t)SFX_K_CLASSES, sizeof(sfx_ray_hit), sizeof(sfx_angle_constraint),
+         offsetof(sfx_distance_constraint, damping));
   return 0;
 }
 """
@@ -62,6 +63,8 @@ int main(void) {
     assert sizes[8] == _abi.SfxFrameStats.color_count.offset
     assert sizes[9] == _abi.K_CLASSES
     assert sizes[10] == _abi.ray_hit_dtype.itemsize
+    assert sizes[11] == _abi.angle_constraint_dtype.itemsize
+    assert sizes[12] == _abi.constraint_dtype.fields["damping"][1]
 
 
 def test_default_config(libsfx):

@@ -48,3 +48,62 @@ def test_cpp_host_api_example_builds_and_runs(tmp_path):
     sys.stdout.write(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ray from above hits body" in out.stdout
+
+
+def test_pose_readback_overlaps_the_next_tick():
+    """sfx_readback_begin / _wait (include/sfx.h): the snapshot is the state at begin, whatever is enqueued after
+    it; two may be in flight, a third is refused; a view stays valid until the second begin after its own."""
+    from starframe_amd import scenes
+    from starframe_amd.world import World
+
+    s = scenes.random_soup(3000, seed=11, extent=8.0)
+    w = World.from_scene(s)
+    for _ in range(3):
+        w.step(1.0 / 60.0)
+    pos0, rot0 = w.poses()
+    w.readback_begin()
+    for _ in range(2):
+        w.step(1.0 / 60.0)                       # overwrites the poses while the copy travels
+    pos2, rot2 = w.poses()
+    w.readback_begin()
+    with pytest.raises(Exception):
+        w.readback_begin()                       # two in flight already
+    a = w.readback_wait(copy=False)
+    assert a.shape == (s.n, 4)
+    assert np.array_equal(a[:, :2], pos0) and np.array_equal(a[:, 2:], rot0)
+    b = w.readback_wait(copy=False)
+    assert np.array_equal(b[:, :2], pos2) and np.array_equal(b[:, 2:], rot2)
+    assert not np.array_equal(pos0, pos2)
+    assert np.array_equal(a[:, :2], pos0)        # both views are live: the first one's slot is taken by the third begin
+    with pytest.raises(Exception):
+        w.readback_wait()                        # nothing begun
+    w.readback_begin()                           # the third begin reuses the first slot, not the second
+    w.readback_wait()
+    assert np.array_equal(b[:, :2], pos2)
+    # a frame loop: every frame's read-back equals the synchronous download taken at the same point
+    for _ in range(5):
+        want = np.concatenate(w.poses(), axis=1)
+        w.readback_begin()
+        w.step(1.0 / 60.0)
+        assert np.array_equal(w.readback_wait(), want)
+    w.close()
+
+
+def test_python_physics_api_joints_rope_and_frame_loop():
+    from starframe_amd.physics import Body, Collider, Physics, PhysicsConfig
+
+    ph = Physics(PhysicsConfig(substeps=8))
+    ph.add(Body.static(), Collider.rect(40.0, 1.0), (0.0, -3.0))
+    bar = ph.add(Body.dynamic(), Collider.rect(1.0, 0.1), (0.5, 2.0))
+    ph.add_attachment(None, bar, anchor_a=(0.0, 2.0), anchor_b=(-0.5, 0.0))
+    ph.add_angle_constraint(None, bar, -0.4, 0.3, damping=2.0)
+    rope = ph.add_rope((3.0, 2.0), (5.0, 2.0), links=16, pin_end=True, slack=0.25)
+    last = None
+    for _ in range(240):
+        last = ph.tick_and_read(1.0 / 60.0)
+    pos, ang = ph.poses()
+    assert abs(ang[bar] + 0.4) < 1e-2                                              # the bar rests on its lower stop
+    assert np.hypot(pos[bar, 0] - 0.5 * np.cos(ang[bar]), pos[bar, 1] - 2.0 - 0.5 * np.sin(ang[bar])) < 5e-3   # pinned
+    seg = np.linalg.norm(np.diff(pos[rope], axis=0), axis=1)
+    assert seg.max() < 0.125 * 1.25 * 1.01 and pos[rope, 1].min() < 1.6                    # taut links, hanging below the pins
+    assert last.shape == (len(pos), 4) and np.abs(last[:, :2] - pos).max() < 0.05   # one frame behind

@@ -222,6 +222,94 @@ def test_rope_links_match_oracle():
     assert abs(gp[tips, 1].mean() - op[tips, 1].mean()) < 0.1
 
 
+def hinged_scene(n_chains=10, links=12):
+    """Chains of bars hanging from the world: pins with offset anchors, angle stops between neighbours, hinge
+    dampers, a damped soft link across each chain, falling onto a floor."""
+    from starframe_amd._abi import WORLD_BODY
+    from starframe_amd.scenes import SceneBuilder
+
+    b = SceneBuilder("hinged", substeps=4)
+    b.static_rect((0.0, -4.0), 40.0, 0.5)
+    for c in range(n_chains):
+        x0, y0 = 1.3 * c - 6.0, 0.5 + 0.07 * c
+        ids = [b.rect((x0 + 0.3 * k + 0.15, y0), 0.13, 0.03, group=100 + c, angle=0.05 * ((k + c) % 3 - 1)) for k in range(links)]
+        b.attach(WORLD_BODY, ids[0], anchor_a=(x0, y0), anchor_b=(-0.15, 0.0), damping=2.0 if c % 2 else 0.0)
+        for k in range(links - 1):
+            b.attach(ids[k], ids[k + 1], anchor_a=(0.15, 0.0), anchor_b=(-0.15, 0.0), compliance=1e-6 if k % 4 == 3 else 0.0)
+            if (k + c) % 3 != 2:
+                b.angle(ids[k], ids[k + 1], -0.5, 0.7 if k % 2 else 0.5, compliance=1e-3 if k % 5 == 0 else 0.0,
+                        damping=3.0 if k % 2 else 0.0)
+        b.distance(ids[0], ids[-1], rest=0.3 * (links - 1), compliance=5e-3, damping=4.0)
+        b.angle(WORLD_BODY, ids[0], -0.3, 0.3)
+    return b.build()
+
+
+def test_hinged_links_match_oracle():
+    """Attachments with offset anchors, angle limits / torsion springs and joint damping (include/sfx.h
+    sfx_angle_constraint, sfx_distance_constraint.damping): joint order and colours equal, 1 and 5 ticks within
+    1e-5 (the deterministic atan2 is shared op for op), 150 ticks statistically."""
+    from oracle.oracle import ORDER_COLORED
+
+    s = hinged_scene()
+    g, o = make_pair(s)
+    gp, gc = g.joint_order()
+    op, oc = o.joint_order()
+    assert len(gp) == len(s.constraints) + len(s.angle_constraints)
+    assert np.array_equal(gp, op) and np.array_equal(gc, oc)
+    for ticks in (1, 4):
+        for _ in range(ticks):
+            g.step(DT)
+            o.step(DT, ORDER_COLORED)
+        assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= TOL
+        assert rel_err(g.poses()[1], o.poses()[1], floor=1.0) <= TOL
+        assert rel_err(g.velocities()[0], o.velocities()[0], floor=1.0) <= 1e-4
+        assert rel_err(g.velocities()[1], o.velocities()[1], floor=1.0) <= 1e-3
+    for _ in range(150):
+        g.step(DT)
+        o.step(DT, ORDER_COLORED)
+    (gpos, grot), (opos, orot) = g.poses(), o.poses()
+    assert np.isfinite(gpos).all()
+    assert abs(gpos[1:, 1].mean() - opos[1:, 1].mean()) < 0.05
+    # every angle stop holds on both sides
+    for pos, rot in ((gpos, grot), (opos, orot)):
+        th = np.arctan2(rot[:, 1], rot[:, 0])
+        a = s.angle_constraints
+        rigid = (a["compliance"] == 0) & (a["body_a"] != 0xFFFFFFFF)
+        rel = th[a["body_b"][rigid]] - th[a["body_a"][rigid]]
+        rel = (rel + np.pi) % (2 * np.pi) - np.pi
+        assert (rel > a["min_angle"][rigid] - 0.05).all() and (rel < a["max_angle"][rigid] + 0.05).all()
+
+
+def test_constraint_validation_through_the_abi():
+    from starframe_amd._abi import WORLD_BODY
+    from starframe_amd.scenes import SceneBuilder
+    from starframe_amd.world import World
+
+    for bad in (dict(limit=1, damping=1.0), dict(damping=-1.0), dict(limit=3)):
+        b = SceneBuilder("bad")
+        b.circle((0.0, 0.0), 0.1)
+        b.circle((1.0, 0.0), 0.1)
+        b.distance(0, 1, **bad)
+        with pytest.raises(Exception):
+            World.from_scene(b.build())
+    for lo, hi in ((0.5, 0.2), (-4.0, 0.0), (0.0, 3.2)):
+        b = SceneBuilder("bad")
+        b.circle((0.0, 0.0), 0.1)
+        b.angle(WORLD_BODY, 0, lo, hi)
+        with pytest.raises(Exception):
+            World.from_scene(b.build())
+    # the two arrays are independent: uploading one keeps the other
+    s = hinged_scene(2, 4)
+    w = World.from_scene(s)
+    n_all = len(w.joint_order()[0])
+    assert n_all == len(s.constraints) + len(s.angle_constraints)
+    w._check(w._f("upload_constraints")(w.handle, 0, None))
+    w.m = n_all
+    assert len(w.joint_order()[0]) == len(s.angle_constraints)
+    w.step(DT)
+    assert np.isfinite(w.poses()[0]).all()
+
+
 def test_empty_and_tiny_worlds():
     from starframe_amd.scenes import SceneBuilder
     from starframe_amd.world import World
