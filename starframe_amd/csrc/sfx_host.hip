@@ -722,7 +722,9 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     ALLOC(w, w->rawp, w->max_pairs); ALLOC(w, w->tpair, w->max_pairs); ALLOC(w, w->torder, w->max_pairs);
     ALLOC(w, w->done, 2 * (size_t)w->ntiles);
     ALLOC(w, w->bruns, 64 * (size_t)w->ntiles);  // a batch holds at least one tile
-    ALLOC(w, w->bbody, 4 * (size_t)n + 16);  // a collider lies in at most four tile blocks
+    // a collider lies in at most four tile blocks; plus the outside (large) colliders of each batch: at most kMaxExt per
+    // batch, one kept pair each at least
+    ALLOC(w, w->bbody, 4 * (size_t)n + 16 + std::min<size_t>((size_t)kMaxExt * w->ntiles, w->max_pairs));
     HIPCHK(w, hipMemset(w->done.p, 0, sizeof(uint32_t) * 2 * (size_t)w->ntiles));
     ALLOC(w, w->fpairs, w->fb_cap); ALLOC(w, w->fsorted, w->fb_cap);
     const size_t mc = std::max<size_t>(w->fb_cap, w->m);
@@ -1244,7 +1246,7 @@ int sfx_sync(sfx_world* w) {
     HIPCHK(w, hipStreamSynchronize(w->stream));
     poll_counters(w);
     if (w->ctr_valid && w->stale.overflow)
-        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list, 32 a fused solve launch gave up waiting)",
+        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list, 32 a fused solve launch gave up waiting, 64 more than 64 large colliders over one batch of tiles)",
                     w->stale.overflow);
     return SFX_OK;
 }

@@ -32,10 +32,12 @@ constexpr int kTileThreads = SFX_TILE_THREADS;      // workgroup of the tile sol
 constexpr uint32_t kBatchP = kMaxP;                 // pairs of a batch of tiles
 constexpr int kMaxGroup = 16;                       // tiles per batch at most
 constexpr uint32_t kExt = 0xFFFFu;                  // local index of a body outside the block (large static)
+constexpr uint32_t kMaxExt = 64;                    // distinct outside bodies a batch can hold in LDS behind its block bodies
+constexpr uint32_t kMaxBX = kMaxB + kMaxExt;        // LDS body slots of a tile solve
 constexpr int kScanItems = 16;                      // items per thread in the block scan
 constexpr int kScanTile = kBlock * kScanItems;      // 4096 items per block
 constexpr uint32_t kLeftCap = 4096;                 // leftover edges the serial finish takes
-constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u, kOvfFallback = 16u, kOvfStall = 32u;
+constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u, kOvfFallback = 16u, kOvfStall = 32u, kOvfExt = 64u;
 
 // stage timing of the tile kernels and the colouring (development builds with -DSFX_TILE_TIMING; `T.dbg` or `dbg` in scope)
 #ifdef SFX_TILE_TIMING
@@ -753,6 +755,7 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
     __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat, s_npruned, s_ptail, s_ptail_first;
     __shared__ uint32_t s_cls[4];
     __shared__ uint32_t s_bidx, s_boff;
+    __shared__ uint32_t s_ext[kMaxExt], s_next;  // large colliders outside the block that the batch's pairs touch
     __shared__ BatchRanges S;
     __shared__ uint32_t s_tile[kMaxGroup], s_tnb[kMaxGroup], s_tnp[kMaxGroup], s_tstart[kMaxGroup];
     __shared__ uint32_t s_bfirst[kMaxGroup + 1], s_poff[kMaxGroup + 1];
@@ -797,15 +800,14 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                 for (uint32_t j = 0; j < c; ++j) { s_poff[j] = run; run += s_tnp[f + j]; }
                 s_poff[c] = run;
                 s_nleft = 0u; s_ovf = 0u; s_npruned = 0u;
-                s_boff = atomicAdd(&ctr->body_cursor, min(S.off[4u * c], MB));  // the batch's body list (never more than 4 per collider in all)
             }
+            if (tid < kMaxExt) s_ext[tid] = 0xFFFFFFFFu;
             if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
             if (tid < 4) s_cls[tid] = 0u;
             __syncthreads();
             const uint32_t nb = min(S.off[4u * c], MB), np = min(s_poff[c], MP);
             for (uint32_t l = tid; l < nb; l += kBlock) {
                 const uint32_t gid = sorted_id[batch_slot(S, 4u * c, l)];
-                if (s_boff + l < bbody_cap) bbody[s_boff + l] = gid;  // the tile solves load their bodies from this list
                 s_dyn[l] = (uint8_t)(filt[gid].w != 0u);
                 s_used[l] = 0ull;
 #pragma unroll
@@ -824,8 +826,30 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                 s_col[e] = keep ? SFX_NO_COLOR : SFX_PRUNED_COLOR;
                 if (!keep) atomicAdd(&s_npruned, 1u);
                 open_edges |= keep ? 1 : 0;
+                if (keep && (s_la[e] == kExt || s_lb[e] == kExt)) {  // an end outside the block: give it an LDS slot of the solves
+                    const uint32_t id = s_la[e] == kExt ? rp.x : rp.y;
+                    uint32_t k = 0;
+                    for (; k < kMaxExt; ++k) {
+                        const uint32_t old = atomicCAS(&s_ext[k], 0xFFFFFFFFu, id);
+                        if (old == 0xFFFFFFFFu || old == id) break;
+                    }
+                    if (k == kMaxExt) atomicOr(&s_ovf, 2u);  // more outside bodies than slots: the pair is dropped, the tick reports it
+                }
             }
             int any_open = __syncthreads_or(open_edges);
+            if (tid < 64u) {  // the batch's body list: block bodies, then the outside bodies (filled from slot 0 on)
+                static_assert(kMaxExt == 64, "one lane per slot");
+                const unsigned long long have = __ballot(s_ext[tid] != 0xFFFFFFFFu);
+                const uint32_t next = (uint32_t)__popcll(have);
+                uint32_t boff = 0u;
+                if (tid == 0) boff = atomicAdd(&ctr->body_cursor, nb + next);
+                boff = (uint32_t)__shfl((int)boff, 0, 64);
+                if (tid == 0) { s_boff = boff; s_next = next; }
+                if (tid < next && boff + nb + tid < bbody_cap) bbody[boff + nb + tid] = s_ext[tid];
+            }
+            __syncthreads();
+            for (uint32_t l = tid; l < nb; l += kBlock)  // the tile solves load their bodies from this list
+                if (s_boff + l < bbody_cap) bbody[s_boff + l] = sorted_id[batch_slot(S, 4u * c, l)];
             SFX_TT(tc1);
 #define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
             for (uint32_t r = 0; r < rounds && any_open; ++r) {  // everything coloured: later rounds would do nothing
@@ -835,7 +859,7 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                     const uint32_t la = s_la[e], lb = s_lb[e];
                     const bool da = TDYN(la), db = TDYN(lb);
                     const unsigned long long freem = ~((da ? s_used[la] : 0ull) | (db ? s_used[lb] : 0ull));
-                    if (freem == 0ull) { s_prop[e] = SFX_NO_COLOR; s_ovf = 1u; continue; }
+                    if (freem == 0ull) { s_prop[e] = SFX_NO_COLOR; atomicOr(&s_ovf, 1u); continue; }
                     const uint32_t cc = (uint32_t)__builtin_ctzll(freem);  // first fit
                     const uint32_t h = edge_hash(s_a[e], s_b[e], r);
                     s_prop[e] = (uint8_t)cc;
@@ -888,7 +912,7 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                         const uint32_t e = s_srt[q], la = s_la[e], lb = s_lb[e];
                         const bool da = TDYN(la), db = TDYN(lb);
                         const unsigned long long freem = ~((da ? s_used[la] : 0ull) | (db ? s_used[lb] : 0ull));
-                        if (freem == 0ull) { s_ovf = 1u; continue; }  // stays uncoloured: dropped from the solve
+                        if (freem == 0ull) { s_ovf |= 1u; continue; }  // stays uncoloured: dropped from the solve
                         const uint32_t cc = (uint32_t)__builtin_ctzll(freem);
                         s_col[e] = (uint8_t)cc;
                         if (da) s_used[la] |= 1ull << cc;
@@ -931,12 +955,13 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                 const uint32_t ph = (t0 & 1u) | (((t0 >> lx) & 1u) << 1);
                 BatchDesc d;
                 d.first = e0 + f;
-                d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nb; d.boff = s_boff; d.roff = roff;
+                d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nb + s_next; d.boff = s_boff; d.roff = roff;
                 const uint32_t bidx = atomicAdd(&ctr->n_batches[ph], 1u);
                 batches[ph * g.pstride + bidx] = d;
                 s_bidx = bidx;
                 atomicMax(&ctr->n_colors, nc);
-                if (s_ovf) atomicOr(&ctr->overflow, kOvfColors);
+                if (s_ovf & 1u) atomicOr(&ctr->overflow, kOvfColors);
+                if (s_ovf & 2u) atomicOr(&ctr->overflow, kOvfExt);
               }
             }
             if (tid < SFX_MAX_COLORS && s_hist[tid]) atomicAdd(&ctr->color_count[tid], s_hist[tid]);
@@ -964,7 +989,14 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                 const uint32_t cc = s_col[e];
                 const uint32_t dst = (cc < SFX_MAX_COLORS) ? atomicAdd(&s_base[cc], 1u)
                                      : (cc == SFX_PRUNED_COLOR) ? atomicAdd(&s_ptail, 1u) : atomicAdd(&s_nleft, 1u);
-                const uint32_t la = s_la[e], lb = s_lb[e];
+                uint32_t la = s_la[e], lb = s_lb[e];
+                if ((la == kExt || lb == kExt) && cc != SFX_PRUNED_COLOR) {  // the outside end's LDS slot (kExt stays when there was none left)
+                    const uint32_t id = la == kExt ? s_a[e] : s_b[e];
+                    uint32_t k = 0;
+                    while (k < s_next && s_ext[k] != id) ++k;
+                    const uint32_t lx = k < s_next ? nb + k : kExt;
+                    if (la == kExt) la = lx; else lb = lx;
+                }
                 tpair[bstart + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), cc | (s_tile[f + s_tj[e]] << 8));
                 if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_prop[e]], 1u)] = bstart + dst;
             }
@@ -1326,11 +1358,11 @@ struct RawSlot {
 template <bool VEL>
 __device__ __forceinline__ void fetch_raw(const TileArrays& T, const ContactArrays& C, uint32_t slot, bool in_range,
                                           RawSlot& q) {
+    // lanes past the end of the run load slot 0 (always there) and ignore it: no branch around the loads, so
+    // nothing has to wait for them before the pair's colour comes up
     q.in_range = in_range;
+    slot = in_range ? slot : 0u;
     q.lam = make_float2(0.0f, 0.0f);
-    q.pr = make_uint4(0, 0, 0, SFX_NO_COLOR);
-    q.hdr = make_float4(0.0f, 0.0f, 0.0f, 0.0f); q.a0 = q.hdr; q.a1 = q.hdr; q.m = q.hdr;
-    if (!in_range) return;
     const float4* line = C.rec + 4u * (size_t)slot;
     q.pr = T.tpair[slot];
     q.m = line[3];
@@ -1341,12 +1373,13 @@ __device__ __forceinline__ void fetch_raw(const TileArrays& T, const ContactArra
 }
 
 template <bool VEL>
-__device__ __forceinline__ void decode_raw(const RawSlot& q, PairSlot& p) {
+__device__ __forceinline__ void decode_raw(const RawSlot& q, PairSlot& p, uint32_t nb) {
     p.valid = false;
     p.r.count = 0;
     p.e = pair_ends(q.pr);
     const int count = (int)__float_as_uint(q.m.y);
     if (!q.in_range || count == 0) return;
+    if (p.e.la >= nb || p.e.lb >= nb) return;  // an outside body that found no LDS slot (kOvfExt was reported)
     if (VEL && !(q.lam.x + q.lam.y > 0.0f)) return;  // nothing was pushed: nothing to do in the velocity pass
     PairRec& r = p.r;
     r.count = count; r.rest = q.m.x;
@@ -1361,10 +1394,10 @@ __device__ __forceinline__ void decode_raw(const RawSlot& q, PairSlot& p) {
 
 template <bool VEL>
 __device__ __forceinline__ void fetch_pair(const TileArrays& T, const ContactArrays& C, uint32_t slot, bool in_range,
-                                           PairSlot& p) {
+                                           PairSlot& p, uint32_t nb) {
     RawSlot q;
     fetch_raw<VEL>(T, C, slot, in_range, q);
-    decode_raw<VEL>(q, p);
+    decode_raw<VEL>(q, p, nb);
 }
 
 // Workgroup barrier for steps that hand data over through LDS only: waits for the LDS traffic,
@@ -1474,9 +1507,10 @@ template <int NT>
 __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   float max_corr) {
-    __shared__ float4 s_pose[kMaxB];
-    __shared__ float2 s_mass[kMaxB];
-    __shared__ uint32_t s_gid[kMaxB];
+    __shared__ float4 s_pose[kMaxBX];
+    __shared__ float2 s_mass[kMaxBX];
+    __shared__ uint32_t s_gid[kMaxBX];
+    __shared__ float2 s_lam[kBatchP];  // the batch's multipliers, written out in one coalesced pass after the colours
     __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
     const uint32_t tid = threadIdx.x;
     const __amdgpu_buffer_rsrc_t pose_rs = record_rsrc(B.pose);
@@ -1490,14 +1524,15 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
         SFX_TT(ttw);
         SFX_TT_ADD(6, tt0, ttw);
-        const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, ncol = d.ncol;
+        const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol, npb = min(d.np, kBatchP);
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
-        for (uint32_t l = tid; l < nb; l += NT) {
+        for (uint32_t l = tid; l < nb; l += NT) {  // block bodies, then the large colliders outside the block its pairs touch
             const uint32_t gid = T.bbody[d.boff + l];
             s_gid[l] = gid;
             s_pose[l] = B.pose[gid];
             s_mass[l] = B.mass[gid];
         }
+        for (uint32_t k = tid; k < npb; k += NT) s_lam[k] = make_float2(0.0f, 0.0f);
         if (tid < SFX_MAX_COLORS) {  // the colour runs of the batch's pair list, tabulated by k_batch_color
             const uint32_t v = T.bruns[64u * d.roff + tid];
             s_cs[tid] = v & 0xFFFFu; s_ce[tid] = v >> 16;
@@ -1505,38 +1540,38 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         __syncthreads();
         SFX_TT(tt1);
         SFX_TT(tt2);
-        auto solve = [&](uint32_t slot, PairSlot& p) {
+        auto solve = [&](uint32_t k, PairSlot& p) {  // everything from LDS: no memory wait inside a colour step
             const PairEnds& e = p.e;
-            const bool ea = e.la == kExt, eb = e.lb == kExt;
-            float4 pa = ea ? B.pose[e.a] : s_pose[e.la];
-            float4 pb = eb ? B.pose[e.b] : s_pose[e.lb];
-            const float2 wa = ea ? B.mass[e.a] : s_mass[e.la];
-            const float2 wb = eb ? B.mass[e.b] : s_mass[e.lb];
+            float4 pa = s_pose[e.la];
+            float4 pb = s_pose[e.lb];
+            const float2 wa = s_mass[e.la];
+            const float2 wb = s_mass[e.lb];
             if (solve_pos_rec(p.r, pa, wa, pb, wb, max_corr)) {
-                if (!ea && (wa.x > 0.0f || wa.y > 0.0f)) s_pose[e.la] = pa;
-                if (!eb && (wb.x > 0.0f || wb.y > 0.0f)) s_pose[e.lb] = pb;
+                if (wa.x > 0.0f || wa.y > 0.0f) s_pose[e.la] = pa;
+                if (wb.x > 0.0f || wb.y > 0.0f) s_pose[e.lb] = pb;
             }
-            C.lam[slot] = make_float2(p.r.l0, p.r.l1);
+            s_lam[k] = make_float2(p.r.l0, p.r.l1);
         };
         RawSlot nxt;
         fetch_raw<false>(T, C, start + s_cs[0] + tid, ncol > 0 && s_cs[0] + tid < s_ce[0], nxt);
         for (uint32_t c = 0; c < ncol; ++c) {
             PairSlot cur;
-            decode_raw<false>(nxt, cur);
+            decode_raw<false>(nxt, cur, nb);
             const uint32_t k0 = s_cs[c] + tid, ce = s_ce[c];
             {   // the next colour's pair, in flight while this one is solved
                 const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
                 fetch_raw<false>(T, C, start + s_cs[c1] + tid, c + 1u < ncol && s_cs[c1] + tid < s_ce[c1], nxt);
             }
-            if (cur.valid) solve(start + k0, cur);
+            if (cur.valid) solve(k0, cur);
             for (uint32_t k = k0 + NT; k < ce; k += NT) {  // colour runs longer than the workgroup (rare)
                 PairSlot more;
-                fetch_pair<false>(T, C, start + k, true, more);
-                if (more.valid) solve(start + k, more);
+                fetch_pair<false>(T, C, start + k, true, more, nb);
+                if (more.valid) solve(k, more);
             }
             lds_barrier();
         }
         __syncthreads();
+        for (uint32_t k = tid; k < npb; k += NT) C.lam[start + k] = s_lam[k];
         SFX_TT(tt3);
         SFX_TT_ADD(1, tt1, tt2); SFX_TT_ADD(2, tt2, tt3); SFX_TT_ADD(5, 0ull, (unsigned long long)ncol);
         if (nph > 1u) {  // fused phases: later batches of this launch read these poses
@@ -1563,10 +1598,10 @@ template <int NT>
 __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   StepParams sp) {
-    __shared__ float4 s_pose[kMaxB];
-    __shared__ float4 s_vel[kMaxB];
-    __shared__ float2 s_mass[kMaxB];
-    __shared__ uint32_t s_gid[kMaxB];
+    __shared__ float4 s_pose[kMaxBX];
+    __shared__ float4 s_vel[kMaxBX];
+    __shared__ float2 s_mass[kMaxBX];
+    __shared__ uint32_t s_gid[kMaxBX];
     __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
     __shared__ uint32_t s_shift;
     const uint32_t tid = threadIdx.x;
@@ -1583,7 +1618,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         SFX_TT(tv0);
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
         SFX_TT(tvw);
-        const uint32_t nb = min(d.nb, kMaxB), start = d.bstart, ncol = d.ncol;
+        const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol;
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
         if (tid == 0) s_shift = 0u;
         if (tid < SFX_MAX_COLORS) {
@@ -1601,14 +1636,13 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         SFX_TT(tv1);
         auto solve = [&](const PairSlot& p) {
             const PairEnds& e = p.e;
-            const bool ea = e.la == kExt, eb = e.lb == kExt;
-            float4 pa = ea ? B.pose[e.a] : s_pose[e.la], va = ea ? B.vel[e.a] : s_vel[e.la];
-            float4 pb = eb ? B.pose[e.b] : s_pose[e.lb], vb = eb ? B.vel[e.b] : s_vel[e.lb];
-            const float2 wa = ea ? B.mass[e.a] : s_mass[e.la], wb = eb ? B.mass[e.b] : s_mass[e.lb];
+            float4 pa = s_pose[e.la], va = s_vel[e.la];
+            float4 pb = s_pose[e.lb], vb = s_vel[e.lb];
+            const float2 wa = s_mass[e.la], wb = s_mass[e.lb];
             const int ch = solve_vel_rec(p.r, pa, va, wa, pb, vb, wb, sp);
             if (ch) {
-                if (!ea && (wa.x > 0.0f || wa.y > 0.0f)) { s_vel[e.la] = va; if (ch & 2) s_pose[e.la] = pa; }
-                if (!eb && (wb.x > 0.0f || wb.y > 0.0f)) { s_vel[e.lb] = vb; if (ch & 2) s_pose[e.lb] = pb; }
+                if (wa.x > 0.0f || wa.y > 0.0f) { s_vel[e.la] = va; if (ch & 2) s_pose[e.la] = pa; }
+                if (wb.x > 0.0f || wb.y > 0.0f) { s_vel[e.lb] = vb; if (ch & 2) s_pose[e.lb] = pb; }
                 if (ch & 2) s_shift = 1u;
             }
         };
@@ -1616,7 +1650,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         fetch_raw<true>(T, C, start + s_cs[0] + tid, ncol > 0 && s_cs[0] + tid < s_ce[0], nxt);
         for (uint32_t c = 0; c < ncol; ++c) {
             PairSlot cur;
-            decode_raw<true>(nxt, cur);
+            decode_raw<true>(nxt, cur, nb);
             const uint32_t k0 = s_cs[c] + tid, ce = s_ce[c];
             {
                 const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
@@ -1625,7 +1659,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
             if (cur.valid) solve(cur);
             for (uint32_t k = k0 + NT; k < ce; k += NT) {
                 PairSlot more;
-                fetch_pair<true>(T, C, start + k, true, more);
+                fetch_pair<true>(T, C, start + k, true, more, nb);
                 if (more.valid) solve(more);
             }
             lds_barrier();
