@@ -1521,15 +1521,15 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         const uint32_t ph = pi.ph, it = pi.it;
         const BatchDesc d = T.batches[ph * g.pstride + it];
         const uint32_t* tiles = T.active + ph * g.pstride + d.first;
-        if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
-        SFX_TT(ttw);
-        SFX_TT_ADD(6, tt0, ttw);
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol, npb = min(d.np, kBatchP);
+        // everything that no earlier phase of this launch writes is fetched before waiting for them: the records of
+        // the first colour (it starts the batch's list), the body ids, the masses, the colour runs
+        RawSlot nxt;
+        fetch_raw<false>(T, C, start + tid, start + tid < T.max_pairs, nxt);
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
         for (uint32_t l = tid; l < nb; l += NT) {  // block bodies, then the large colliders outside the block its pairs touch
             const uint32_t gid = T.bbody[d.boff + l];
             s_gid[l] = gid;
-            s_pose[l] = B.pose[gid];
             s_mass[l] = B.mass[gid];
         }
         for (uint32_t k = tid; k < npb; k += NT) s_lam[k] = make_float2(0.0f, 0.0f);
@@ -1537,7 +1537,12 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
             const uint32_t v = T.bruns[64u * d.roff + tid];
             s_cs[tid] = v & 0xFFFFu; s_ce[tid] = v >> 16;
         }
+        if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
+        SFX_TT(ttw);
+        SFX_TT_ADD(6, tt0, ttw);
+        for (uint32_t l = tid; l < nb; l += NT) s_pose[l] = B.pose[s_gid[l]];  // (the lane that stored s_gid[l])
         __syncthreads();
+        nxt.in_range = ncol > 0u && tid < s_ce[0];
         SFX_TT(tt1);
         SFX_TT(tt2);
         auto solve = [&](uint32_t k, PairSlot& p) {  // everything from LDS: no memory wait inside a colour step
@@ -1552,8 +1557,6 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
             }
             s_lam[k] = make_float2(p.r.l0, p.r.l1);
         };
-        RawSlot nxt;
-        fetch_raw<false>(T, C, start + s_cs[0] + tid, ncol > 0 && s_cs[0] + tid < s_ce[0], nxt);
         for (uint32_t c = 0; c < ncol; ++c) {
             PairSlot cur;
             decode_raw<false>(nxt, cur, nb);
@@ -1616,9 +1619,9 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         const BatchDesc d = T.batches[ph * g.pstride + it];
         const uint32_t* tiles = T.active + ph * g.pstride + d.first;
         SFX_TT(tv0);
-        if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
-        SFX_TT(tvw);
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol;
+        RawSlot nxt;  // as in k_tile_pos: what earlier phases do not write is fetched before waiting for them
+        fetch_raw<true>(T, C, start + tid, start + tid < T.max_pairs, nxt);
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
         if (tid == 0) s_shift = 0u;
         if (tid < SFX_MAX_COLORS) {
@@ -1628,11 +1631,17 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         for (uint32_t l = tid; l < nb; l += NT) {
             const uint32_t gid = T.bbody[d.boff + l];
             s_gid[l] = gid;
-            s_pose[l] = B.pose[gid];
-            s_vel[l] = B.vel[gid];
             s_mass[l] = B.mass[gid];
         }
+        if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
+        SFX_TT(tvw);
+        for (uint32_t l = tid; l < nb; l += NT) {
+            const uint32_t gid = s_gid[l];
+            s_pose[l] = B.pose[gid];
+            s_vel[l] = B.vel[gid];
+        }
         __syncthreads();
+        nxt.in_range = ncol > 0u && tid < s_ce[0];
         SFX_TT(tv1);
         auto solve = [&](const PairSlot& p) {
             const PairEnds& e = p.e;
@@ -1646,8 +1655,6 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
                 if (ch & 2) s_shift = 1u;
             }
         };
-        RawSlot nxt;
-        fetch_raw<true>(T, C, start + s_cs[0] + tid, ncol > 0 && s_cs[0] + tid < s_ce[0], nxt);
         for (uint32_t c = 0; c < ncol; ++c) {
             PairSlot cur;
             decode_raw<true>(nxt, cur, nb);
