@@ -138,6 +138,11 @@ def main():
                     help="rehearse the N > 1 code path (slab driver over torch.distributed nccl) with one rank")
     args = ap.parse_args()
     rank, local_rank, world = dist_env()
+    # stdout carries the one JSON line and nothing else: what libraries print to file descriptor 1 (RCCL's version
+    # banner at communicator creation) goes to stderr until the line is printed
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus and world > 1:
         raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
 
@@ -287,6 +292,8 @@ def main():
     w.close()
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(scene)
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
