@@ -77,4 +77,41 @@ sl = DistSlab(s, World, dist, device_index=0)
 timed("f DistSlab.step", sl.world, lambda: sl.step(bench.DT))
 print("stats", sl.world.stats().n_pairs, sl.world.stats().n_manifolds, sl.world.stats().n_colors)
 sl.close()
+
+# (g) the exchange mechanism itself: 2 x 1500 bodies sent from rank 0 to itself over RCCL every substep
+# (received into the same bodies, so the physics does not change): pack, send/recv, unpack on the world's stream
+import numpy as np
+from starframe_amd.slab import _DeviceArray
+
+w = World.from_scene(s)
+stream = torch.cuda.Stream()
+w.set_stream(stream.cuda_stream)
+idx = np.arange(2000, 5000, dtype=np.uint32)
+w.halo_set(idx, idx)
+sp, rp = w.halo_buffer_pointers()
+send = torch.as_tensor(_DeviceArray(sp, 8 * len(idx)), device="cuda")
+recv = torch.as_tensor(_DeviceArray(rp, 8 * len(idx)), device="cuda")
+h = 8 * 1500
+
+
+def exch_step(pack_only=False):
+    w.tick_begin(bench.DT)
+    for _ in range(s.substeps):
+        w.tick_substep()
+        w.halo_pack()
+        if not pack_only:
+            ops = [dist.P2POp(dist.isend, send[:h], 0), dist.P2POp(dist.irecv, recv[:h], 0),
+                   dist.P2POp(dist.isend, send[h:], 0), dist.P2POp(dist.irecv, recv[h:], 0)]
+            with torch.cuda.stream(stream):
+                for wk in dist.batch_isend_irecv(ops):
+                    wk.wait()
+        else:
+            with torch.cuda.stream(stream):
+                recv.copy_(send)
+        w.halo_unpack()
+
+
+timed("g0 pack + copy + unpack per substep", w, lambda: exch_step(True))
+timed("g self send/recv 2 x 1500 bodies", w, exch_step)
+w.close()
 dist.destroy_process_group()

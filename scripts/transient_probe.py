@@ -1,13 +1,13 @@
 """ms/tick and pair counts in windows of 20 ticks after the settled pile is restarted without damping."""
-import sys, time
+import os, sys, time
 sys.path.insert(0, ".")
 import bench
 from starframe_amd import scenes
 from starframe_amd.world import World
-s = bench.settle(scenes.mixed_pile(n=100000), 0, frames=600)
+s = bench.settle(scenes.mixed_pile(n=100000), 0, frames=int(os.environ.get("FRAMES", "600")))
 w = World.from_scene(s)
 w.sync()
-for k in range(24):
+for k in range(int(os.environ.get("WINDOWS", "24"))):
     t0 = time.perf_counter()
     for _ in range(20):
         w.step(bench.DT)

@@ -41,10 +41,24 @@ def main():
     w.halo_unpack()                   # body idx[::-1][k] <- state of body idx[k]
     pos2, _ = w.poses()
     assert np.array_equal(pos2[idx[::-1]], pos[idx]), "unpack did not read what torch wrote"
-    w.close()
 
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
+        # the exchange DistSlab runs between ranks, here from rank 0 to itself: RCCL send/recv straight
+        # from / into the library's buffers on the world's stream, ordered between pack and unpack
+        for _ in range(3):
+            w.step(DT)
+        w.halo_pack()
+        w.sync()
+        sent = send.cpu().numpy().reshape(-1, 8).copy()
+        with torch.cuda.stream(stream):
+            for work in dist.batch_isend_irecv([dist.P2POp(dist.isend, send, 0), dist.P2POp(dist.irecv, recv, 0)]):
+                work.wait()
+        w.halo_unpack()
+        pos3, _ = w.poses()
+        assert np.array_equal(pos3[idx[::-1]], sent[:, 0:2]), "RCCL self send/recv did not carry the packed halo"
+        w.close()
+
         slab = DistSlab(s, World, dist, device_index=0)
         ref = World.from_scene(s)
         assert slab.on_device
