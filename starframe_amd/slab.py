@@ -140,6 +140,22 @@ def plan_slabs(scene, nranks, halo=None):
     return plans, bounds
 
 
+def slab_counts(x, bounds, nranks):
+    """How many of the bodies at `x` lie in each slab of `bounds` now (the per-frame count exchange)."""
+    o = np.clip(np.searchsorted(bounds, np.asarray(x, np.float64), side="right") - 1, 0, nranks - 1)
+    return np.bincount(o, minlength=nranks).astype(np.int64)
+
+
+def needs_replan(counts, moved, halo, tol):
+    """Re-cut when the slabs' populations differ by more than `tol` of the mean (10 %) or
+    when a body has moved so far on x since the cut that the ghost lists may miss a contact: a body that
+    was not ghosted lay more than `halo` = 4 r_max + pads beyond the boundary and touches nothing further
+    than 2 r_max away, so the lists are good while no body has moved more than a quarter of the halo."""
+    mean = counts.sum() / max(len(counts), 1)
+    imbalance = float(counts.max() / mean - 1.0) if mean > 0 else 0.0
+    return imbalance > tol or moved > 0.25 * halo, imbalance
+
+
 def local_scene(scene, plan):
     s = scene.subset(plan.ids, name=f"{scene.name}_slab{plan.rank}")
     return s
@@ -149,13 +165,38 @@ class LocalSlabs:
     """All slabs of a scene in one process: logical slabs on one GPU (device-to-device halo
     copies) or on any engine with halo_get / halo_put (host copies)."""
 
-    def __init__(self, scene, nslabs, engine, halo=None, **cfg_kw):
+    def __init__(self, scene, nslabs, engine, halo=None, rebalance_every=0, imbalance_tol=0.10, **cfg_kw):
+        self.engine, self.nslabs, self.cfg_kw = engine, nslabs, cfg_kw
+        self.halo = default_halo(scene) if halo is None else float(halo)
+        self.rebalance_every, self.imbalance_tol = int(rebalance_every), float(imbalance_tol)
+        self.frames = self.replans = 0
+        self.worlds = []
+        self._build(scene)
+
+    def _build(self, scene):
         self.scene = scene
-        self.plans, self.bounds = plan_slabs(scene, nslabs, halo)
-        self.worlds = [engine.from_scene(local_scene(scene, p), **cfg_kw) for p in self.plans]
+        self.plans, self.bounds = plan_slabs(scene, self.nslabs, self.halo)
+        self.worlds = [self.engine.from_scene(local_scene(scene, p), **self.cfg_kw) for p in self.plans]
         for w, p in zip(self.worlds, self.plans):
             w.halo_set(p.send_idx, p.recv_idx)
         self.device_copies = all(hasattr(w, "halo_copy_from") for w in self.worlds)
+
+    def rebalance(self, force=False):
+        """Count exchange + migration, all slabs in one process: see DistSlab.rebalance."""
+        counts, moved = np.zeros(self.nslabs, np.int64), 0.0
+        for w, p in zip(self.worlds, self.plans):
+            x = w.poses()[0][:p.n_owned, 0]
+            counts += slab_counts(x, self.bounds, self.nslabs)
+            if p.n_owned:
+                moved = max(moved, float(np.abs(x - self.scene.pos[p.ids[:p.n_owned], 0]).max()))
+        need, self.imbalance = needs_replan(counts, moved, self.halo, self.imbalance_tol)
+        if not (need or force):
+            return False
+        state = self.gather()
+        self.close()
+        self._build(self.scene.with_state(*state))
+        self.replans += 1
+        return True
 
     def exchange(self):
         ws, ps = self.worlds, self.plans
@@ -186,6 +227,9 @@ class LocalSlabs:
             for w in self.worlds:
                 w.tick_substep()
             self.exchange()
+        self.frames += 1
+        if self.rebalance_every and self.frames % self.rebalance_every == 0:
+            self.rebalance()
 
     def gather(self):
         """Global (pos, rot, vel, angvel): every body from its owner (fixed bodies from any copy)."""
@@ -221,29 +265,42 @@ class DistSlab:
     moved peer to peer on the stream the world runs on -- no host copy, no synchronisation.
     Any other backend ("gloo"): the halo goes through host memory (tests, CPU engines)."""
 
-    def __init__(self, scene, engine, dist, halo=None, device_index=None, **cfg_kw):
+    def __init__(self, scene, engine, dist, halo=None, device_index=None, rebalance_every=0, imbalance_tol=0.10,
+                 **cfg_kw):
         import torch
 
         self.torch, self.dist = torch, dist
         self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
-        self.scene = scene
-        plans, self.bounds = plan_slabs(scene, self.nranks, halo)
-        self.plan = plans[self.rank]
-        self.all_plans = plans
+        self.engine, self.device_index = engine, device_index
+        self.halo = default_halo(scene) if halo is None else float(halo)
+        self.rebalance_every, self.imbalance_tol = int(rebalance_every), float(imbalance_tol)
+        self.frames = self.replans = 0
+        self.imbalance = 0.0
         if device_index is not None:
             cfg_kw = dict(cfg_kw, device=device_index)
-        self.world = engine.from_scene(local_scene(scene, self.plan), **cfg_kw)
+        self.cfg_kw = cfg_kw
+        self.stream = None
+        self._build(scene)
+
+    def _build(self, scene):
+        torch, dist, device_index = self.torch, self.dist, self.device_index
+        self.scene = scene
+        plans, self.bounds = plan_slabs(scene, self.nranks, self.halo)
+        self.plan = plans[self.rank]
+        self.all_plans = plans
+        self.world = self.engine.from_scene(local_scene(scene, self.plan), **self.cfg_kw)
         self.world.halo_set(self.plan.send_idx, self.plan.recv_idx)
         self.on_device = dist.get_backend() == "nccl" and hasattr(self.world, "halo_buffer_pointers")
         p = self.plan
         self.n_sl, self.n_sr, self.n_rl, self.n_rr = len(p.send_left), len(p.send_right), len(p.recv_left), len(p.recv_right)
-        self.send = self.recv = self.stream = None
+        self.send = self.recv = None
         if self.on_device:
             try:
                 dev = torch.device("cuda", device_index if device_index is not None else torch.cuda.current_device())
                 torch.cuda.set_device(dev)
                 # one stream carries the world's kernels and orders the RCCL transfers against them
-                self.stream = torch.cuda.Stream(dev)
+                if self.stream is None:
+                    self.stream = torch.cuda.Stream(dev)
                 self.world.set_stream(self.stream.cuda_stream)
                 sp, rp = self.world.halo_buffer_pointers()
                 ns, nr = 8 * (self.n_sl + self.n_sr), 8 * (self.n_rl + self.n_rr)
@@ -255,6 +312,38 @@ class DistSlab:
                 warnings.warn(f"device halo buffers unavailable ({e!r}); staging the halo through host memory")
                 self.on_device = False
                 self.world.set_stream(0)
+
+    def drift(self):
+        """The per-frame count exchange: every rank bins its owned bodies' current x into the
+        slabs, one all-reduce (SUM) of `nranks` counts and one (MAX) of the largest x displacement since the
+        cut.  Returns (counts per slab, largest displacement), the same on every rank.  Reads the owned
+        poses back, so it synchronises: call it every few frames, not every substep."""
+        t, p = self.torch, self.plan
+        x = self.world.poses()[0][:p.n_owned, 0]
+        moved = float(np.abs(x - self.scene.pos[p.ids[:p.n_owned], 0]).max()) if p.n_owned else 0.0
+        dev = t.device("cuda", t.cuda.current_device()) if self.on_device else t.device("cpu")
+        c = t.tensor(slab_counts(x, self.bounds, self.nranks), dtype=t.int64, device=dev)
+        m = t.tensor([moved], dtype=t.float64, device=dev)
+        self.dist.all_reduce(c, op=self.dist.ReduceOp.SUM)
+        self.dist.all_reduce(m, op=self.dist.ReduceOp.MAX)
+        return c.cpu().numpy(), float(m.item())
+
+    def rebalance(self, force=False):
+        """Migration: when the populations differ by more than `imbalance_tol` or a body has
+        moved a quarter of the halo since the cut, the ranks all-gather the owned states, cut the scene again
+        at equal counts and rebuild their worlds -- bodies change owner, ghost and send lists are new.  Every
+        rank decides on the same all-reduced figures.  The migration goes through host memory (a re-upload):
+        it is a per-many-frames event, not on the substep path.  Returns True when the slabs were re-cut."""
+        counts, moved = self.drift()
+        need, self.imbalance = needs_replan(counts, moved, self.halo, self.imbalance_tol)
+        if not (need or force):
+            return False
+        state = self.gather()
+        self.send = self.recv = None   # views of the old world's buffers
+        self.world.close()
+        self._build(self.scene.with_state(*state))
+        self.replans += 1
+        return True
 
     def _ops(self, send, recv):
         d, r = self.dist, self.rank
@@ -295,6 +384,9 @@ class DistSlab:
         for _ in range(self.scene.substeps):
             self.world.tick_substep()
             self.exchange()
+        self.frames += 1
+        if self.rebalance_every and self.frames % self.rebalance_every == 0:
+            self.rebalance()
 
     def sync(self):
         self.world.sync()

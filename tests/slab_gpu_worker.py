@@ -67,6 +67,25 @@ def main():
             ref.step(DT)
         slab.sync()
         assert np.array_equal(slab.gather()[0].view(np.uint32), ref.poses()[0].view(np.uint32))
+
+        # count exchange + migration on the device path: the forced re-cut carries every body's state over
+        # exactly (new world, new halo buffers on the same stream) and the run goes on
+        counts, moved = slab.drift()
+        dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+        assert counts.sum() == dyn.sum() and moved > 0.0
+        before = slab.gather()
+        assert slab.rebalance(force=True) and slab.replans == 1 and slab.on_device
+        for a, b in zip(before, slab.gather()):
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), "state changed in the migration"
+        assert slab.drift()[1] == 0.0
+        for _ in range(20):
+            slab.step(DT)
+            ref.step(DT)
+        slab.sync()
+        pos4 = slab.gather()[0]
+        assert np.isfinite(pos4).all() and abs(pos4[dyn, 1].mean() - ref.poses()[0][dyn, 1].mean()) < 0.02
+        slab.close()
+        ref.close()
     finally:
         dist.destroy_process_group()
     print("slab gpu worker ok")

@@ -136,6 +136,79 @@ def test_two_ranks_over_gloo_equal_logical_slabs(tmp_path):
     assert float(z["max_depth"]) == pytest.approx(max(w.stats().max_depth for w in L.worlds), rel=1e-6)
 
 
+def drifting_scene():
+    """The small pile with 2 m/s to the right: it slides against the right wall, bodies cross the cuts."""
+    s = small_scene()
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    vel = np.zeros_like(s.pos)
+    vel[dyn, 0] = 2.0
+    return s.with_state(s.pos, s.rot, vel, s.angvel)
+
+
+def test_rebalancing_recuts_the_slabs_when_bodies_migrate():
+    """count exchange + migration.  A pile that slides sideways leaves its slabs; the driver
+    notices (population imbalance > 10 % or a body moved a quarter of the halo), gathers the owned states
+    and cuts again.  The run stays a valid simulation: nothing lost at the seams, same pile as undecomposed."""
+    from oracle.oracle import OracleWorld
+
+    s = drifting_scene()
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    L = LocalSlabs(s, 3, OracleWorld, rebalance_every=5)
+    frozen = LocalSlabs(s, 3, OracleWorld)            # never re-cut: its populations drift apart
+    W = OracleWorld.from_scene(s)
+    b0 = L.bounds.copy()
+    for _ in range(240):
+        L.step(DT)
+        W.step(DT)
+    for _ in range(60):
+        frozen.step(DT)
+    assert L.replans >= 2
+    assert not np.array_equal(b0, L.bounds)
+    # right after a cut every dynamic body is owned once and the populations are equal
+    owned = np.concatenate([p.ids[:p.n_owned] for p in L.plans])
+    assert np.array_equal(np.sort(owned), np.nonzero(dyn)[0])
+    assert L.rebalance(force=True)
+    counts = [p.n_owned for p in L.plans]
+    assert max(counts) - min(counts) <= 1
+    assert not L.rebalance() and L.imbalance <= 0.10   # nothing moved since: no new cut
+    # the frozen cut has drifted out of balance by now (that is what the re-cut is for)
+    from starframe_amd.slab import needs_replan, slab_counts
+    x = frozen.gather()[0][dyn, 0]
+    need, imb = needs_replan(slab_counts(x, frozen.bounds, 3), 0.0, frozen.halo, 0.10)
+    assert need and imb > 0.10
+    pos, rot, vel, ang = L.gather()
+    ref = W.poses()[0]
+    assert np.isfinite(pos).all()
+    assert pos[dyn, 1].min() > -0.1 and np.abs(pos[dyn, 0]).max() < 8.5     # nothing fell through a seam
+    assert abs(pos[dyn, 1].mean() - ref[dyn, 1].mean()) < 0.05
+    assert abs(pos[dyn, 0].mean() - ref[dyn, 0].mean()) < 0.15               # slid equally far
+    assert max(w.stats().max_depth for w in L.worlds) < 0.05 and W.stats().max_depth < 0.05
+
+
+def test_two_ranks_over_gloo_rebalance_like_logical_slabs(tmp_path):
+    """world_size 2, gloo: the distributed count exchange (all-reduce) and migration (all-gather + new cut)
+    take the same decisions at the same frames as the one-process driver: bit-identical states."""
+    from oracle.oracle import OracleWorld
+
+    out = str(tmp_path / "dist.npz")
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_worker.py"), out, "60", "drift"], env=env))
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    z = np.load(out)
+    L = LocalSlabs(drifting_scene(), 2, OracleWorld, rebalance_every=5)
+    for _ in range(60):
+        L.step(DT)
+    pos, rot, vel, ang = L.gather()
+    assert int(z["replans"]) == L.replans and L.replans >= 1
+    assert np.array_equal(z["bounds"], L.bounds)
+    assert np.array_equal(z["pos"].view(np.uint32), pos.view(np.uint32))
+    assert np.array_equal(z["vel"].view(np.uint32), vel.view(np.uint32))
+
+
 @pytest.mark.gpu
 def test_gpu_logical_slabs_match_oracle_slabs_and_undecomposed():
     """Four logical slabs on one MI355X, halos copied device to device through the C ABI:
