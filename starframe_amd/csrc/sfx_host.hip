@@ -18,6 +18,12 @@
 
 using namespace sfx;
 
+// worlds alive per device in this process, and whether other processes use the device too (see sfx_tick_substep)
+#include <atomic>
+constexpr int kMaxDevices = 64;
+static std::atomic<int> g_live_worlds[kMaxDevices];
+static const bool g_shared_device = [] { const char* e = getenv("SFX_SHARED_DEVICE"); return e && e[0] == '1'; }();
+
 constexpr uint32_t kTargetBatches = 224;  // batches per phase the grouping aims at (< 256 CUs)
 
 
@@ -75,6 +81,7 @@ struct sfx_world {
     uint32_t epoch = 0;            // one per fused multi-phase launch; never reset, so T.done needs no clearing
     // workgroups of the solve kernels the device holds at once, per workgroup size variant (512, 256 threads)
     uint32_t resident_pos_v[2] = {0, 0}, resident_vel_v[2] = {0, 0};
+    bool counted = false;          // this world is in g_live_worlds[device]
     int tile_variant_fixed = -1;   // SFX_TILE_NT=512|256 pins the variant (tuning); -1: chosen per tick
     int tile_variant_pos = -1, tile_variant_vel = -1;  // SFX_TILE_NT_POS / SFX_TILE_NT_VEL: per kernel (tuning)
     bool fuse_phases = true;
@@ -496,16 +503,18 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
     w->cfg = *cfg;
     resolve_defaults(w->cfg);
     w->device = cfg->device;
+    if (w->device < kMaxDevices) { g_live_worlds[w->device].fetch_add(1); w->counted = true; }
     // SFX_NULL_STREAM=1 runs the world on the device's default stream (profilers that cannot
     // follow a second queue)
-    {   // how many workgroups of the solve kernels are resident at once: the fused multi-phase launches
-        // never use more, so that no waiting workgroup keeps a not yet started one off the device
+    {   // how many workgroups of the solve kernels the device holds at once: a fused multi-phase launch is
+        // that large (more would only queue up; batches are handed out by ticket to running workgroups, so
+        // the launch makes progress whatever the grid size)
         hipDeviceProp_t prop;
         bool ok = hipGetDeviceProperties(&prop, w->device) == hipSuccess;
         auto occ = [&](auto kernel, int nt, uint32_t& out) {
             int b = 0;
             if (ok && hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, kernel, nt, 0) == hipSuccess)
-                out = (uint32_t)std::max(b, 0) * (uint32_t)prop.multiProcessorCount * 7u / 8u;
+                out = (uint32_t)std::max(b, 0) * (uint32_t)prop.multiProcessorCount;
             else ok = false;
         };
         occ(k_tile_pos<512>, 512, w->resident_pos_v[0]); occ(k_tile_vel<512>, 512, w->resident_vel_v[0]);
@@ -551,6 +560,7 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
 
 void sfx_destroy(sfx_world* w) {
     if (!w) return;
+    if (w->counted) g_live_worlds[w->device].fetch_sub(1);
     (void)hipSetDevice(w->device);
     (void)hipStreamSynchronize(w->stream);
     for (auto& e : w->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -933,10 +943,14 @@ int sfx_tick_substep(sfx_world* w) {
     if (tv < 0) {
         uint32_t nbatch = 0;
         if (w->ctr_valid) for (uint32_t ph = 0; ph < nph; ++ph) nbatch += w->stale.n_batches[ph];
-        tv = (nbatch > 2u * w->resident_pos_v[0]) ? 1 : 0;
+        tv = (nbatch > 2u * (w->resident_pos_v[0] * 7u / 8u)) ? 1 : 0;   // (measured cross-over: 500 k slab vs 100 k pile)
     }
     const int tvp = w->tile_variant_pos >= 0 ? w->tile_variant_pos : tv, tvv = w->tile_variant_vel >= 0 ? w->tile_variant_vel : tv;
     const uint32_t res_pos = w->resident_pos_v[tvp], res_vel = w->resident_vel_v[tvv];
+    // Fused launches: workgroup b may start with batch b (no ticket round trip) while this world is the only one
+    // on its device -- the grid is then resident as a whole.  With other worlds on the device (logical slabs, several
+    // ranks per GPU: SFX_SHARED_DEVICE=1 says so for other processes) every batch is handed out by ticket.
+    const int first = (w->counted && g_live_worlds[w->device].load() == 1 && !g_shared_device) ? kTileStaticFirst : 0;
     auto launch_pos = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
         const uint32_t nt = tvp == 0 ? 512u : 256u;
         if (tvp == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
@@ -956,11 +970,11 @@ int sfx_tick_substep(sfx_world* w) {
     if (w->fuse_phases) {
         // all phases in one launch, batches wait for the neighbouring batches of earlier phases
         Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_kept : 0);
-        launch_pos(std::min(total_grid, res_pos), 0u, nph, ++w->epoch, 1);
+        launch_pos(std::min(total_grid, res_pos), 0u, nph, ++w->epoch, kTileFallback | first);
     } else {
         for (uint32_t ph = 0; ph < nph; ++ph) {
             Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_kept / nph : 0);
-            launch_pos(w->tile_grid[ph], ph, 1u, 0u, ph + 1 == nph ? 1 : 0);
+            launch_pos(w->tile_grid[ph], ph, 1u, 0u, (ph + 1 == nph ? kTileFallback : 0) | kTileStaticFirst);
         }
     }
     { Prof p(w, SFX_K_DERIVE_VEL, n);
@@ -973,11 +987,11 @@ int sfx_tick_substep(sfx_world* w) {
     }
     if (w->fuse_phases) {
         Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_kept : 0);
-        launch_vel(std::min(total_grid, res_vel), 0u, nph, ++w->epoch, 1);
+        launch_vel(std::min(total_grid, res_vel), 0u, nph, ++w->epoch, kTileFallback | first);
     } else {
         for (uint32_t ph = 0; ph < nph; ++ph) {
             Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_kept / nph : 0);
-            launch_vel(w->tile_grid[ph], ph, 1u, 0u, ph + 1 == nph ? 1 : 0);
+            launch_vel(w->tile_grid[ph], ph, 1u, 0u, (ph + 1 == nph ? kTileFallback : 0) | kTileStaticFirst);
         }
     }
     HIPCHK(w, hipGetLastError());

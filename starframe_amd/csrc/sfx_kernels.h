@@ -77,7 +77,7 @@ struct Counters {
     uint32_t fb_start[SFX_MAX_COLORS + 1];  // colour-major offsets into the sorted fallback list
     uint32_t n_kept;        // tile pairs within reach (the solves' pairs; the fallback list is not tested)
     uint32_t run_cursor;    // batches that have written their colour run table
-    uint32_t pad3[1];
+    uint32_t item_ticket;   // next batch of a tile-solve launch (handed out in item order; the last workgroup to leave resets it)
 };
 static_assert(sizeof(Counters) % 16 == 0, "the per-tick block is cleared in 16-byte units");
 
@@ -1314,7 +1314,7 @@ __device__ __forceinline__ bool last_workgroup(Counters* __restrict__ ctr) {
         __threadfence();
         const uint32_t tk = atomicAdd(&ctr->ticket, 1u);
         s_last = (tk + 1u == gridDim.x) ? 1u : 0u;
-        if (s_last) { ctr->ticket = 0u; __threadfence(); }
+        if (s_last) { ctr->ticket = 0u; ctr->item_ticket = 0u; __threadfence(); }
     }
     __syncthreads();
     const bool last = s_last != 0u;
@@ -1434,6 +1434,37 @@ __device__ __forceinline__ uint32_t phase_total(const Counters* __restrict__ ctr
     return t;
 }
 
+// The batches of a launch are handed out in item order through a ticket, to workgroups that are running: the
+// lowest unfinished item is therefore always held by a workgroup on the device, and since items only wait for
+// lower-numbered ones the launch cannot stall on a workgroup that has not been scheduled yet -- whatever the grid
+// size and however many workgroups the device holds at once.  (A static blockIdx -> item map needs every
+// workgroup resident and a safety margin that, at one workgroup per CU, cost the 100 k pile a third round of
+// batches.)  All threads call this; the body of the loop has a barrier between two calls.
+// Flags of a tile-solve launch.  kTileStaticFirst: workgroup b starts with item b and tickets count from gridDim.x
+// -- saves the first ticket's round trip (3.7 us per launch on the 100 k pile: every workgroup asks at once), but
+// then the argument above needs every workgroup of the grid on the device, which the host can promise only while
+// no other world runs fused launches on the same device (sfx_host.hip: live worlds per device, SFX_SHARED_DEVICE).
+constexpr int kTileFallback = 1, kTileStaticFirst = 2;
+
+__device__ __forceinline__ uint32_t next_item(Counters* __restrict__ ctr, int flags) {
+    if (flags & kTileStaticFirst) return blockIdx.x;
+    __shared__ uint32_t s_item;
+    if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(&ctr->item_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    return s_item;
+}
+
+// The ticket of the workgroup's NEXT batch is taken while the current one is solved, by the first lane of the last
+// wave (the wave with the least to do in a colour step), so that its latency is off the batch's chain.  A ticket
+// held ahead belongs to a running workgroup that works on a lower item: the argument above still holds.
+template <int NT>
+__device__ __forceinline__ uint32_t take_ahead(Counters* __restrict__ ctr, int flags) {
+    uint32_t t = 0u;
+    if (threadIdx.x == NT - 64)
+        t = __hip_atomic_fetch_add(&ctr->item_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((flags & kTileStaticFirst) ? gridDim.x : 0u);
+    return t;
+}
+
 // all threads of the workgroup; tiles = the batch's tile ids
 // Hand-off between the batches of one fused launch (MI355X: eight XCDs with private L2s, one L1
 // per CU that other CUs' stores never refresh).  Producer: the poses / velocities a batch writes
@@ -1504,7 +1535,7 @@ __device__ __forceinline__ void publish_batch(const TileArrays& T, const GridPar
 // next colour's pair while it solves the current one.  Finally the blocks' dynamic bodies are
 // written back.  Batches of one phase have disjoint blocks.
 template <int NT>
-__global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
+__global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int flags, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   float max_corr) {
     __shared__ float4 s_pose[kMaxBX];
@@ -1515,7 +1546,8 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
     const uint32_t tid = threadIdx.x;
     const __amdgpu_buffer_rsrc_t pose_rs = record_rsrc(B.pose);
     const uint32_t nitems = phase_total(ctr, ph0, nph);
-    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+    __shared__ uint32_t s_next;
+    for (uint32_t item = next_item(ctr, flags); item < nitems; item = s_next) {
         SFX_TT(tt0);
         const PhaseItem pi = phase_item(ctr, ph0, nph, item);
         const uint32_t ph = pi.ph, it = pi.it;
@@ -1543,6 +1575,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         for (uint32_t l = tid; l < nb; l += NT) s_pose[l] = B.pose[s_gid[l]];  // (the lane that stored s_gid[l])
         __syncthreads();
         nxt.in_range = ncol > 0u && tid < s_ce[0];
+        const uint32_t ahead = take_ahead<NT>(ctr, flags);  // the next batch's ticket, in flight during the colour loop
         SFX_TT(tt1);
         SFX_TT(tt2);
         auto solve = [&](uint32_t k, PairSlot& p) {  // everything from LDS: no memory wait inside a colour step
@@ -1574,6 +1607,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
             lds_barrier();
         }
         __syncthreads();
+        if (tid == NT - 64) s_next = ahead;  // read after the barrier that ends the write-back
         for (uint32_t k = tid; k < npb; k += NT) C.lam[start + k] = s_lam[k];
         SFX_TT(tt3);
         SFX_TT_ADD(1, tt1, tt2); SFX_TT_ADD(2, tt2, tt3); SFX_TT_ADD(5, 0ull, (unsigned long long)ncol);
@@ -1594,11 +1628,11 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         SFX_TT(tt4);
         SFX_TT_ADD(0, ttw, tt1); SFX_TT_ADD(3, tt0, tt4); SFX_TT_ADD(4, 0ull, 1ull); SFX_TT_ADD(7, tt3, tt4); SFX_TT_MAX(15, ttw, tt4);
     }
-    if (with_fallback && last_workgroup(ctr)) fallback_pos(T, ctr, B, C, max_corr);
+    if (last_workgroup(ctr) && (flags & kTileFallback)) fallback_pos(T, ctr, B, C, max_corr);
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph0, uint32_t nph, uint32_t epoch, int with_fallback, GridParams g,
+__global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph0, uint32_t nph, uint32_t epoch, int flags, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   StepParams sp) {
     __shared__ float4 s_pose[kMaxBX];
@@ -1613,7 +1647,8 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
 #endif
     const __amdgpu_buffer_rsrc_t pose_rs = record_rsrc(B.pose), vel_rs = record_rsrc(B.vel);
     const uint32_t nitems = phase_total(ctr, ph0, nph);
-    for (uint32_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+    __shared__ uint32_t s_next;
+    for (uint32_t item = next_item(ctr, flags); item < nitems; item = s_next) {
         const PhaseItem pi = phase_item(ctr, ph0, nph, item);
         const uint32_t ph = pi.ph, it = pi.it;
         const BatchDesc d = T.batches[ph * g.pstride + it];
@@ -1642,6 +1677,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         }
         __syncthreads();
         nxt.in_range = ncol > 0u && tid < s_ce[0];
+        const uint32_t ahead = take_ahead<NT>(ctr, flags);
         SFX_TT(tv1);
         auto solve = [&](const PairSlot& p) {
             const PairEnds& e = p.e;
@@ -1672,6 +1708,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
             lds_barrier();
         }
         __syncthreads();
+        if (tid == NT - 64) s_next = ahead;
         SFX_TT(tv2);
         const bool shifted = s_shift != 0u;
         if (nph > 1u) {  // fused phases: later batches of this launch read these records
@@ -1704,7 +1741,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         }
 #endif
     }
-    if (with_fallback && last_workgroup(ctr)) fallback_vel(T, ctr, B, C, sp);
+    if (last_workgroup(ctr) && (flags & kTileFallback)) fallback_vel(T, ctr, B, C, sp);
 #ifdef SFX_TILE_TIMING
     if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[49 + 2 * (epoch & 15u)], wall_clock64());    // latest kernel exit
 #endif

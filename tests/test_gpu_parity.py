@@ -353,3 +353,31 @@ def test_largest_grid_scans():
     assert np.array_equal(g.pairs(), o.pairs())
     g.step(DT)
     assert g.stats().overflow == 0
+
+
+def test_batches_by_ticket_equal_batches_by_workgroup_index():
+    """A world alone on its device starts workgroup b of a fused tile-solve launch with batch b; with a second
+    world alive on the device every batch is handed out by ticket (two partly resident launches must not wait
+    for each other).  Which workgroup solves a batch is scheduling only: the states are bit-identical, also
+    when the two worlds' launches overlap on the device."""
+    from starframe_amd.world import World
+
+    s = scenes.mixed_pile(n=20000, width=400)
+    alone = World.from_scene(s)
+    for _ in range(30):
+        alone.step(DT)
+    ref_pos, ref_rot = alone.poses()
+    ref_vel, _ = alone.velocities()
+    assert alone.stats().n_manifolds > 1000
+    alone.close()
+    a, b = World.from_scene(s), World.from_scene(s)      # own streams: their launches run side by side
+    for _ in range(30):
+        a.step(DT)
+        b.step(DT)
+    for w in (a, b):
+        pos, rot = w.poses()
+        assert w.stats().overflow == 0
+        assert np.array_equal(pos.view(np.uint32), ref_pos.view(np.uint32))
+        assert np.array_equal(rot.view(np.uint32), ref_rot.view(np.uint32))
+        assert np.array_equal(w.velocities()[0].view(np.uint32), ref_vel.view(np.uint32))
+        w.close()
