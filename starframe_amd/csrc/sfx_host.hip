@@ -82,6 +82,7 @@ struct sfx_world {
     // workgroups of the solve kernels the device holds at once, per workgroup size variant (512, 256 threads)
     uint32_t resident_pos_v[2] = {0, 0}, resident_vel_v[2] = {0, 0};
     bool counted = false;          // this world is in g_live_worlds[device]
+    int tile_slot = 0;             // ticket counter of the next tile-solve launch (alternates)
     int tile_variant_fixed = -1;   // SFX_TILE_NT=512|256 pins the variant (tuning); -1: chosen per tick
     int tile_variant_pos = -1, tile_variant_vel = -1;  // SFX_TILE_NT_POS / SFX_TILE_NT_VEL: per kernel (tuning)
     bool fuse_phases = true;
@@ -952,11 +953,13 @@ int sfx_tick_substep(sfx_world* w) {
     // ranks per GPU: SFX_SHARED_DEVICE=1 says so for other processes) every batch is handed out by ticket.
     const int first = (w->counted && g_live_worlds[w->device].load() == 1 && !g_shared_device) ? kTileStaticFirst : 0;
     auto launch_pos = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
+        fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;
         const uint32_t nt = tvp == 0 ? 512u : 256u;
         if (tvp == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
         else hipLaunchKernelGGL(k_tile_pos<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
     };
     auto launch_vel = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
+        fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;
         const uint32_t nt = tvv == 0 ? 512u : 256u;
         if (tvv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
         else hipLaunchKernelGGL(k_tile_vel<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);

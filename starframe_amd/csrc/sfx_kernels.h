@@ -77,7 +77,9 @@ struct Counters {
     uint32_t fb_start[SFX_MAX_COLORS + 1];  // colour-major offsets into the sorted fallback list
     uint32_t n_kept;        // tile pairs within reach (the solves' pairs; the fallback list is not tested)
     uint32_t run_cursor;    // batches that have written their colour run table
-    uint32_t item_ticket;   // next batch of a tile-solve launch (handed out in item order; the last workgroup to leave resets it)
+    uint32_t item_ticket[2];  // next batch of a tile-solve launch, handed out in item order; launches alternate between
+                              // the two counters and every launch clears the one its successor will use
+    uint32_t pad3[3];
 };
 static_assert(sizeof(Counters) % 16 == 0, "the per-tick block is cleared in 16-byte units");
 
@@ -1314,7 +1316,7 @@ __device__ __forceinline__ bool last_workgroup(Counters* __restrict__ ctr) {
         __threadfence();
         const uint32_t tk = atomicAdd(&ctr->ticket, 1u);
         s_last = (tk + 1u == gridDim.x) ? 1u : 0u;
-        if (s_last) { ctr->ticket = 0u; ctr->item_ticket = 0u; __threadfence(); }
+        if (s_last) { ctr->ticket = 0u; __threadfence(); }
     }
     __syncthreads();
     const bool last = s_last != 0u;
@@ -1444,12 +1446,20 @@ __device__ __forceinline__ uint32_t phase_total(const Counters* __restrict__ ctr
 // -- saves the first ticket's round trip (3.7 us per launch on the 100 k pile: every workgroup asks at once), but
 // then the argument above needs every workgroup of the grid on the device, which the host can promise only while
 // no other world runs fused launches on the same device (sfx_host.hip: live worlds per device, SFX_SHARED_DEVICE).
-constexpr int kTileFallback = 1, kTileStaticFirst = 2;
+// kTileSlot: which of the two ticket counters this launch uses.
+constexpr int kTileFallback = 1, kTileStaticFirst = 2, kTileSlot = 4;
+
+__device__ __forceinline__ uint32_t* ticket_of(Counters* __restrict__ ctr, int flags) {
+    return &ctr->item_ticket[(flags & kTileSlot) ? 1 : 0];
+}
 
 __device__ __forceinline__ uint32_t next_item(Counters* __restrict__ ctr, int flags) {
+    // the next launch's counter starts at zero (that launch begins after this one has ended; the previous one, which
+    // used it, has ended before this one began)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctr->item_ticket[(flags & kTileSlot) ? 0 : 1] = 0u;
     if (flags & kTileStaticFirst) return blockIdx.x;
     __shared__ uint32_t s_item;
-    if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(&ctr->item_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(ticket_of(ctr, flags), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     return s_item;
 }
@@ -1461,7 +1471,7 @@ template <int NT>
 __device__ __forceinline__ uint32_t take_ahead(Counters* __restrict__ ctr, int flags) {
     uint32_t t = 0u;
     if (threadIdx.x == NT - 64)
-        t = __hip_atomic_fetch_add(&ctr->item_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((flags & kTileStaticFirst) ? gridDim.x : 0u);
+        t = __hip_atomic_fetch_add(ticket_of(ctr, flags), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((flags & kTileStaticFirst) ? gridDim.x : 0u);
     return t;
 }
 
@@ -1628,7 +1638,8 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         SFX_TT(tt4);
         SFX_TT_ADD(0, ttw, tt1); SFX_TT_ADD(3, tt0, tt4); SFX_TT_ADD(4, 0ull, 1ull); SFX_TT_ADD(7, tt3, tt4); SFX_TT_MAX(15, ttw, tt4);
     }
-    if (last_workgroup(ctr) && (flags & kTileFallback)) fallback_pos(T, ctr, B, C, max_corr);
+    // the fallback list is usually empty: then no workgroup pays for the exit ticket (fence + atomic round trip)
+    if ((flags & kTileFallback) && ctr->n_fb != 0u && last_workgroup(ctr)) fallback_pos(T, ctr, B, C, max_corr);
 }
 
 template <int NT>
@@ -1741,7 +1752,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         }
 #endif
     }
-    if (last_workgroup(ctr) && (flags & kTileFallback)) fallback_vel(T, ctr, B, C, sp);
+    if ((flags & kTileFallback) && ctr->n_fb != 0u && last_workgroup(ctr)) fallback_vel(T, ctr, B, C, sp);
 #ifdef SFX_TILE_TIMING
     if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[49 + 2 * (epoch & 15u)], wall_clock64());    // latest kernel exit
 #endif
