@@ -80,10 +80,10 @@ struct sfx_world {
     DevBuf<uint32_t> torder, done, bbody, bruns;
     uint32_t epoch = 0;            // one per fused multi-phase launch; never reset, so T.done needs no clearing
     // workgroups of the solve kernels the device holds at once, per workgroup size variant (512, 256 threads)
-    uint32_t resident_pos_v[2] = {0, 0}, resident_vel_v[2] = {0, 0};
+    uint32_t resident_pos_v[3] = {0, 0, 0}, resident_vel_v[3] = {0, 0, 0};
     bool counted = false;          // this world is in g_live_worlds[device]
     int tile_slot = 0;             // ticket counter of the next tile-solve launch (alternates)
-    int tile_variant_fixed = -1;   // SFX_TILE_NT=512|256 pins the variant (tuning); -1: chosen per tick
+    int tile_variant_fixed = -1;   // SFX_TILE_NT=512|256|128 pins the variant (tuning); -1: the default (256)
     int tile_variant_pos = -1, tile_variant_vel = -1;  // SFX_TILE_NT_POS / SFX_TILE_NT_VEL: per kernel (tuning)
     bool fuse_phases = true;
     DevBuf<int2> cellxy, sorted_cell;
@@ -520,12 +520,14 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
         };
         occ(k_tile_pos<512>, 512, w->resident_pos_v[0]); occ(k_tile_vel<512>, 512, w->resident_vel_v[0]);
         occ(k_tile_pos<256>, 256, w->resident_pos_v[1]); occ(k_tile_vel<256>, 256, w->resident_vel_v[1]);
+        occ(k_tile_pos<128>, 128, w->resident_pos_v[2]); occ(k_tile_vel<128>, 128, w->resident_vel_v[2]);
+        auto variant = [](int v) { return v == 512 ? 0 : v == 256 ? 1 : v == 128 ? 2 : -1; };
         if (const char* nt = getenv("SFX_TILE_NT")) {
             const int v = atoi(nt);
-            w->tile_variant_fixed = v == 512 ? 0 : v == 256 ? 1 : -1;
+            w->tile_variant_fixed = variant(v);
         }
-        if (const char* nt = getenv("SFX_TILE_NT_POS")) { const int v = atoi(nt); w->tile_variant_pos = v == 512 ? 0 : v == 256 ? 1 : -1; }
-        if (const char* nt = getenv("SFX_TILE_NT_VEL")) { const int v = atoi(nt); w->tile_variant_vel = v == 512 ? 0 : v == 256 ? 1 : -1; }
+        if (const char* nt = getenv("SFX_TILE_NT_POS")) { const int v = atoi(nt); w->tile_variant_pos = variant(v); }
+        if (const char* nt = getenv("SFX_TILE_NT_VEL")) { const int v = atoi(nt); w->tile_variant_vel = variant(v); }
         const char* nf = getenv("SFX_NO_FUSE");   // tuning knob: one launch per phase
         w->fuse_phases = !(nf && nf[0] == '1') && ok && w->resident_pos_v[0] >= 32 && w->resident_vel_v[0] >= 32;
     }
@@ -936,16 +938,13 @@ int sfx_tick_substep(sfx_world* w) {
     const uint32_t nph = (w->tly == w->gyl) ? 2u : 4u;
     uint32_t total_grid = 0;
     for (uint32_t ph = 0; ph < nph; ++ph) total_grid += w->tile_grid[ph];
-    // Workgroup size of the tile solves.  A batch is a dependent chain (narrowphase, then one short step
-    // per colour) that keeps few lanes busy, so a CU only fills up when it holds several batches at once:
-    // 512 threads (one workgroup per CU) finish a batch soonest and win while all batches of a sweep fit
-    // on the device together (the 100 k pile); 256 threads (three per CU) win as soon as they do not.
-    int tv = w->tile_variant_fixed;
-    if (tv < 0) {
-        uint32_t nbatch = 0;
-        if (w->ctr_valid) for (uint32_t ph = 0; ph < nph; ++ph) nbatch += w->stale.n_batches[ph];
-        tv = (nbatch > 2u * (w->resident_pos_v[0] * 7u / 8u)) ? 1 : 0;   // (measured cross-over: 500 k slab vs 100 k pile)
-    }
+    // Workgroup size of the tile solves.  A batch is a dependent chain (one short step per colour) that keeps one or
+    // two waves busy, so what counts is that every batch of the sweep is on the device at once (a later phase's batch
+    // fetches its records, body ids and masses while it waits for its neighbours) and that the barriers are cheap:
+    // 256 threads (three workgroups per CU by LDS).  With batches handed out by workgroup index and a 7/8 residency
+    // margin, 512 threads used to win on the 100 k pile; with tickets 256 wins on every BASELINE config (measured:
+    // pyramid 0.605 vs 0.631 ms, 10 k circles 0.385 vs 0.401, 100 k pile 0.775 vs 0.795, 500 k slab 2.13 vs 2.56).
+    const int tv = w->tile_variant_fixed >= 0 ? w->tile_variant_fixed : 1;
     const int tvp = w->tile_variant_pos >= 0 ? w->tile_variant_pos : tv, tvv = w->tile_variant_vel >= 0 ? w->tile_variant_vel : tv;
     const uint32_t res_pos = w->resident_pos_v[tvp], res_vel = w->resident_vel_v[tvv];
     // Fused launches: workgroup b may start with batch b (no ticket round trip) while this world is the only one
@@ -954,14 +953,16 @@ int sfx_tick_substep(sfx_world* w) {
     const int first = (w->counted && g_live_worlds[w->device].load() == 1 && !g_shared_device) ? kTileStaticFirst : 0;
     auto launch_pos = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
         fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;
-        const uint32_t nt = tvp == 0 ? 512u : 256u;
-        if (tvp == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
+        const uint32_t nt = tvp == 0 ? 512u : tvp == 1 ? 256u : 128u;
+        if (tvp == 2) hipLaunchKernelGGL(k_tile_pos<128>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
+        else if (tvp == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
         else hipLaunchKernelGGL(k_tile_pos<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
     };
     auto launch_vel = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
         fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;
-        const uint32_t nt = tvv == 0 ? 512u : 256u;
-        if (tvv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
+        const uint32_t nt = tvv == 0 ? 512u : tvv == 1 ? 256u : 128u;
+        if (tvv == 2) hipLaunchKernelGGL(k_tile_vel<128>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
+        else if (tvv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
         else hipLaunchKernelGGL(k_tile_vel<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
     };
     {   // manifolds of all solver pairs at the poses integration and joints left (one pair per lane)
