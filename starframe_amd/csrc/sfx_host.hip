@@ -968,7 +968,8 @@ int sfx_tick_substep(sfx_world* w) {
     {   // manifolds of all solver pairs at the poses integration and joints left (one pair per lane)
         const uint32_t est = w->ctr_valid ? w->stale.n_pairs : w->max_pairs;
         Prof p(w, SFX_K_NARROW, w->ctr_valid ? w->stale.n_kept : 0);
-        hipLaunchKernelGGL(k_narrow, dim3(std::min(std::max(cdiv(est, kBlock), 1u), 16384u)), dim3(kBlock), 0, w->stream, T, w->ctr,
+        static const uint32_t ndiv = [] { const char* e = getenv("SFX_NARROW_DIV"); return e ? (uint32_t)std::max(1, atoi(e)) : 1u; }();
+        hipLaunchKernelGGL(k_narrow, dim3(std::min(std::max(cdiv(est, kBlock * ndiv), 1u), 16384u)), dim3(kBlock), 0, w->stream, T, w->ctr,
                            B, C, w->cfg.speculative_margin);
     }
     if (w->fuse_phases) {

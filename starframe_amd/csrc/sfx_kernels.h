@@ -1233,7 +1233,10 @@ __device__ __forceinline__ void load_record(const ContactArrays& C, uint32_t slo
 // -- the tile pairs in the batches' class-grouped order, then the fallback list -- at the poses the
 // integration (and the joints) left, one pair per lane, records to the contact arrays.  Every pair
 // is independent, so this is the one stage of the contact sweep that fills the whole device.
-__global__ __launch_bounds__(kBlock) void k_narrow(TileArrays T, const Counters* __restrict__ ctr, BodyArrays B,
+#ifndef SFX_NARROW_WAVES
+#define SFX_NARROW_WAVES 1   // waves per SIMD the register budget of k_narrow must allow (build knob)
+#endif
+__global__ __launch_bounds__(kBlock, SFX_NARROW_WAVES) void k_narrow(TileArrays T, const Counters* __restrict__ ctr, BodyArrays B,
                                                     ContactArrays C, float sm) {
     const uint32_t ntp = min(ctr->tp_cursor, T.max_pairs);
     const uint32_t nfb = min(ctr->n_fb, T.fb_cap) ? ctr->fb_start[SFX_MAX_COLORS] : 0u;
