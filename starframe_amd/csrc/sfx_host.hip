@@ -1486,7 +1486,7 @@ int sfx_stats(sfx_world* w, sfx_frame_stats* out) {
     out->n_manifolds2 = s.n_manifolds2;
     memcpy(&out->max_depth, &s.max_depth_bits, 4);
     out->kinetic_energy = s.ke;
-    memcpy(out->color_count, c.color_count, sizeof(out->color_count));
+    for (int k = 0; k < SFX_MAX_COLORS; ++k) out->color_count[k] = c.color_count[k] + s.color_count[k];  // fallback list + tiles
     return SFX_OK;
 }
 

@@ -966,7 +966,8 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                 if (s_ovf & 2u) atomicOr(&ctr->overflow, kOvfExt);
               }
             }
-            if (tid < SFX_MAX_COLORS && s_hist[tid]) atomicAdd(&ctr->color_count[tid], s_hist[tid]);
+            // (the per-colour pair counts of sfx_frame_stats are tallied by k_stats_pairs when somebody asks: adding every
+            // batch's histogram to one global table cost ~9000 device-scope atomics on two cache lines per tick)
             __syncthreads();
             const uint32_t bstart = s_bstart;
             if (tid < c) tile_batch[s_tile[f + tid]] = s_bidx + 1u;
@@ -1824,11 +1825,15 @@ __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restri
     const uint32_t ntp = cin->n_tile_pairs, nfb = cin->fb_start[SFX_MAX_COLORS];
     uint32_t contacts = 0, mf = 0, mf2 = 0;
     float md = 0.0f;
+    __shared__ uint32_t s_hist[SFX_MAX_COLORS];  // tile pairs per colour (the fallback list's are counted by k_color_global)
+    if (threadIdx.x < SFX_MAX_COLORS) s_hist[threadIdx.x] = 0u;
+    __syncthreads();
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < ntp + nfb; k += gridDim.x * kBlock) {
         uint32_t a, b, slot;
         if (k < ntp) {
             const uint4 pr = T.tpair[k];
             if ((pr.w & 0xFFu) >= SFX_MAX_COLORS) continue;  // uncoloured: never solved
+            atomicAdd(&s_hist[pr.w & 0xFFu], 1u);
             a = pr.x; b = pr.y; slot = k;
         } else {
             const uint2 ab = T.fsorted[k - ntp];
@@ -1850,6 +1855,8 @@ __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restri
     if (mf) atomicAdd(&ctr->n_manifolds, mf);
     if (mf2) atomicAdd(&ctr->n_manifolds2, mf2);
     if (md > 0.0f) atomicMax(&ctr->max_depth_bits, __float_as_uint(md));
+    __syncthreads();
+    if (threadIdx.x < SFX_MAX_COLORS && s_hist[threadIdx.x]) atomicAdd(&ctr->color_count[threadIdx.x], s_hist[threadIdx.x]);
 }
 
 __global__ __launch_bounds__(kBlock) void k_contacts_debug(uint32_t np, const uint2* __restrict__ pairs, BodyArrays B,
