@@ -83,6 +83,7 @@ struct sfx_world {
     uint32_t resident_pos_v[3] = {0, 0, 0}, resident_vel_v[3] = {0, 0, 0};
     bool counted = false;          // this world is in g_live_worlds[device]
     int tile_slot = 0;             // ticket counter of the next tile-solve launch (alternates)
+    uint32_t ctr_skipped = 0;      // ticks since the last asynchronous read-back of the counters
     int tile_variant_fixed = -1;   // SFX_TILE_NT=512|256|128 pins the variant (tuning); -1: the default (256)
     int tile_variant_pos = -1, tile_variant_vel = -1;  // SFX_TILE_NT_POS / SFX_TILE_NT_VEL: per kernel (tuning)
     bool fuse_phases = true;
@@ -432,11 +433,19 @@ int broadphase(sfx_world* w, float dt) {
 }
 
 // poll the async counter copy of an earlier tick (never blocks)
+void adopt_counters(sfx_world* w);
 void poll_counters(sfx_world* w) {
     if (w->ctr_pending && hipEventQuery(w->ev_ctr) == hipSuccess) {
         w->stale = *w->h_ctr;
-        w->ctr_valid = true;
         w->ctr_pending = false;
+        adopt_counters(w);
+    }
+}
+
+// new counters in w->stale: the launch sizes of the next ticks follow them
+void adopt_counters(sfx_world* w) {
+    {
+        w->ctr_valid = true;
         // tiles per batch: about kTargetBatches batches per phase (one workgroup each, all resident at
         // once), but no batch beyond ~2/3 of the pair and body capacities on average
         const uint32_t ntl = w->stale.n_active[0];
@@ -1003,7 +1012,11 @@ int sfx_tick_substep(sfx_world* w) {
     if (++w->substeps_done >= w->cfg.substeps) {
         // end of the tick: start the asynchronous read-back of its counters
         w->tick_open = false;
-        if (!w->ctr_pending) {
+        static const uint32_t every = [] { const char* e = getenv("SFX_CTR_EVERY"); return e ? (uint32_t)std::max(1, atoi(e)) : 8u; }();
+        // the counters only size the next ticks' grids (every kernel loops over what it is given), so they are read
+        // back every few ticks: the copy costs the stream about 6 us
+        if (!w->ctr_pending && (!w->ctr_valid || ++w->ctr_skipped >= every)) {
+            w->ctr_skipped = 0;
             HIPCHK(w, hipMemcpyAsync(w->h_ctr, w->ctr, sizeof(Counters), hipMemcpyDeviceToHost, w->stream));
             HIPCHK(w, hipEventRecord(w->ev_ctr, w->stream));
             w->ctr_pending = true;
@@ -1264,6 +1277,13 @@ int sfx_sync(sfx_world* w) {
     HIPCHK(w, hipSetDevice(w->device));
     HIPCHK(w, hipStreamSynchronize(w->stream));
     poll_counters(w);
+    if (!w->ctr_pending && w->ctr_skipped && !w->tick_open) {
+        // the asynchronous read-back skipped the last ticks: a sync point reports what they flagged all the same
+        int rc = sync_counters(w, &w->stale, w->ctr);
+        if (rc) return rc;
+        w->ctr_skipped = 0;
+        adopt_counters(w);
+    }
     if (w->ctr_valid && w->stale.overflow)
         return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list, 32 a fused solve launch gave up waiting, 64 more than 64 large colliders over one batch of tiles)",
                     w->stale.overflow);
