@@ -134,6 +134,12 @@ def main():
     ap.add_argument("--bodies", type=int, default=100_000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--settle-frames", type=int, default=600)
+    ap.add_argument("--live-events", default="solve_vel",
+                    help="comma-separated kernel classes bracketed with HIP events INSIDE the timed region (the roofline's "
+                         "launch time when the dominant kernel is among them); 'off' = none")
+    ap.add_argument("--live-every", type=int, default=8,
+                    help="bracket the --live-events launches in every n-th timed tick (an event record costs the stream "
+                         "3.4 us: every tick would take 3.4 %% off the value, every 8th takes 0.4 %%)")
     ap.add_argument("--force-slab", action="store_true",
                     help="rehearse the N > 1 code path (slab driver over torch.distributed nccl) with one rank")
     args = ap.parse_args()
@@ -197,11 +203,22 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    # HIP events around the launches of the dominant kernel class over exactly the timed steps (recorded by libsfx on
+    # the stream the kernels run on; nothing is collected or synchronised until the region has ended)
+    live = [] if args.live_events == "off" else [c for c in args.live_events.split(",") if c]
+    w.kernel_times(reset=True)
+    every = max(1, args.live_every)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if live and i % every == 0:
+            w.set_profiling_classes(live)          # a host-side flag: no device work, no synchronisation
+        elif live and i % every == 1:
+            w.set_profiling_classes(["stats"])     # a class no tick kernel belongs to = paused (0 would collect and synchronise)
         step()
     w.sync()
     elapsed = time.perf_counter() - t0
+    kt_live = w.kernel_times(reset=True) if live else {}
+    w.set_profiling(False)
     if dist is not None:
         import torch
 
@@ -211,7 +228,7 @@ def main():
         dist.barrier()
     st = w.stats()
 
-    # roofline leg: the same ticks again with per-launch HIP events (kept out of `value`)
+    # second leg: the same ticks again with HIP events around EVERY launch (per-kernel table; kept out of `value`)
     prof_frames = max(8, min(args.steps, 60))
     w.set_profiling(True)
     w.kernel_times(reset=True)
@@ -231,7 +248,18 @@ def main():
         per_kernel[cls] = {"bytes_per_launch": nbytes / per_launch, "launch_us": dur * 1e6,
                            "achieved": nbytes / per_launch / dur / 1e9, "ms_per_step": k["total_ms"] / prof_frames}
     dom = max(per_kernel, key=lambda c: per_kernel[c]["ms_per_step"])   # the kernel the tick spends most time in
-    sp = per_kernel[dom]
+    sp = dict(per_kernel[dom])
+    measured_over = f"{prof_frames} further ticks after the timed region (the dominant kernel was not among --live-events)"
+    if dom in kt_live and kt_live[dom]["launches"]:
+        k = kt_live[dom]
+        nbytes = kernel_bytes(st)[dom]
+        live_ticks = len(range(0, args.steps, every))
+        per_launch = k["launches"] / (live_ticks * scene.substeps)
+        dur = 1e-3 * k["total_ms"] / k["launches"]
+        sp = {"bytes_per_launch": nbytes / per_launch, "launch_us": dur * 1e6, "achieved": nbytes / per_launch / dur / 1e9,
+              "ms_per_step": k["total_ms"] / live_ticks}
+        measured_over = (f"every {every}th of the {args.steps} timed ticks ({k['launches']} launches inside the timed region)"
+                         if every > 1 else f"the {args.steps} timed ticks ({k['launches']} launches)")
     achieved = sp["achieved"]
     kernel_ms = {k: round(v["total_ms"] / prof_frames, 4) for k, v in kt.items() if v["launches"]}
     value = n_dyn * scene.substeps * args.steps / elapsed
@@ -275,6 +303,7 @@ def main():
             "bytes_per_launch": sp["bytes_per_launch"],
             "launch_us": sp["launch_us"],
             "launches_per_step": kt[dom]["launches"] / prof_frames,
+            "launch_us_second_leg": per_kernel[dom]["launch_us"],
             "other_kernels": {KERNEL_NAMES[c].split(" ")[0]: {"achieved": round(v["achieved"], 1), "frac": round(v["achieved"] / HBM_PEAK_GBS, 4),
                                                                 "launch_us": round(v["launch_us"], 2), "bytes_per_launch": v["bytes_per_launch"],
                                                                 "traffic": load_traffic(c)}
@@ -282,8 +311,9 @@ def main():
             "tick_bytes_per_body_substep": bpbs,
             "tick_frac": (value / world) * bpbs / (HBM_PEAK_GBS * 1e9),
             "kernel_ms_per_step": kernel_ms,
-            "note": "launch time from hipEvents recorded by libsfx around every launch on its own stream, "
-                    f"over {prof_frames} further ticks after the timed region; traffic = 2 x FETCH_SIZE + WRITE_SIZE from "
+            "note": "launch time of the dominant kernel from hipEvents recorded by libsfx around its launches on the stream they "
+                    f"run on, over {measured_over}; other_kernels and kernel_ms_per_step from a second leg of {prof_frames} "
+                    "ticks with events around every launch; traffic = 2 x FETCH_SIZE + WRITE_SIZE from "
                     "rocprofv3 --pmc passes of the native driver on the same settled scene (profiles/)",
         },
     }

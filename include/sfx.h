@@ -316,7 +316,10 @@ int sfx_debug_joint_order(sfx_world* w, uint32_t* perm, uint8_t* colors, size_t 
 
 /* ---- reporting ------------------------------------------------------------ */
 int sfx_stats(sfx_world* w, sfx_frame_stats* out); /* synchronises */
-int sfx_set_profiling(sfx_world* w, int on);       /* brackets every launch with events */
+int sfx_set_profiling(sfx_world* w, int on);       /* 1: brackets every launch with events (and synchronises once per tick
+                                                      to collect them); 2 * m: only the launches of the classes in the bit
+                                                      mask m (bit SFX_K_x), nothing synchronises until sfx_kernel_times or
+                                                      sfx_set_profiling(w, 0) collects them -- cheap enough for a timed run */
 int sfx_kernel_times(sfx_world* w, sfx_kernel_time* out /* [SFX_K_CLASSES] */, int reset);
 const char* sfx_kernel_class_name(int cls);
 /* device time of everything enqueued between begin and end, via events on the world's stream */

@@ -147,6 +147,7 @@ struct sfx_world {
     bool ticked = false;
     // profiling
     bool profiling = false;
+    uint32_t prof_mask = 0;        // sfx_set_profiling(w, 2 * mask): events around the launches of these classes only, collected on demand
     std::vector<Event2> ev_used;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     sfx_kernel_time ktime[SFX_K_CLASSES]{};
@@ -290,7 +291,7 @@ struct Prof {
     int cls;
     bool on;
     size_t idx = 0;
-    Prof(sfx_world* w_, int cls_, uint64_t items) : w(w_), cls(cls_), on(w_->profiling) {
+    Prof(sfx_world* w_, int cls_, uint64_t items) : w(w_), cls(cls_), on(w_->profiling || ((w_->prof_mask >> cls_) & 1u)) {
         w->launches++;
         if (!on) return;
         if (w->ev_pool.empty()) {
@@ -1512,8 +1513,9 @@ int sfx_stats(sfx_world* w, sfx_frame_stats* out) {
 
 int sfx_set_profiling(sfx_world* w, int on) {
     if (!w) return SFX_ERR_INVALID;
-    if (!on && w->profiling) collect_profile(w);
-    w->profiling = on != 0;
+    if (!on && (w->profiling || w->prof_mask)) collect_profile(w);
+    w->profiling = on == 1;                           // every launch, collected (with a synchronisation) at the end of each tick
+    w->prof_mask = on > 1 ? (uint32_t)on >> 1 : 0u;   // chosen classes only, collected by sfx_kernel_times / when switched off
     return SFX_OK;
 }
 

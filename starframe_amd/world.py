@@ -263,6 +263,15 @@ class World(WorldBase):
     def set_profiling(self, on):
         self._check(self.lib.sfx_set_profiling(self.handle, int(on)))
 
+    def set_profiling_classes(self, names):
+        """Events around the launches of the named kernel classes only ("solve_vel", "narrow", ...); nothing
+        synchronises until kernel_times() collects them, so a timed run can carry it."""
+        known = {self.lib.sfx_kernel_class_name(k).decode(): k for k in range(K_CLASSES)}
+        mask = 0
+        for n in names:
+            mask |= 1 << known[n]
+        self._check(self.lib.sfx_set_profiling(self.handle, 2 * mask))
+
     def kernel_times(self, reset=False):
         arr = (SfxKernelTime * K_CLASSES)()
         self._check(self.lib.sfx_kernel_times(self.handle, arr, int(reset)))
