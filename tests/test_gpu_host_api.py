@@ -107,3 +107,32 @@ def test_python_physics_api_joints_rope_and_frame_loop():
     seg = np.linalg.norm(np.diff(pos[rope], axis=0), axis=1)
     assert seg.max() < 0.125 * 1.25 * 1.01 and pos[rope, 1].min() < 1.6                    # taut links, hanging below the pins
     assert last.shape == (len(pos), 4) and np.abs(last[:, :2] - pos).max() < 0.05   # one frame behind
+
+
+def test_kernel_times_of_all_launches_and_of_chosen_classes():
+    """sfx_set_profiling: 1 brackets every launch (collected per tick), 2 * mask only the chosen classes (collected
+    on demand, nothing synchronises in between); either way the tick's results are the same."""
+    from starframe_amd import scenes
+    from starframe_amd.world import World
+
+    s = scenes.mixed_pile(n=3000, width=100)
+    plain, prof = World.from_scene(s), World.from_scene(s)
+    for _ in range(5):
+        plain.step(1.0 / 60.0)
+    prof.set_profiling(True)
+    for _ in range(2):
+        prof.step(1.0 / 60.0)
+    kt = prof.kernel_times(reset=True)
+    assert kt["solve_vel"]["launches"] == 2 * s.substeps and kt["narrow"]["launches"] == 2 * s.substeps
+    assert kt["pair_count"]["launches"] == 2 and kt["solve_vel"]["total_ms"] > 0.0
+    prof.set_profiling_classes(["solve_vel", "narrow"])
+    for _ in range(3):
+        prof.step(1.0 / 60.0)
+    kt = prof.kernel_times(reset=True)
+    assert kt["solve_vel"]["launches"] == 3 * s.substeps and kt["narrow"]["launches"] == 3 * s.substeps
+    assert kt["solve_pos"]["launches"] == 0 and kt["pair_count"]["launches"] == 0
+    assert 0.0 < kt["solve_vel"]["total_ms"] < 50.0
+    prof.set_profiling(False)
+    assert np.array_equal(plain.poses()[0].view(np.uint32), prof.poses()[0].view(np.uint32))
+    plain.close()
+    prof.close()
