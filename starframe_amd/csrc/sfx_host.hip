@@ -410,6 +410,13 @@ int broadphase(sfx_world* w, float dt) {
       hipLaunchKernelGGL(k_pairs<false>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
                          w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }
     { Prof p(w, SFX_K_TILE_LIST, w->ntiles);
+      if (n / std::max(w->ntiles, 1u) >= 32u)
+          hipLaunchKernelGGL(k_tile_count<64>, dim3(cdiv(w->ntiles, kBlock / 64)), dim3(kBlock), 0, w->stream, g, w->cell_start,
+                             w->slot_cnt.p, w->tile_cnt);
+      else
+          hipLaunchKernelGGL(k_tile_count<8>, dim3(cdiv(w->ntiles, kBlock / 8)), dim3(kBlock), 0, w->stream, g, w->cell_start,
+                             w->slot_cnt.p, w->tile_cnt); }
+    { Prof p(w, SFX_K_TILE_LIST, w->ntiles);
       hipLaunchKernelGGL(k_tile_list, dim3(cdiv(w->ntiles, kBlock)), dim3(kBlock), 0, w->stream, g, w->cell_start,
                          w->tile_cnt, w->tile_flag, w->active.p, w->ctr); }
     rc = scan_u32(w, w->tile_cnt, w->ntiles + 1, nullptr);

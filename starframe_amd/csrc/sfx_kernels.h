@@ -449,13 +449,18 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
             copy = P.slot_cnt[3 * p + 2] == 0u && cc0 + cc1 <= kHitTmp;
         }
         const bool test = live && !copy;
-        // six candidate ranges per slot, walked in lockstep by the eight groups of the wave
+        // Six candidate ranges per slot (own cell behind the slot, four forward neighbour cells, the large colliders),
+        // laid end to end: the group's eight lanes stride over the joined list, so a slot with a handful of
+        // candidates in all (the usual case: under one collider per bucket) takes one or two trips instead of one
+        // per range.  The joined order is range-major, entry-minor -- the order the ranges were walked in one by
+        // one -- so the compacted hits land exactly where they did.
+        uint32_t qs_[6], off_[7];
+        int32_t ncx_[6], ncy_[6];
+        off_[0] = 0u;
 #pragma unroll
         for (int r = 0; r < 6; ++r) {
             uint32_t qs = 0, qe = 0;
             int32_t ncx = 0, ncy = 0;
-            bool check_cell = true;
-            int stream = 0;
             if (test && p < ns) {
                 if (r == 0) {
                     ncx = c.x; ncy = c.y;
@@ -466,47 +471,58 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                     ncx = c.x + dx; ncy = c.y + dy;
                     const uint32_t bk = bucket_of(ncx, ncy, g);
                     qs = cell_start[bk]; qe = cell_start[bk + 1];
-                    stream = ((ncx >> g.tlx) < txp) ? 1 : 0;
                 } else {
-                    qs = ns; qe = nact; check_cell = false;
+                    qs = ns; qe = nact;
                 }
             } else if (test && r == 5) {
-                qs = p + 1; qe = nact; check_cell = false; stream = 2;  // large slot: later larges only
+                qs = p + 1; qe = nact;  // large slot: later larges only
             }
-            for (uint32_t q0 = qs; __any(q0 < qe); q0 += kGroup) {
-                const uint32_t q = q0 + (uint32_t)gl;
-                bool hit = false;
-                uint32_t j = 0;
-                int st = stream;
-                if (q < qe) {
-                    bool ok = true;
-                    if (check_cell) { const int2 cq = sorted_cell[q]; ok = (cq.x == ncx && cq.y == ncy); }
-                    if (ok && aabb_overlap(Ai, sorted_aabb[q])) {
-                        j = sorted_id[q];
-                        const uint4 fj = filt[j];
-                        hit = pair_filter(fi, fj);
-                        if (r == 5 && p < ns && fj.w != 0u) st = 2;  // small against a large dynamic collider
-                    }
-                }
+            qs_[r] = qs; ncx_[r] = ncx; ncy_[r] = ncy;
+            off_[r + 1] = off_[r] + (qe > qs ? qe - qs : 0u);
+        }
+        const bool small_slot = p < ns;
+        const uint32_t L = off_[6];
+        for (uint32_t x0 = 0; __any(x0 < L); x0 += kGroup) {
+            const uint32_t x = x0 + (uint32_t)gl;
+            int r = 0;
+            uint32_t q = qs_[0] + x;
+            int32_t ncx = ncx_[0], ncy = ncy_[0];
 #pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3) {
-                    const bool mine = hit && st == s3;
-                    const uint64_t bal = (__ballot(mine) >> gshift) & ((1ull << kGroup) - 1ull);
-                    if (!FILL && mine && s3 < 2) {
-                        const uint32_t idx = cnt[s3] + (uint32_t)__popcll(bal & below);
-                        if (idx < kHitTmp) P.hit_tmp[(size_t)p * kHitTmp + (s3 == 0 ? idx : kHitTmp - 1u - idx)] = make_uint2(j, q);
-                    }
-                    if (FILL && mine) {
-                        const uint32_t dst = base[s3] + cnt[s3] + (uint32_t)__popcll(bal & below);
-                        const bool swap = j < i;
-                        if (to_fb[s3]) {
-                            if (dst < P.fb_cap) P.fpairs[dst] = make_uint2(swap ? j : i, swap ? i : j);
-                        } else if (dst < P.max_pairs) {
-                            P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, swap ? p : q);
-                        }
-                    }
-                    cnt[s3] += (uint32_t)__popcll(bal);
+            for (int k = 1; k < 6; ++k)
+                if (x >= off_[k]) { r = k; q = qs_[k] + (x - off_[k]); ncx = ncx_[k]; ncy = ncy_[k]; }
+            bool hit = false;
+            uint32_t j = 0;
+            // stream: a neighbour cell in the tile to the left -> that tile's stream; a large slot's pairs and a small
+            // slot's pair with a large dynamic collider -> the fallback list
+            int st = (!small_slot) ? 2 : (r >= 1 && r < 5 && (ncx >> g.tlx) < txp) ? 1 : 0;
+            if (x < L) {
+                bool ok = true;
+                if (r < 5) { const int2 cq = sorted_cell[q]; ok = (cq.x == ncx && cq.y == ncy); }
+                if (ok && aabb_overlap(Ai, sorted_aabb[q])) {
+                    j = sorted_id[q];
+                    const uint4 fj = filt[j];
+                    hit = pair_filter(fi, fj);
+                    if (r == 5 && small_slot && fj.w != 0u) st = 2;  // small against a large dynamic collider
                 }
+            }
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const bool mine = hit && st == s3;
+                const uint64_t bal = (__ballot(mine) >> gshift) & ((1ull << kGroup) - 1ull);
+                if (!FILL && mine && s3 < 2) {
+                    const uint32_t idx = cnt[s3] + (uint32_t)__popcll(bal & below);
+                    if (idx < kHitTmp) P.hit_tmp[(size_t)p * kHitTmp + (s3 == 0 ? idx : kHitTmp - 1u - idx)] = make_uint2(j, q);
+                }
+                if (FILL && mine) {
+                    const uint32_t dst = base[s3] + cnt[s3] + (uint32_t)__popcll(bal & below);
+                    const bool swap = j < i;
+                    if (to_fb[s3]) {
+                        if (dst < P.fb_cap) P.fpairs[dst] = make_uint2(swap ? j : i, swap ? i : j);
+                    } else if (dst < P.max_pairs) {
+                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, swap ? p : q);
+                    }
+                }
+                cnt[s3] += (uint32_t)__popcll(bal);
             }
         }
         if (FILL && copy) {
@@ -527,9 +543,8 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
         }
         if (!FILL) {
             if (live && gl == 0) { P.slot_cnt[3 * p] = cnt[0]; P.slot_cnt[3 * p + 1] = cnt[1]; P.slot_cnt[3 * p + 2] = cnt[2]; }
-            const uint32_t none = 0xFFFFFF00u + (uint32_t)(lane >> 3);
-            (void)wave_group_add<false>(P.tile_cnt, (live && cnt[0]) ? T0 : none, cnt[0], lane);
-            (void)wave_group_add<false>(P.tile_cnt, (live && cnt[1]) ? T1 : none, cnt[1], lane);
+            // (the tiles' pair counts are summed from slot_cnt by k_tile_count: two atomics per wave on the tiles'
+            // counters -- some fifty on each -- cost this pass 25 of its 47 us)
         }
     }
 }
@@ -570,6 +585,30 @@ __device__ __forceinline__ uint32_t block_slot(const BlockRanges& R, uint32_t l)
     for (int k = 0; k < 4; ++k)
         if (l >= R.off[k] && l < R.off[k + 1]) s = R.ts[k] + (l - R.off[k]);
     return s;
+}
+
+// Pairs per tile after the count pass, one wave per tile: the stream-0 counts of the tile's own slots (slots are
+// sorted tile-major, a tile's colliders are one contiguous range) plus the stream-1 counts of the slots of the tile
+// to its right, whose pairs with the neighbour cell (-1, +1) this tile owns.
+template <int LPT>  // lanes per tile: 64 for tiles of hundreds of colliders (strips), 8 for the small tiles of wide grids
+__global__ __launch_bounds__(kBlock) void k_tile_count(GridParams g, const uint32_t* __restrict__ cell_start,
+                                                        const uint32_t* __restrict__ slot_cnt, uint32_t* __restrict__ tile_cnt) {
+    const uint32_t t = (blockIdx.x * kBlock + threadIdx.x) / (uint32_t)LPT;
+    const uint32_t lane = threadIdx.x & (uint32_t)(LPT - 1);
+    const bool live = t < g.ntiles;
+    const uint32_t sh = g.tlx + g.tly, lx = g.gxl - g.tlx;
+    const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
+    const uint32_t tr = tile_of(tx + 1, ty, g);
+    uint32_t sum = 0;
+    if (live) {
+        const uint32_t s0 = cell_start[t << sh], e0 = cell_start[(t + 1u) << sh];
+        const uint32_t s1 = cell_start[tr << sh], e1 = cell_start[(tr + 1u) << sh];
+        for (uint32_t p = s0 + lane; p < e0; p += (uint32_t)LPT) sum += slot_cnt[3u * p];
+        for (uint32_t p = s1 + lane; p < e1; p += (uint32_t)LPT) sum += slot_cnt[3u * p + 1u];
+    }
+#pragma unroll
+    for (int off = LPT / 2; off > 0; off >>= 1) sum += (uint32_t)__shfl_xor((int)sum, off, 64);
+    if (live && lane == 0) tile_cnt[t] = sum;
 }
 
 // One thread per tile, after the count pass: tiles over capacity are flagged (their pair count
