@@ -75,7 +75,7 @@ struct sfx_world {
     Counters* ctr = nullptr;
     uint32_t *cell_start = nullptr, *tile_cnt = nullptr, *tile_fill = nullptr, *tile_flag = nullptr, *tile_batch = nullptr;
     size_t zero_bytes = 0;
-    DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, scan_sums, active;
+    DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, slot_off, scan_sums, active;
     DevBuf<BatchDesc> batches;
     DevBuf<uint32_t> torder, done, bbody, bruns;
     uint32_t epoch = 0;            // one per fused multi-phase launch; never reset, so T.done needs no clearing
@@ -402,7 +402,7 @@ int broadphase(sfx_world* w, float dt) {
                          w->bucket.p, w->aabb.p, w->cellxy.p, w->large_tmp.p, w->large_cap, w->sorted_id.p,
                          w->sorted_aabb.p, w->sorted_cell.p, w->ctr); }
     PairArrays P;
-    P.slot_cnt = w->slot_cnt.p; P.tile_cnt = w->tile_cnt; P.tile_fill = w->tile_fill; P.tile_flag = w->tile_flag;
+    P.slot_cnt = w->slot_cnt.p; P.slot_off = w->slot_off.p; P.tile_cnt = w->tile_cnt; P.tile_fill = w->tile_fill; P.tile_flag = w->tile_flag;
     P.rawp = w->rawp.p; P.fpairs = w->fpairs.p; P.hit_tmp = w->hit_tmp.p; P.max_pairs = w->max_pairs; P.fb_cap = w->fb_cap;
     // one 8-lane group per slot: 32 slots per block
     const uint32_t gp = std::min(std::max(cdiv(n + 1, kBlock / kGroup), 1u), 8192u);
@@ -412,10 +412,10 @@ int broadphase(sfx_world* w, float dt) {
     { Prof p(w, SFX_K_TILE_LIST, w->ntiles);
       if (n / std::max(w->ntiles, 1u) >= 32u)
           hipLaunchKernelGGL(k_tile_count<64>, dim3(cdiv(w->ntiles, kBlock / 64)), dim3(kBlock), 0, w->stream, g, w->cell_start,
-                             w->slot_cnt.p, w->tile_cnt);
+                             w->slot_cnt.p, w->tile_cnt, w->tile_fill, w->slot_off.p);
       else
           hipLaunchKernelGGL(k_tile_count<8>, dim3(cdiv(w->ntiles, kBlock / 8)), dim3(kBlock), 0, w->stream, g, w->cell_start,
-                             w->slot_cnt.p, w->tile_cnt); }
+                             w->slot_cnt.p, w->tile_cnt, w->tile_fill, w->slot_off.p); }
     { Prof p(w, SFX_K_TILE_LIST, w->ntiles);
       hipLaunchKernelGGL(k_tile_list, dim3(cdiv(w->ntiles, kBlock)), dim3(kBlock), 0, w->stream, g, w->cell_start,
                          w->tile_cnt, w->tile_flag, w->active.p, w->ctr); }
@@ -590,7 +590,7 @@ void sfx_destroy(sfx_world* w) {
     w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
     w->active.release(); w->batches.release(); w->torder.release(); w->done.release(); w->bbody.release(); w->bruns.release(); w->rawp.release(); w->tpair.release();
     w->fpairs.release(); w->fsorted.release(); w->hit_tmp.release();
-    w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->scan_sums.release();
+    w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->slot_off.release(); w->scan_sums.release();
     w->cellxy.release(); w->sorted_cell.release();
     w->used.release(); w->claim.release(); w->left_list.release();
     w->pcolor.release(); w->prop.release(); w->jctr.release(); w->dbg.release();
@@ -649,7 +649,7 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
         ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
         ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
         ALLOC(w, w->bucket, c); ALLOC(w, w->tmp_id, c); ALLOC(w, w->sorted_id, c); ALLOC(w, w->large_tmp, c);
-        ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->hit_tmp, kHitTmp * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
+        ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->slot_off, 2 * ((size_t)n + 1)); ALLOC(w, w->hit_tmp, kHitTmp * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
         ALLOC(w, w->used, c); ALLOC(w, w->claim, c * kClaim);
         w->large_cap = n;
     }

@@ -358,7 +358,9 @@ constexpr int kSlotsPerWave = 64 / kGroup;
 struct PairArrays {
     uint32_t* slot_cnt;      // [3 * (n + 1)] per slot: stream sizes (count pass out, fill pass in)
     uint32_t* tile_cnt;      // count pass: pairs per tile (atomics); fill pass: scanned = tile start
-    uint32_t* tile_fill;     // fill pass: per tile cursor
+    uint32_t* tile_fill;     // per tile: pairs of the tile's own slots (stream 0); the stream-1 pairs of its right neighbour's
+                             // slots follow them in the tile's range (written by k_tile_count)
+    const uint32_t* slot_off; // [2 * (n + 1)] per slot: pairs of its tile's earlier slots, stream 0 / stream 1 (k_tile_count)
     const uint32_t* tile_flag;  // != 0: tile hands its pairs to the fallback list
     uint4* rawp;             // tile-ordered pairs (id a, id b, slot a, slot b)
     uint2* fpairs;           // fallback list (id a, id b)
@@ -432,8 +434,10 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
             const uint32_t fb_total = c2 + (f0 ? c0 : 0u) + (f1 ? c1 : 0u);
             // groups that are not live or have nothing for a stream get an index of their own
             const uint32_t none = 0xFFFFFF00u + (uint32_t)(lane >> 3);
-            const uint32_t r0 = wave_group_add<true>(P.tile_fill, (live && c0 && !f0) ? T0 : none, f0 ? 0u : c0, lane);
-            const uint32_t r1 = wave_group_add<true>(P.tile_fill, (live && c1 && !f1) ? T1 : none, f1 ? 0u : c1, lane);
+            // places inside the tiles' ranges come from the prefix sums of k_tile_count: no cursor, no atomic, and the
+            // pairs of a tile are in slot order whatever the waves' timing
+            const uint32_t r0 = (live && c0 && !f0) ? P.slot_off[2 * p] : 0u;
+            const uint32_t r1 = (live && c1 && !f1) ? P.tile_fill[T1] + P.slot_off[2 * p + 1] : 0u;
             const uint32_t r2 = wave_group_add<true>(&ctr->n_fb, fb_total ? 0u : none, fb_total, lane);
             base[2] = r2;
             base[0] = f0 ? r2 + c2 : ((live && c0) ? P.tile_cnt[T0] + r0 : 0u);
@@ -592,23 +596,41 @@ __device__ __forceinline__ uint32_t block_slot(const BlockRanges& R, uint32_t l)
 // to its right, whose pairs with the neighbour cell (-1, +1) this tile owns.
 template <int LPT>  // lanes per tile: 64 for tiles of hundreds of colliders (strips), 8 for the small tiles of wide grids
 __global__ __launch_bounds__(kBlock) void k_tile_count(GridParams g, const uint32_t* __restrict__ cell_start,
-                                                        const uint32_t* __restrict__ slot_cnt, uint32_t* __restrict__ tile_cnt) {
+                                                        const uint32_t* __restrict__ slot_cnt, uint32_t* __restrict__ tile_cnt,
+                                                        uint32_t* __restrict__ tile_own, uint32_t* __restrict__ slot_off) {
     const uint32_t t = (blockIdx.x * kBlock + threadIdx.x) / (uint32_t)LPT;
     const uint32_t lane = threadIdx.x & (uint32_t)(LPT - 1);
     const bool live = t < g.ntiles;
     const uint32_t sh = g.tlx + g.tly, lx = g.gxl - g.tlx;
     const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
     const uint32_t tr = tile_of(tx + 1, ty, g);
-    uint32_t sum = 0;
+    uint32_t s0 = 0, e0 = 0, s1 = 0, e1 = 0;
     if (live) {
-        const uint32_t s0 = cell_start[t << sh], e0 = cell_start[(t + 1u) << sh];
-        const uint32_t s1 = cell_start[tr << sh], e1 = cell_start[(tr + 1u) << sh];
-        for (uint32_t p = s0 + lane; p < e0; p += (uint32_t)LPT) sum += slot_cnt[3u * p];
-        for (uint32_t p = s1 + lane; p < e1; p += (uint32_t)LPT) sum += slot_cnt[3u * p + 1u];
+        s0 = cell_start[t << sh]; e0 = cell_start[(t + 1u) << sh];
+        s1 = cell_start[tr << sh]; e1 = cell_start[(tr + 1u) << sh];
     }
+    // the tile's own slots: exclusive prefix sums of both streams (where the fill pass puts each slot's pairs)
+    uint32_t run0 = 0, run1 = 0;
+    for (uint32_t base = s0; __any(base < e0); base += (uint32_t)LPT) {  // the groups of a wave keep in step for the shuffles
+        const uint32_t p = base + lane;
+        const bool in = p < e0;
+        const uint32_t c0 = in ? slot_cnt[3u * p] : 0u, c1 = in ? slot_cnt[3u * p + 1u] : 0u;
+        uint32_t i0 = c0, i1 = c1;
+#pragma unroll
+        for (int off = 1; off < LPT; off <<= 1) {
+            const uint32_t u0 = (uint32_t)__shfl_up((int)i0, off, LPT), u1 = (uint32_t)__shfl_up((int)i1, off, LPT);
+            if ((int)lane >= off) { i0 += u0; i1 += u1; }
+        }
+        if (in) { slot_off[2u * p] = run0 + i0 - c0; slot_off[2u * p + 1u] = run1 + i1 - c1; }
+        run0 += (uint32_t)__shfl((int)i0, LPT - 1, LPT);
+        run1 += (uint32_t)__shfl((int)i1, LPT - 1, LPT);
+    }
+    // the stream-1 pairs of the right neighbour's slots are this tile's as well
+    uint32_t sum = 0;
+    for (uint32_t p = s1 + lane; p < e1; p += (uint32_t)LPT) sum += slot_cnt[3u * p + 1u];
 #pragma unroll
     for (int off = LPT / 2; off > 0; off >>= 1) sum += (uint32_t)__shfl_xor((int)sum, off, 64);
-    if (live && lane == 0) tile_cnt[t] = sum;
+    if (live && lane == 0) { tile_cnt[t] = run0 + sum; tile_own[t] = run0; }
 }
 
 // One thread per tile, after the count pass: tiles over capacity are flagged (their pair count
