@@ -59,13 +59,13 @@ def kernel_bytes(st):
     """Algorithmic (compulsory) bytes of ONE launch of each contact-sweep kernel (one launch per substep),
     from the tick's measured counts.  DESIGN.md "Kernels": P = solver pairs, M = touching pairs (manifolds),
     M2 = of which with two points.
-      k_narrow   : P x (4 order + 16 pair + 2 x (16 pose + 16 shape) read, 8 count written)
+      k_narrow   : P x (16 order (ids + slot) + 2 x (16 pose + 16 shape) read, 8 count written)
                    + M x (2 x 16 velocity read; 16 normal/friction + 16 anchors + 8 lambda + 8 pre-velocity written) + M2 x 16
       k_tile_pos : P x (16 pair + 8 count read) + M x (32 record + 2 x (16 pose + 8 mass) read; 8 lambda + 2 x 16 pose written) + M2 x 16
       k_tile_vel : P x (16 + 8 read) + M x (48 record + 2 x (16 pose + 16 velocity + 8 mass) read; 2 x 16 velocity written) + M2 x 16"""
     P, M, M2 = float(st.n_solver_pairs), float(st.n_manifolds), float(st.n_manifolds2)
     return {
-        "narrow": P * 92.0 + M * 80.0 + M2 * 16.0,
+        "narrow": P * 88.0 + M * 80.0 + M2 * 16.0,
         "solve_pos": P * 24.0 + M * 120.0 + M2 * 16.0,
         "solve_vel": P * 24.0 + M * 160.0 + M2 * 16.0,
     }

@@ -77,7 +77,8 @@ struct sfx_world {
     size_t zero_bytes = 0;
     DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, slot_off, scan_sums, active;
     DevBuf<BatchDesc> batches;
-    DevBuf<uint32_t> torder, done, bbody, bruns;
+    DevBuf<uint4> torder;
+    DevBuf<uint32_t> done, bbody, bruns;
     uint32_t epoch = 0;            // one per fused multi-phase launch; never reset, so T.done needs no clearing
     // workgroups of the solve kernels the device holds at once, per workgroup size variant (512, 256 threads)
     uint32_t resident_pos_v[3] = {0, 0, 0}, resident_vel_v[3] = {0, 0, 0};

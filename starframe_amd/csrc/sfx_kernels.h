@@ -793,7 +793,7 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                                                          const uint32_t* __restrict__ tile_start,
                                                          const uint32_t* __restrict__ list, const uint4* __restrict__ rawp,
                                                          uint4* __restrict__ tpair, BatchDesc* __restrict__ batches,
-                                                         const float4* __restrict__ shape, uint32_t* __restrict__ torder,
+                                                         const float4* __restrict__ shape, uint4* __restrict__ torder,
                                                          uint32_t* __restrict__ tile_batch,
                                                          uint32_t* __restrict__ bbody, uint32_t bbody_cap,
                                                          uint32_t* __restrict__ bruns, uint32_t bruns_cap,
@@ -1062,9 +1062,9 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                     if (la == kExt) la = lx; else lb = lx;
                 }
                 tpair[bstart + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), cc | (s_tile[f + s_tj[e]] << 8));
-                if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_prop[e]], 1u)] = bstart + dst;
+                if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_prop[e]], 1u)] = make_uint4(s_a[e], s_b[e], bstart + dst, 0u);
             }
-            for (uint32_t e = s_ptail_first + tid; e < np; e += kBlock) torder[bstart + e] = kNoPair;  // pruned pairs: no narrowphase
+            for (uint32_t e = s_ptail_first + tid; e < np; e += kBlock) torder[bstart + e] = make_uint4(0u, 0u, kNoPair, 0u);  // pruned pairs: no narrowphase
             __syncthreads();
             SFX_TT(tc4);
             SFX_TT_ADD(96, tc0, tc1); SFX_TT_ADD(97, tc1, tc2); SFX_TT_ADD(99, tc2, tc3); SFX_TT_ADD(100, tc3, tc4);
@@ -1248,7 +1248,8 @@ struct TileArrays {
     const uint32_t* active;       // per phase tile lists
     const BatchDesc* batches;     // per phase batch tables
     const uint4* tpair;           // colour-major per batch
-    const uint32_t* torder;       // narrowphase order: positions in tpair, per batch grouped by shape-pair class (kNoPair: skip)
+    const uint4* torder;          // narrowphase order, per batch grouped by shape-pair class: (body a, body b, position in tpair
+                                  // = record slot, -); slot kNoPair: skip.  The ids ride along so that k_narrow has one dependent load less
     const uint32_t* bbody;        // per batch (BatchDesc.boff): body ids in local-index order
     const uint32_t* bruns;        // per batch (BatchDesc.roff): 64 colour runs, first | end << 16
     const uint32_t* tile_batch;   // per tile: 1 + index of its batch on its phase's table (0: none this tick)
@@ -1305,10 +1306,10 @@ __global__ __launch_bounds__(kBlock, SFX_NARROW_WAVES) void k_narrow(TileArrays 
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < ntp + nfb; j += gridDim.x * kBlock) {
         uint32_t a, b, slot;
         if (j < ntp) {
-            slot = T.torder[j];
+            const uint4 o = T.torder[j];
+            slot = o.z;
             if (slot == kNoPair) continue;
-            const uint4 pr = T.tpair[slot];
-            a = pr.x; b = pr.y;
+            a = o.x; b = o.y;
         } else {
             const uint2 ab = T.fsorted[j - ntp];
             a = ab.x; b = ab.y; slot = T.max_pairs + (j - ntp);
