@@ -350,10 +350,11 @@ int scan_u32(sfx_world* w, uint32_t* data, uint32_t count, uint32_t* copy) {
     } else {
         { Prof p(w, SFX_K_SCAN, count);
           hipLaunchKernelGGL(k_scan_local, dim3(nb), dim3(kBlock), 0, w->stream, data, count, w->scan_sums.p, (uint32_t*)nullptr, 0); }
-        { Prof p(w, SFX_K_SCAN, nb);
+        const int raw = nb <= (uint32_t)kBlock;  // few tiles: k_scan_add sums the totals before its tile itself
+        if (!raw) { Prof p(w, SFX_K_SCAN, nb);
           hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, w->stream, w->scan_sums.p, nb); }
         { Prof p(w, SFX_K_SCAN, count);
-          hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kBlock), 0, w->stream, data, count, w->scan_sums.p, copy); }
+          hipLaunchKernelGGL(k_scan_add, dim3(nb), dim3(kBlock), 0, w->stream, data, count, w->scan_sums.p, copy, raw); }
     }
     return SFX_OK;
 }
@@ -417,11 +418,17 @@ int broadphase(sfx_world* w, float dt) {
       else
           hipLaunchKernelGGL(k_tile_count<8>, dim3(cdiv(w->ntiles, kBlock / 8)), dim3(kBlock), 0, w->stream, g, w->cell_start,
                              w->slot_cnt.p, w->tile_cnt, w->tile_fill, w->slot_off.p); }
-    { Prof p(w, SFX_K_TILE_LIST, w->ntiles);
-      hipLaunchKernelGGL(k_tile_list, dim3(cdiv(w->ntiles, kBlock)), dim3(kBlock), 0, w->stream, g, w->cell_start,
-                         w->tile_cnt, w->tile_flag, w->active.p, w->ctr); }
-    rc = scan_u32(w, w->tile_cnt, w->ntiles + 1, nullptr);
-    if (rc) return rc;
+    if (w->ntiles + 1u <= (uint32_t)kScanTile) {
+      Prof p(w, SFX_K_TILE_LIST, w->ntiles);
+      hipLaunchKernelGGL(k_tile_list_scan, dim3(1), dim3(kBlock), 0, w->stream, g, w->cell_start,
+                         w->tile_cnt, w->tile_flag, w->active.p, w->ctr);
+    } else {
+      { Prof p(w, SFX_K_TILE_LIST, w->ntiles);
+        hipLaunchKernelGGL(k_tile_list, dim3(cdiv(w->ntiles, kBlock)), dim3(kBlock), 0, w->stream, g, w->cell_start,
+                           w->tile_cnt, w->tile_flag, w->active.p, w->ctr); }
+      rc = scan_u32(w, w->tile_cnt, w->ntiles + 1, nullptr);
+      if (rc) return rc;
+    }
     { Prof p(w, SFX_K_PAIR_FILL, n);
       hipLaunchKernelGGL(k_pairs<true>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
                          w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }

@@ -218,11 +218,10 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
 
 // data[0..count) scanned in place per tile; tile totals to sums[block].  If single != 0 the
 // grid is one block and the result is final (copy, if given, receives it too).
-__global__ __launch_bounds__(kBlock) void k_scan_local(uint32_t* __restrict__ data, uint32_t count,
-                                                        uint32_t* __restrict__ sums, uint32_t* __restrict__ copy,
-                                                        int single) {
+__device__ __forceinline__ void scan_tile(uint32_t blk, uint32_t* data, uint32_t count, uint32_t* sums, uint32_t* copy,
+                                          int single) {
     __shared__ uint32_t lds[kBlock / 64 + 1];
-    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    const uint32_t base = blk * kScanTile + threadIdx.x * kScanItems;
     uint32_t v[kScanItems];
     if (base + kScanItems <= count) {
 #pragma unroll
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_local(uint32_t* __restrict__ da
     for (int k = 0; k < kScanItems; ++k) { uint32_t t = v[k]; v[k] = sum; sum += t; }
     uint32_t total;
     const uint32_t pre = block_exclusive_scan<kBlock>(sum, lds, &total);
-    if (threadIdx.x == 0 && !single) sums[blockIdx.x] = total;
+    if (threadIdx.x == 0 && !single) sums[blk] = total;
 #pragma unroll
     for (int k = 0; k < kScanItems; ++k) v[k] += pre;
     if (base + kScanItems <= count) {
@@ -254,6 +253,12 @@ __global__ __launch_bounds__(kBlock) void k_scan_local(uint32_t* __restrict__ da
         for (int k = 0; k < kScanItems; ++k)
             if (base + k < count) { data[base + k] = v[k]; if (single && copy) copy[base + k] = v[k]; }
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scan_local(uint32_t* __restrict__ data, uint32_t count,
+                                                        uint32_t* __restrict__ sums, uint32_t* __restrict__ copy,
+                                                        int single) {
+    scan_tile(blockIdx.x, data, count, sums, copy, single);
 }
 
 // exclusive scan of up to 8192 tile totals by one block of 1024 threads
@@ -274,9 +279,25 @@ __global__ __launch_bounds__(1024) void k_scan_sums(uint32_t* __restrict__ sums,
         if (base + k < nsums) sums[base + k] = v[k] + pre;
 }
 
+// raw != 0 (at most kBlock tiles): sums still holds the tile totals of k_scan_local and every block adds up
+// the totals of the tiles before its own, which saves the k_scan_sums launch in between
 __global__ __launch_bounds__(kBlock) void k_scan_add(uint32_t* __restrict__ data, uint32_t count,
-                                                      const uint32_t* __restrict__ sums, uint32_t* __restrict__ copy) {
-    const uint32_t add = sums[blockIdx.x];
+                                                      const uint32_t* __restrict__ sums, uint32_t* __restrict__ copy,
+                                                      int raw) {
+    uint32_t add;
+    if (raw) {
+        __shared__ uint32_t part[kBlock / 64];
+        uint32_t s = threadIdx.x < blockIdx.x ? sums[threadIdx.x] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += (uint32_t)__shfl_xor((int)s, off, 64);
+        if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = s;
+        __syncthreads();
+        add = 0u;
+#pragma unroll
+        for (int q = 0; q < kBlock / 64; ++q) add += part[q];
+    } else {
+        add = sums[blockIdx.x];
+    }
     const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
     if (base + kScanItems <= count) {
 #pragma unroll
@@ -635,10 +656,9 @@ __global__ __launch_bounds__(kBlock) void k_tile_count(GridParams g, const uint3
 
 // One thread per tile, after the count pass: tiles over capacity are flagged (their pair count
 // is zeroed so that the scan skips them), the others listed per phase.
-__global__ __launch_bounds__(kBlock) void k_tile_list(GridParams g, const uint32_t* __restrict__ cell_start,
-                                                       uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_flag,
-                                                       uint32_t* __restrict__ active, Counters* __restrict__ ctr) {
-    const uint32_t t = blockIdx.x * kBlock + threadIdx.x;
+__device__ __forceinline__ void tile_list_step(uint32_t t, const GridParams& g, const uint32_t* __restrict__ cell_start,
+                                               uint32_t* tile_cnt, uint32_t* __restrict__ tile_flag,
+                                               uint32_t* __restrict__ active, Counters* __restrict__ ctr) {
     const uint32_t cnt = t < g.ntiles ? tile_cnt[t] : 0u;
     // 0..3: listed under that phase, 4: over capacity, 5: nothing to do
     uint32_t kind = 5u, nb = 0u;
@@ -679,6 +699,23 @@ __global__ __launch_bounds__(kBlock) void k_tile_list(GridParams g, const uint32
         mb = max(mb, (uint32_t)__shfl_xor((int)mb, off, 64));
     }
     if (lane == 0 && mp) { atomicMax(&ctr->max_tile_pairs, mp); atomicMax(&ctr->max_tile_bodies, mb); }
+}
+
+__global__ __launch_bounds__(kBlock) void k_tile_list(GridParams g, const uint32_t* __restrict__ cell_start,
+                                                       uint32_t* __restrict__ tile_cnt, uint32_t* __restrict__ tile_flag,
+                                                       uint32_t* __restrict__ active, Counters* __restrict__ ctr) {
+    tile_list_step(blockIdx.x * kBlock + threadIdx.x, g, cell_start, tile_cnt, tile_flag, active, ctr);
+}
+
+// Grids of fewer than kScanTile tiles: one workgroup lists the tiles and then scans their pair counts (tile_cnt[0..ntiles]
+// becomes the tiles' pair offsets), one launch instead of two.
+__global__ __launch_bounds__(kBlock) void k_tile_list_scan(GridParams g, const uint32_t* __restrict__ cell_start,
+                                                            uint32_t* tile_cnt, uint32_t* __restrict__ tile_flag,
+                                                            uint32_t* __restrict__ active, Counters* __restrict__ ctr) {
+    for (uint32_t t0 = 0; t0 < g.ntiles; t0 += kBlock)
+        tile_list_step(t0 + threadIdx.x, g, cell_start, tile_cnt, tile_flag, active, ctr);
+    __syncthreads();  // the zeroed counts of tiles over capacity are visible to the scan
+    scan_tile(0u, tile_cnt, g.ntiles + 1u, nullptr, nullptr, 1);
 }
 
 // pair range of tile t after the scan, clamped to the pair capacity
