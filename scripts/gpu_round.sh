@@ -17,6 +17,9 @@ step rocprof-stats
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --steps 60 --warmup 20 --no-cpu --settle-frames 400 > $OUT/bench_rocprof.json 2> $OUT/bench_rocprof.err || { tail -20 $OUT/bench_rocprof.err; exit 1; }
 cat $OUT/bench_rocprof.json
+step rocprof-same
+# the default bench command itself under the kernel trace (CPU leg off): scripts/trace_window.py reads its settled ticks
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_same -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu > $OUT/bench_rocprof_same.json 2> $OUT/bench_rocprof_same.err || { tail -20 $OUT/bench_rocprof_same.err; exit 1; }
 step native
 cd $GRAFT_REPO_ROOT
 timeout -k 10 120 tools/sfx_run data/pile100k.bin 200 400 > $OUT/sfx_run.log 2>&1 || { tail $OUT/sfx_run.log; exit 1; }
