@@ -344,10 +344,15 @@ def test_pair_capacity_overflow_reported():
         w.sync()
 
 
-def test_largest_grid_scans():
-    """4096 x 4096 buckets (what a 4 M-body scene resolves to): the cell scan takes 2^24 + 1 items."""
+@pytest.mark.parametrize("grid_log2", [(12, 12), (9, 9), (10, 10), (6, 6)], ids=["4096x4096", "512x512", "1024x1024", "64x64"])
+def test_largest_grid_scans(grid_log2):
+    """4096 x 4096 buckets (what a 4 M-body scene resolves to): the cell scan takes 2^24 + 1 items, 4097 scan tiles
+    whose totals k_scan_sums scans.  512 x 512 (the 100 k pile's grid): 65 scan tiles, k_scan_add sums the totals
+    before its tile itself; 1024 x 1024: 257 tiles, the first count over that path's limit; 64 x 64: two tiles.
+    The tile lists of the small grids come from the one-workgroup k_tile_list_scan, the large ones from
+    k_tile_list + the scan launches."""
     s = scenes.random_soup(400, seed=9, extent=5.0)
-    g, o = make_pair(s, grid_log2=(12, 12))
+    g, o = make_pair(s, grid_log2=grid_log2)
     g.broadphase(DT)
     o.broadphase(DT)
     assert np.array_equal(g.pairs(), o.pairs())
