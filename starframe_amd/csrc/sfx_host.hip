@@ -74,7 +74,8 @@ struct sfx_world {
     DevBuf<uint32_t> zero;
     Counters* ctr = nullptr;
     uint32_t *cell_start = nullptr, *tile_cnt = nullptr, *tile_fill = nullptr, *tile_flag = nullptr, *tile_batch = nullptr;
-    size_t zero_bytes = 0;
+    size_t zero_bytes = 0;         // one half of `zero`: the tick's counters, cell counts and tile tables
+    uint32_t zero_half = 0;        // the half this tick uses; the other one is cleared while it runs (broadphase)
     DevBuf<uint32_t> bucket, cell_fill, tmp_id, sorted_id, large_tmp, slot_cnt, slot_off, scan_sums, active;
     DevBuf<BatchDesc> batches;
     DevBuf<uint4> torder;
@@ -340,6 +341,19 @@ ContactArrays contact_arrays(sfx_world* w) {
     return C;
 }
 
+// The tick's zero-initialised block (counters, cell counts, tile tables) exists twice: a tick works in one half while its
+// first kernel clears the other for the next tick, so that no tick starts with a clearing launch of its own.
+void point_zero_block(sfx_world* w) {
+    const size_t pad = kScanItems;
+    uint32_t* base = w->zero.p + (size_t)w->zero_half * (w->zero_bytes / 4);
+    w->ctr = reinterpret_cast<Counters*>(base);
+    w->cell_start = base + sizeof(Counters) / 4;
+    w->tile_cnt = w->cell_start + ((size_t)w->ncell + 1 + pad);
+    w->tile_fill = w->tile_cnt + ((size_t)w->ntiles + 1 + pad);
+    w->tile_flag = w->tile_fill + w->ntiles;
+    w->tile_batch = w->tile_flag + w->ntiles;
+}
+
 // exclusive scan of data[0..count) in place (count <= 8192 * 4096); copy receives the result too
 int scan_u32(sfx_world* w, uint32_t* data, uint32_t count, uint32_t* copy) {
     const uint32_t nb = cdiv(count, kScanTile);
@@ -387,14 +401,22 @@ void color_global(sfx_world* w, const uint2* edges, const uint32_t* n_edges, uin
 int broadphase(sfx_world* w, float dt) {
     const uint32_t n = w->n;
     const GridParams g = grid_params(w);
-    { Prof p(w, SFX_K_AABB_COUNT, 0);
-      const uint32_t n16 = (uint32_t)(w->zero_bytes / 16);
-      hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, reinterpret_cast<uint4*>(w->zero.p), n16); }
+    // this tick takes the half that the previous tick cleared; the previous tick's half is cleared by k_aabb_count on the way
+    // (by k_zero when the block is large against the body count: a 4096 x 4096 grid with a few hundred bodies)
+    uint4* stale_half = reinterpret_cast<uint4*>(w->zero.p + (size_t)w->zero_half * (w->zero_bytes / 4));
+    w->zero_half ^= 1u;
+    point_zero_block(w);
     const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
+    uint32_t n16 = (uint32_t)(w->zero_bytes / 16);
+    if (n16 > 16u * gb * kBlock) {
+      Prof p(w, SFX_K_AABB_COUNT, 0);
+      hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, stale_half, n16);
+      n16 = 0u;
+    }
     { Prof p(w, SFX_K_AABB_COUNT, n);
       hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p,
                          w->poly.p, w->cfg.aabb_margin, w->cfg.vel_pad_max, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start,
-                         w->large_tmp.p, w->large_cap, w->ctr); }
+                         w->large_tmp.p, w->large_cap, w->ctr, stale_half, n16); }
     int rc = scan_u32(w, w->cell_start, w->ncell + 1, w->cell_fill.p);
     if (rc) return rc;
     { Prof p(w, SFX_K_SCATTER, n);
@@ -747,14 +769,10 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     const size_t words = sizeof(Counters) / 4 + ((size_t)w->ncell + 1 + pad) + ((size_t)w->ntiles + 1 + pad) +
                          3 * (size_t)w->ntiles;
     const size_t words16 = (words + 3) & ~(size_t)3;  // cleared by k_zero in 16-byte units
-    ALLOC(w, w->zero, words16);
+    ALLOC(w, w->zero, 2 * words16);
     w->zero_bytes = words16 * 4;
-    w->ctr = reinterpret_cast<Counters*>(w->zero.p);
-    w->cell_start = w->zero.p + sizeof(Counters) / 4;
-    w->tile_cnt = w->cell_start + ((size_t)w->ncell + 1 + pad);
-    w->tile_fill = w->tile_cnt + ((size_t)w->ntiles + 1 + pad);
-    w->tile_flag = w->tile_fill + w->ntiles;
-    w->tile_batch = w->tile_flag + w->ntiles;
+    w->zero_half = 0;
+    point_zero_block(w);
     ALLOC(w, w->cell_fill, (size_t)w->ncell + 1 + pad);
     ALLOC(w, w->active, 2 * (size_t)w->ntiles); ALLOC(w, w->batches, 2 * (size_t)w->ntiles);
     ALLOC(w, w->rawp, w->max_pairs); ALLOC(w, w->tpair, w->max_pairs); ALLOC(w, w->torder, w->max_pairs);
@@ -770,7 +788,7 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     const size_t mp = (size_t)w->max_pairs + w->fb_cap;  // record slots: tile pairs, then the fallback list
     ALLOC(w, w->c_rec, 4 * mp); ALLOC(w, w->c_lam, mp);
     HIPCHK(w, hipMemset(w->c_rec.p, 0, sizeof(float4) * 4 * mp));
-    HIPCHK(w, hipMemset(w->zero.p, 0, w->zero_bytes));
+    HIPCHK(w, hipMemset(w->zero.p, 0, 2 * w->zero_bytes));
     w->ctr_valid = false; w->ctr_pending = false;
     w->ticked = false;
     w->q_valid = false;
@@ -1184,7 +1202,8 @@ int ensure_query_index(sfx_world* w) {
     HIPCHK(w, hipMemsetAsync(w->q_bounds.p, 0, 4 * sizeof(uint32_t), w->stream));
     { Prof p(w, SFX_K_QUERY, n);
       hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p, w->poly.p,
-                         0.0f, 0.0f, 0.0f, g, w->q_aabb.p, w->q_bucket.p, w->q_cellxy.p, qcs, w->q_large_tmp.p, w->large_cap, qctr); }
+                         0.0f, 0.0f, 0.0f, g, w->q_aabb.p, w->q_bucket.p, w->q_cellxy.p, qcs, w->q_large_tmp.p, w->large_cap, qctr,
+                         (uint4*)nullptr, 0u); }
     rc = scan_u32(w, qcs, w->ncell + 1, w->q_cell_fill.p);
     if (rc) return rc;
     { Prof p(w, SFX_K_QUERY, n);

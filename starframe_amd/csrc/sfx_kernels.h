@@ -162,8 +162,11 @@ __global__ __launch_bounds__(kBlock) void k_aabb_count(uint32_t n, const float4*
                                                         float dt, GridParams g, float4* __restrict__ aabb,
                                                         uint32_t* __restrict__ bucket, int2* __restrict__ cellxy,
                                                         uint32_t* __restrict__ cell_count, uint32_t* __restrict__ large_tmp,
-                                                        uint32_t large_cap, Counters* __restrict__ ctr) {
+                                                        uint32_t large_cap, Counters* __restrict__ ctr,
+                                                        uint4* __restrict__ stale_half, uint32_t n16) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    // the zero block of the previous tick (the next tick's): cleared here, nothing in this tick reads it
+    for (uint32_t k = i; k < n16; k += gridDim.x * kBlock) stale_half[k] = make_uint4(0u, 0u, 0u, 0u);
     if (i >= n) return;
     const float4 sh = shape[i];
     const float4 A = compute_aabb(pose[i], vel[i], sh, poly, margin, vel_pad_max, dt);
