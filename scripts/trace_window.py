@@ -1,7 +1,7 @@
 """Per-kernel mean duration over the LAST ticks of a rocprofv3 --kernel-trace run of bench.py (the settled pile the
 timed region runs on; the --stats summary of the same run averages over the 600 settling ticks as well):
    python scripts/trace_window.py <dir>/bench_kernel_trace.csv [ticks=200] [skip_last=70]
-A tick starts at a k_zero dispatch.  Durations are End - Start of each dispatch; gaps are Start(next) - End."""
+A tick starts at a k_aabb_count dispatch (its first kernel; traces from before the double zero block: k_zero).  Durations are End - Start of each dispatch; gaps are Start(next) - End."""
 import collections
 import csv
 import statistics as st
@@ -12,7 +12,8 @@ ticks = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 skip = int(sys.argv[3]) if len(sys.argv) > 3 else 70     # the second (all-events) leg and the stats calls at the end
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = [r["Kernel_Name"].split("(")[0].replace("void ", "").replace("sfx::", "") for r in rows]
-zeros = [i for i, n in enumerate(names) if n == "k_zero"]
+first = "k_zero" if "k_zero" in names else "k_aabb_count"
+zeros = [i for i, n in enumerate(names) if n == first]
 sel = zeros[-(ticks + skip) - 1:-skip]
 durs, tick_ns, busy, gap = collections.defaultdict(list), [], [], []
 for a, b in zip(sel[:-1], sel[1:]):
