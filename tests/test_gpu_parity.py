@@ -386,3 +386,25 @@ def test_batches_by_ticket_equal_batches_by_workgroup_index():
         assert np.array_equal(rot.view(np.uint32), ref_rot.view(np.uint32))
         assert np.array_equal(w.velocities()[0].view(np.uint32), ref_vel.view(np.uint32))
         w.close()
+
+
+def test_every_tick_starts_from_cleared_tables():
+    """The tick's zero-initialised block (counters, cell counts, tile tables) has two halves; a tick works in the half
+    that the previous tick's k_aabb_count cleared.  After each of several ticks the oracle takes the GPU's state over
+    and both run the broadphase: pair sets, tiles and colours are equal every time (a count or a flag left over from
+    two ticks earlier would show up as a missing or an extra pair, or as a tile on the wrong list)."""
+    s = scenes.random_soup(1500, seed=5, extent=7.0)
+    g, o = make_pair(s)
+    for tick in range(5):
+        g.step(DT)
+        pos, rot = g.poses()
+        vel, angvel = g.velocities()
+        o.set_state(pos, rot, vel, angvel, s.inv_mass, s.inv_inertia)
+        g.broadphase(DT)   # one more flip of the halves between two ticks
+        o.broadphase(DT)
+        assert np.array_equal(g.pairs(), o.pairs()), tick
+        gk, gc, gt = colors_by_key(*g.pair_colors())
+        ok, oc, ot = colors_by_key(*o.pair_colors())
+        assert np.array_equal(gk, ok) and np.array_equal(gt, ot) and np.array_equal(gc, oc), tick
+        gs, os_ = g.stats(), o.stats()
+        assert gs.overflow == 0 and gs.n_pairs == os_.n_pairs and gs.n_fallback == os_.n_fallback, tick
