@@ -298,6 +298,23 @@ int sfx_query_aabbs(sfx_world* w, uint32_t n, const float* boxes /* [n][4] */, u
 int sfx_query_rays(sfx_world* w, uint32_t n, const float* rays /* [n][4] */, const float* max_t /* [n] */,
                    uint32_t mask, sfx_ray_hit* hits /* [n] */);
 
+/* ---- the entry point that allocates nothing ------------------------------------------------
+ * sfx_query_points_static has NO counterpart in the reference (and none in SURVEY.md section 8): it is
+ * sfx_query_points for callers that cannot allocate device memory or synchronise -- code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc.  Same kernels and the same results as
+ * sfx_query_points, but
+ *  - the query index lives in a file-scope static device array of the library (10.5 MB per GPU the library
+ *    runs on, held until the process ends) instead of buffers allocated at the first query;
+ *  - points, body and count are DEVICE pointers ([n][2] floats, [n], [n] or NULL); nothing is copied;
+ *  - everything is enqueued on the world's stream and the call returns without synchronising; it calls no
+ *    hipMalloc / hipFree / allocating routine.
+ * Limits: worlds of at most 131072 bodies on a grid of at most 2^18 cells (the automatic grid of <= 131072
+ * bodies), else SFX_ERR_UNSUPPORTED; profiling must be off (event pools allocate), else SFX_ERR_INVALID.
+ * The index is rebuilt by every call.  All worlds on a GPU share that GPU's array: calls that overlap on one
+ * GPU (two streams, two threads) race; serialise them. */
+int sfx_query_points_static(sfx_world* w, uint32_t n, const float* points_dev /* [n][2], device */, uint32_t mask,
+                            uint32_t* body_dev /* [n], device */, uint32_t* count_dev /* [n] or NULL, device */);
+
 /* ---- parity hooks (slow paths, used by tests) ----------------------------- */
 /* world AABBs [n][4] = (lo.x, lo.y, hi.x, hi.y) of the last tick's broadphase */
 int sfx_debug_aabbs(sfx_world* w, float* out);

@@ -199,7 +199,7 @@ SFX_SYMBOLS = [
     "sfx_readback_begin", "sfx_readback_wait",
     "sfx_tick_begin", "sfx_tick_substep", "sfx_set_stream", "sfx_halo_set", "sfx_halo_pack", "sfx_halo_unpack",
     "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy",
-    "sfx_query_points", "sfx_query_aabbs", "sfx_query_rays",
+    "sfx_query_points", "sfx_query_aabbs", "sfx_query_rays", "sfx_query_points_static",
     "sfx_debug_aabbs", "sfx_debug_pairs", "sfx_debug_pair_colors", "sfx_debug_broadphase",
     "sfx_debug_contacts", "sfx_debug_joint_order",
     "sfx_stats", "sfx_set_profiling", "sfx_kernel_times", "sfx_kernel_class_name",
@@ -273,7 +273,8 @@ def load_libsfx(path=None):
     lib.sfx_query_points.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_uint32, vp, vp]
     lib.sfx_query_aabbs.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_uint32, vp, C.c_size_t, P(C.c_size_t)]
     lib.sfx_query_rays.argtypes = [vp, C.c_uint32, P(C.c_float), P(C.c_float), C.c_uint32, vp]
-    for n in ("sfx_query_points", "sfx_query_aabbs", "sfx_query_rays"):
+    lib.sfx_query_points_static.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, vp]
+    for n in ("sfx_query_points", "sfx_query_aabbs", "sfx_query_rays", "sfx_query_points_static"):
         getattr(lib, n).restype = C.c_int
     lib.sfx_debug_aabbs.argtypes = [vp, P(C.c_float)]
     lib.sfx_debug_pairs.argtypes = [vp, vp, C.c_size_t, P(C.c_size_t)]

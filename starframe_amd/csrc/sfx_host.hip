@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,21 @@ static std::atomic<int> g_live_worlds[kMaxDevices];
 static const bool g_shared_device = [] { const char* e = getenv("SFX_SHARED_DEVICE"); return e && e[0] == '1'; }();
 
 constexpr uint32_t kTargetBatches = 224;  // batches per phase the grouping aims at (< 256 CUs)
+
+// ---- static device scratch of sfx_query_points_static (the entry point that allocates nothing) ----------------
+// Holds one query index (DESIGN.md "Contract / spatial queries") for a world of at most kStaticMaxBodies bodies on
+// a grid of at most kStaticMaxCells buckets.  Every GPU the library runs on holds its own copy of the array, at its
+// own address, until the process ends; `scratch` below is only the host-side stand-in of the symbol, the device
+// address is looked up once per device (scratch_address) and everything on the host goes through that pointer.
+constexpr uint32_t kStaticMaxBodies = 131072u;
+constexpr uint32_t kStaticMaxCells = 1u << 18;
+constexpr size_t kStaticZeroBytes = ((sizeof(sfx::Counters) + ((size_t)kStaticMaxCells + 1 + sfx::kScanItems) * 4 + 255) / 256) * 256;
+constexpr size_t kStaticFillBytes = ((((size_t)kStaticMaxCells + 1 + sfx::kScanItems) * 4 + 255) / 256) * 256;
+constexpr size_t kStaticScratchBytes = kStaticZeroBytes + kStaticFillBytes + 256 /* bounds */ +
+                                       (size_t)kStaticMaxBodies * (4 * 4 + 2 * 16 + 2 * 8);   // = 10.5 MB
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+static unsigned char* g_scratch_ptr[kMaxDevices];   // device address of `scratch` on each device, nullptr = not looked up yet
+static std::mutex g_scratch_mutex;
 
 
 namespace {
@@ -182,6 +198,21 @@ int fail(sfx_world* w, int code, const char* fmt, ...) {
             return fail(w, SFX_ERR_NOMEM, "hipMalloc of %zu bytes failed for " #buf,     \
                         (size_t)(count) * sizeof(*(buf).p));                             \
     } while (0)
+
+// device address of the static scratch array on `device`, which must be the current device (looked up once per device)
+int scratch_address(int device, unsigned char** out, hipError_t* err) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) { *err = hipErrorInvalidDevice; return -1; }
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        unsigned char* ptr = nullptr;
+        const hipError_t e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) { *err = e != hipSuccess ? e : hipErrorInvalidSymbol; return -1; }
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
 
 void resolve_defaults(sfx_config& c) {
     if (c.substeps == 0) c.substeps = 1;
@@ -598,6 +629,15 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
         return SFX_ERR_DEVICE;
     }
     w->stream = w->own_stream_handle;
+    {   // the static scratch of sfx_query_points_static: its address on this device, with the device current
+        unsigned char* sp = nullptr;
+        hipError_t se = hipSuccess;
+        if (w->device < kMaxDevices && scratch_address(w->device, &sp, &se) != 0) {
+            fail(nullptr, SFX_ERR_DEVICE, "hipGetSymbolAddress(scratch) failed on device %d: %s", w->device, hipGetErrorString(se));
+            sfx_destroy(w);
+            return SFX_ERR_DEVICE;
+        }
+    }
     if (w->jctr.alloc(1) || w->scan_sums.alloc(1024 * kSumItems) || w->left_list.alloc(kLeftCap) ||
         w->j_count_dev.alloc(1)) {
         fail(nullptr, SFX_ERR_NOMEM, "hipMalloc failed");
@@ -1168,8 +1208,63 @@ int sfx_halo_copy(sfx_world* dst, uint32_t dst_first, sfx_world* src, uint32_t s
 // ---- spatial queries ------------------------------------------------------------------
 namespace {
 
-// (re)builds the query index at the current poses: the broadphase's counting sort on tight AABBs
-// (margin, pad and dt = 0, row-major buckets) in buffers of its own, then the bounds of the small boxes
+// The buffers of a query index: the library's own (allocated at the first query) or carved out of the static device
+// scratch array of sfx_query_points_static.
+struct QueryBuffers {
+    uint32_t* zero;      // [Counters][cell_start: ncell + 1 + pad], cleared by k_zero
+    size_t zero_bytes;
+    uint32_t *cell_fill, *bucket, *tmp_id, *sorted_id, *large_tmp, *bounds;
+    float4 *aabb, *sorted_aabb;
+    int2 *cellxy, *sorted_cell;
+};
+
+size_t query_zero_words(const sfx_world* w) {
+    const size_t words = sizeof(Counters) / 4 + ((size_t)w->ncell + 1 + kScanItems);
+    return (words + 3) & ~(size_t)3;  // cleared in 16-byte units
+}
+
+// builds the query index at the current poses into Q: the broadphase's counting sort on tight AABBs
+// (margin, pad and dt = 0, row-major buckets), then the bounds of the small boxes.  Enqueues only.
+int build_query_index(sfx_world* w, const QueryBuffers& Q) {
+    const uint32_t n = w->n;
+    Counters* qctr = reinterpret_cast<Counters*>(Q.zero);
+    uint32_t* qcs = Q.zero + sizeof(Counters) / 4;
+    GridParams g = grid_params(w);
+    g.tlx = 0; g.tly = 0; g.ntiles = w->ncell; g.pstride = 0;  // plain row-major buckets
+    const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
+    { Prof p(w, SFX_K_QUERY, 0);
+      const uint32_t n16 = (uint32_t)(Q.zero_bytes / 16);
+      hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, reinterpret_cast<uint4*>(Q.zero), n16); }
+    HIPCHK(w, hipMemsetAsync(Q.bounds, 0, 4 * sizeof(uint32_t), w->stream));
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p, w->poly.p,
+                         0.0f, 0.0f, 0.0f, g, Q.aabb, Q.bucket, Q.cellxy, qcs, Q.large_tmp, w->large_cap, qctr,
+                         (uint4*)nullptr, 0u); }
+    int rc = scan_u32(w, qcs, w->ncell + 1, Q.cell_fill);
+    if (rc) return rc;
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(kBlock), 0, w->stream, n, Q.bucket, Q.cell_fill, Q.tmp_id); }
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_finalize_slots, dim3(gb), dim3(kBlock), 0, w->stream, n, g, qcs, Q.tmp_id, Q.bucket,
+                         Q.aabb, Q.cellxy, Q.large_tmp, w->large_cap, Q.sorted_id, Q.sorted_aabb,
+                         Q.sorted_cell, qctr); }
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_query_bounds, dim3(std::min(gb, 1024u)), dim3(kBlock), 0, w->stream, qcs, w->ncell,
+                         Q.sorted_aabb, Q.bounds); }
+    HIPCHK(w, hipGetLastError());
+    return SFX_OK;
+}
+
+QueryBuffers own_query_buffers(sfx_world* w) {
+    QueryBuffers Q{};
+    Q.zero = w->q_zero.p; Q.zero_bytes = w->q_zero_bytes;
+    Q.cell_fill = w->q_cell_fill.p; Q.bucket = w->q_bucket.p; Q.tmp_id = w->q_tmp_id.p; Q.sorted_id = w->q_sorted_id.p;
+    Q.large_tmp = w->q_large_tmp.p; Q.bounds = w->q_bounds.p;
+    Q.aabb = w->q_aabb.p; Q.sorted_aabb = w->q_sorted_aabb.p; Q.cellxy = w->q_cellxy.p; Q.sorted_cell = w->q_sorted_cell.p;
+    return Q;
+}
+
+// (re)builds the library-owned query index when the poses changed since the last query
 int ensure_query_index(sfx_world* w) {
     int rc = ready(w);
     if (rc) return rc;
@@ -1179,8 +1274,7 @@ int ensure_query_index(sfx_world* w) {
     const size_t pad = kScanItems;
     if (w->q_n != n || w->q_ncell != w->ncell || !w->q_zero.p) {
         const size_t c = std::max(n, 1u);
-        const size_t words = sizeof(Counters) / 4 + ((size_t)w->ncell + 1 + pad);
-        const size_t words16 = (words + 3) & ~(size_t)3;
+        const size_t words16 = query_zero_words(w);
         ALLOC(w, w->q_zero, words16);
         w->q_zero_bytes = words16 * 4;
         ALLOC(w, w->q_cell_fill, (size_t)w->ncell + 1 + pad);
@@ -1191,31 +1285,8 @@ int ensure_query_index(sfx_world* w) {
         w->q_valid = false;
     }
     if (w->q_valid) return SFX_OK;
-    Counters* qctr = reinterpret_cast<Counters*>(w->q_zero.p);
-    uint32_t* qcs = w->q_zero.p + sizeof(Counters) / 4;
-    GridParams g = grid_params(w);
-    g.tlx = 0; g.tly = 0; g.ntiles = w->ncell; g.pstride = 0;  // plain row-major buckets
-    const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
-    { Prof p(w, SFX_K_QUERY, 0);
-      const uint32_t n16 = (uint32_t)(w->q_zero_bytes / 16);
-      hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, reinterpret_cast<uint4*>(w->q_zero.p), n16); }
-    HIPCHK(w, hipMemsetAsync(w->q_bounds.p, 0, 4 * sizeof(uint32_t), w->stream));
-    { Prof p(w, SFX_K_QUERY, n);
-      hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p, w->poly.p,
-                         0.0f, 0.0f, 0.0f, g, w->q_aabb.p, w->q_bucket.p, w->q_cellxy.p, qcs, w->q_large_tmp.p, w->large_cap, qctr,
-                         (uint4*)nullptr, 0u); }
-    rc = scan_u32(w, qcs, w->ncell + 1, w->q_cell_fill.p);
+    rc = build_query_index(w, own_query_buffers(w));
     if (rc) return rc;
-    { Prof p(w, SFX_K_QUERY, n);
-      hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(kBlock), 0, w->stream, n, w->q_bucket.p, w->q_cell_fill.p, w->q_tmp_id.p); }
-    { Prof p(w, SFX_K_QUERY, n);
-      hipLaunchKernelGGL(k_finalize_slots, dim3(gb), dim3(kBlock), 0, w->stream, n, g, qcs, w->q_tmp_id.p, w->q_bucket.p,
-                         w->q_aabb.p, w->q_cellxy.p, w->q_large_tmp.p, w->large_cap, w->q_sorted_id.p, w->q_sorted_aabb.p,
-                         w->q_sorted_cell.p, qctr); }
-    { Prof p(w, SFX_K_QUERY, n);
-      hipLaunchKernelGGL(k_query_bounds, dim3(std::min(gb, 1024u)), dim3(kBlock), 0, w->stream, qcs, w->ncell,
-                         w->q_sorted_aabb.p, w->q_bounds.p); }
-    HIPCHK(w, hipGetLastError());
     w->q_valid = true;
     return SFX_OK;
 }
@@ -1227,16 +1298,18 @@ int query_buffers(sfx_world* w, size_t in_bytes, size_t out_bytes) {
     return SFX_OK;
 }
 
-QueryIndex query_index(sfx_world* w) {
+QueryIndex query_index_of(sfx_world* w, const QueryBuffers& B) {
     QueryIndex Q;
-    Q.cell_start = w->q_zero.p + sizeof(Counters) / 4;
-    Q.sorted_id = w->q_sorted_id.p; Q.sorted_aabb = w->q_sorted_aabb.p; Q.sorted_cell = w->q_sorted_cell.p;
-    Q.ctr = reinterpret_cast<const Counters*>(w->q_zero.p);
-    Q.bounds = w->q_bounds.p;
+    Q.cell_start = B.zero + sizeof(Counters) / 4;
+    Q.sorted_id = B.sorted_id; Q.sorted_aabb = B.sorted_aabb; Q.sorted_cell = B.sorted_cell;
+    Q.ctr = reinterpret_cast<const Counters*>(B.zero);
+    Q.bounds = B.bounds;
     Q.gxl = w->gxl; Q.gyl = w->gyl; Q.ncell = w->ncell; Q.large_cap = w->large_cap;
     Q.inv_cell = w->inv_cell; Q.cell = w->cell;
     return Q;
 }
+
+QueryIndex query_index(sfx_world* w) { return query_index_of(w, own_query_buffers(w)); }
 
 }  // namespace
 
@@ -1305,6 +1378,50 @@ int sfx_query_rays(sfx_world* w, uint32_t n, const float* rays, const float* max
     if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
     if (e != hipSuccess) return fail(w, SFX_ERR_DEVICE, "ray query failed: %s", hipGetErrorString(e));
     return w->profiling ? collect_profile(w) : SFX_OK;
+}
+
+// The point query without any allocation: same kernels as sfx_query_points, the query index in the static device
+// scratch array instead of library-allocated buffers, inputs and outputs in DEVICE memory, everything enqueued on the
+// world's stream (no copy, no synchronisation).  The index is rebuilt by every call (the scratch is shared by all
+// worlds of the device and keeps the last call's contents: the counters, the cell histogram and the bounds are
+// cleared first).  Calls that overlap on one GPU (two streams, two threads, two processes do NOT share it: the
+// array is per process) race on the scratch.
+int sfx_query_points_static(sfx_world* w, uint32_t n, const float* points_dev, uint32_t mask, uint32_t* body_dev,
+                            uint32_t* count_dev) {
+    if (!w || (n && (!points_dev || !body_dev))) return fail(w, SFX_ERR_INVALID, "null argument");
+    int rc = ready(w);
+    if (rc) return rc;
+    if (w->tick_open) return fail(w, SFX_ERR_INVALID, "spatial queries are not allowed inside an open tick");
+    if (w->n > kStaticMaxBodies || w->ncell > kStaticMaxCells)
+        return fail(w, SFX_ERR_UNSUPPORTED, "sfx_query_points_static: %u bodies / %u grid cells exceed the static scratch (%u bodies, %u cells); use sfx_query_points",
+                    w->n, w->ncell, kStaticMaxBodies, kStaticMaxCells);
+    if (w->profiling || w->prof_mask) return fail(w, SFX_ERR_INVALID, "sfx_query_points_static: switch profiling off (event pools allocate)");
+    if (w->device >= kMaxDevices || !g_scratch_ptr[w->device]) return fail(w, SFX_ERR_DEVICE, "static scratch address unknown for device %d", w->device);
+    HIPCHK(w, hipSetDevice(w->device));
+    if (n == 0) return SFX_OK;
+    // carve the index out of the scratch through its DEVICE address (never through the symbol's host-side name)
+    unsigned char* ptr = g_scratch_ptr[w->device];
+    QueryBuffers Q{};
+    const size_t nb = kStaticMaxBodies;
+    Q.zero = reinterpret_cast<uint32_t*>(ptr); Q.zero_bytes = query_zero_words(w) * 4; ptr += kStaticZeroBytes;
+    Q.cell_fill = reinterpret_cast<uint32_t*>(ptr); ptr += kStaticFillBytes;
+    Q.bounds = reinterpret_cast<uint32_t*>(ptr); ptr += 256;
+    Q.aabb = reinterpret_cast<float4*>(ptr); ptr += 16 * nb;
+    Q.sorted_aabb = reinterpret_cast<float4*>(ptr); ptr += 16 * nb;
+    Q.cellxy = reinterpret_cast<int2*>(ptr); ptr += 8 * nb;
+    Q.sorted_cell = reinterpret_cast<int2*>(ptr); ptr += 8 * nb;
+    Q.bucket = reinterpret_cast<uint32_t*>(ptr); ptr += 4 * nb;
+    Q.tmp_id = reinterpret_cast<uint32_t*>(ptr); ptr += 4 * nb;
+    Q.sorted_id = reinterpret_cast<uint32_t*>(ptr); ptr += 4 * nb;
+    Q.large_tmp = reinterpret_cast<uint32_t*>(ptr); ptr += 4 * nb;
+    static_assert(kStaticZeroBytes + kStaticFillBytes + 256 + (size_t)kStaticMaxBodies * 64 == kStaticScratchBytes, "scratch layout");
+    if (Q.zero_bytes > kStaticZeroBytes) return fail(w, SFX_ERR_UNSUPPORTED, "sfx_query_points_static: grid too large for the scratch");
+    rc = build_query_index(w, Q);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_query_points, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, w->stream, n, reinterpret_cast<const float2*>(points_dev),
+                       mask, query_index_of(w, Q), body_arrays(w), body_dev, count_dev);
+    HIPCHK(w, hipGetLastError());
+    return SFX_OK;
 }
 
 int sfx_sync(sfx_world* w) {

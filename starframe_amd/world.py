@@ -205,6 +205,12 @@ class World(WorldBase):
         self._check(self.lib.sfx_query_rays(self.handle, len(r), fptr(r), fptr(mt), mask, vptr(out)))
         return out
 
+    def query_points_static(self, points_dev, n, body_dev, count_dev=0, mask=0xFFFFFFFF):
+        """sfx_query_points_static: device addresses (ints) of [n][2] float points and [n] uint32 outputs; enqueues on
+        the world's stream, allocates nothing, does not synchronise."""
+        self._check(self.lib.sfx_query_points_static(self.handle, n, C.c_void_p(points_dev), mask, C.c_void_p(body_dev),
+                                                     C.c_void_p(count_dev or None)))
+
     # ---- parity hooks
     def broadphase(self, dt):
         self._check(self.lib.sfx_debug_broadphase(self.handle, dt))
