@@ -232,6 +232,12 @@ int sfx_upload_angle_constraints(sfx_world* w, uint32_t m, const sfx_angle_const
  * solve, velocity derive, velocity pass).  Asynchronous on the world's
  * stream; sfx_sync / any download waits for it. */
 int sfx_step(sfx_world* w, float frame_dt);
+/* Waits for everything enqueued.  Capacity overflows are detected on the device and kept in a sticky word until a
+ * call reports them: sfx_sync returns SFX_ERR_CAPACITY -- once -- when ANY tick since the last sfx_sync exceeded a
+ * capacity (candidate pairs, colours, fallback list, a fused launch that gave up waiting ...), however many ticks ago,
+ * and clears the condition.  sfx_step / sfx_tick_begin refuse to start a tick (SFX_ERR_CAPACITY, state untouched)
+ * once the host has seen such a bit (through its asynchronous counter read-back, a few ticks late) and until sfx_sync
+ * has reported it; sfx_frame_stats.overflow shows the bits without clearing them. */
 int sfx_sync(sfx_world* w);
 
 /* ---- the tick in pieces + slab halos (BASELINE.json:5 "slab domain decomposition,

@@ -114,6 +114,8 @@ struct sfx_world {
     DevBuf<uint32_t> left_list;
     DevBuf<uint8_t> pcolor, prop;
     DevBuf<Counters> jctr;
+    DevBuf<uint32_t> sticky;       // overflow bits of every tick since the last report (device side, see k_zero)
+    uint32_t ovf_host = 0;         // the same, as far as the host has seen them (polled counters)
     // slab halos
     DevBuf<uint32_t> halo_send_idx, halo_recv_idx;
     DevBuf<float4> halo_send, halo_recv;
@@ -223,7 +225,7 @@ void resolve_defaults(sfx_config& c) {
     if (c.speculative_margin < 0.0f) c.speculative_margin = 0.0f;
     if (c.restitution_threshold == 0.0f) c.restitution_threshold = 2.0f;
     if (c.vel_pad_max == 0.0f) c.vel_pad_max = 0.03f;
-    if (c.max_depenetration_velocity == 0.0f) c.max_depenetration_velocity = 3.0f;
+    if (c.max_depenetration_velocity == 0.0f) c.max_depenetration_velocity = 10.0f;
     if (c.max_depenetration_velocity < 0.0f) c.max_depenetration_velocity = INFINITY;
     if (c.vel_pad_max < 0.0f) c.vel_pad_max = 0.0f;
 }
@@ -441,13 +443,13 @@ int broadphase(sfx_world* w, float dt) {
     uint32_t n16 = (uint32_t)(w->zero_bytes / 16);
     if (n16 > 16u * gb * kBlock) {
       Prof p(w, SFX_K_AABB_COUNT, 0);
-      hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, stale_half, n16);
+      hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, stale_half, n16, w->sticky.p);
       n16 = 0u;
     }
     { Prof p(w, SFX_K_AABB_COUNT, n);
       hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p,
                          w->poly.p, w->cfg.aabb_margin, w->cfg.vel_pad_max, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start,
-                         w->large_tmp.p, w->large_cap, w->ctr, stale_half, n16); }
+                         w->large_tmp.p, w->large_cap, w->ctr, stale_half, n16, w->sticky.p); }
     int rc = scan_u32(w, w->cell_start, w->ncell + 1, w->cell_fill.p);
     if (rc) return rc;
     { Prof p(w, SFX_K_SCATTER, n);
@@ -506,6 +508,7 @@ void adopt_counters(sfx_world* w);
 void poll_counters(sfx_world* w) {
     if (w->ctr_pending && hipEventQuery(w->ev_ctr) == hipSuccess) {
         w->stale = *w->h_ctr;
+        w->ovf_host |= w->stale.overflow;
         w->ctr_pending = false;
         adopt_counters(w);
     }
@@ -583,6 +586,11 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
     resolve_defaults(w->cfg);
     w->device = cfg->device;
     if (w->device < kMaxDevices) { g_live_worlds[w->device].fetch_add(1); w->counted = true; }
+    if ((e = hipSetDevice(w->device)) != hipSuccess) {   // before the occupancy queries below: they are taken on the current device
+        fail(nullptr, SFX_ERR_DEVICE, "hipSetDevice(%d) failed: %s", w->device, hipGetErrorString(e));
+        sfx_destroy(w);
+        return SFX_ERR_DEVICE;
+    }
     // SFX_NULL_STREAM=1 runs the world on the device's default stream (profilers that cannot
     // follow a second queue)
     {   // how many workgroups of the solve kernels the device holds at once: a fused multi-phase launch is
@@ -639,7 +647,7 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
         }
     }
     if (w->jctr.alloc(1) || w->scan_sums.alloc(1024 * kSumItems) || w->left_list.alloc(kLeftCap) ||
-        w->j_count_dev.alloc(1)) {
+        w->j_count_dev.alloc(1) || w->sticky.alloc(4) || hipMemset(w->sticky.p, 0, 16) != hipSuccess) {
         fail(nullptr, SFX_ERR_NOMEM, "hipMalloc failed");
         sfx_destroy(w);
         return SFX_ERR_NOMEM;
@@ -663,7 +671,7 @@ void sfx_destroy(sfx_world* w) {
     w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->slot_off.release(); w->scan_sums.release();
     w->cellxy.release(); w->sorted_cell.release();
     w->used.release(); w->claim.release(); w->left_list.release();
-    w->pcolor.release(); w->prop.release(); w->jctr.release(); w->dbg.release();
+    w->pcolor.release(); w->prop.release(); w->jctr.release(); w->sticky.release(); w->dbg.release();
     w->halo_send_idx.release(); w->halo_recv_idx.release(); w->halo_send.release(); w->halo_recv.release();
     w->q_zero.release(); w->q_bucket.release(); w->q_cell_fill.release(); w->q_tmp_id.release(); w->q_sorted_id.release();
     w->q_large_tmp.release(); w->q_bounds.release(); w->q_nhits.release(); w->q_aabb.release(); w->q_sorted_aabb.release();
@@ -829,6 +837,8 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     ALLOC(w, w->c_rec, 4 * mp); ALLOC(w, w->c_lam, mp);
     HIPCHK(w, hipMemset(w->c_rec.p, 0, sizeof(float4) * 4 * mp));
     HIPCHK(w, hipMemset(w->zero.p, 0, 2 * w->zero_bytes));
+    HIPCHK(w, hipMemset(w->sticky.p, 0, sizeof(uint32_t)));   // every table is new: earlier overflows no longer apply
+    w->ovf_host = 0;
     w->ctr_valid = false; w->ctr_pending = false;
     w->ticked = false;
     w->q_valid = false;
@@ -972,6 +982,9 @@ int sfx_tick_begin(sfx_world* w, float frame_dt) {
     if (!(frame_dt > 0.0f)) return fail(w, SFX_ERR_INVALID, "frame_dt must be positive");
     HIPCHK(w, hipSetDevice(w->device));
     poll_counters(w);
+    if (w->ovf_host)
+        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u, see sfx_sync): its results are incomplete; "
+                    "sfx_sync reports and clears the condition, raise the capacity (sfx_config.max_pairs) and upload again", w->ovf_host);
     w->launches = 0;
     rc = broadphase(w, frame_dt);
     if (rc) return rc;
@@ -1234,12 +1247,12 @@ int build_query_index(sfx_world* w, const QueryBuffers& Q) {
     const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
     { Prof p(w, SFX_K_QUERY, 0);
       const uint32_t n16 = (uint32_t)(Q.zero_bytes / 16);
-      hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, reinterpret_cast<uint4*>(Q.zero), n16); }
+      hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, reinterpret_cast<uint4*>(Q.zero), n16, (uint32_t*)nullptr); }
     HIPCHK(w, hipMemsetAsync(Q.bounds, 0, 4 * sizeof(uint32_t), w->stream));
     { Prof p(w, SFX_K_QUERY, n);
       hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p, w->poly.p,
                          0.0f, 0.0f, 0.0f, g, Q.aabb, Q.bucket, Q.cellxy, qcs, Q.large_tmp, w->large_cap, qctr,
-                         (uint4*)nullptr, 0u); }
+                         (uint4*)nullptr, 0u, (uint32_t*)nullptr); }
     int rc = scan_u32(w, qcs, w->ncell + 1, Q.cell_fill);
     if (rc) return rc;
     { Prof p(w, SFX_K_QUERY, n);
@@ -1429,16 +1442,26 @@ int sfx_sync(sfx_world* w) {
     HIPCHK(w, hipSetDevice(w->device));
     HIPCHK(w, hipStreamSynchronize(w->stream));
     poll_counters(w);
-    if (!w->ctr_pending && w->ctr_skipped && !w->tick_open) {
-        // the asynchronous read-back skipped the last ticks: a sync point reports what they flagged all the same
+    // Overflow bits live in three places: the tick's own counter block (the last tick's), the device's sticky word
+    // (every earlier tick's: folded in when its block is cleared, two ticks later) and what the asynchronous counter
+    // copies showed the host.  A sync point reports all of them, once, and clears them.
+    uint32_t bits = w->ovf_host, dev_sticky = 0;
+    HIPCHK(w, hipMemcpy(&dev_sticky, w->sticky.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    bits |= dev_sticky;
+    if (w->ticked && w->have_colliders && !w->tick_open) {
         int rc = sync_counters(w, &w->stale, w->ctr);
         if (rc) return rc;
         w->ctr_skipped = 0;
         adopt_counters(w);
+        bits |= w->stale.overflow;
     }
-    if (w->ctr_valid && w->stale.overflow)
-        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list, 32 a fused solve launch gave up waiting, 64 more than 64 large colliders over one batch of tiles)",
-                    w->stale.overflow);
+    if (bits) {
+        w->ovf_host = 0;
+        HIPCHK(w, hipMemset(w->sticky.p, 0, sizeof(uint32_t)));
+        if (w->ticked && w->have_colliders && !w->tick_open) { HIPCHK(w, hipMemset(&w->ctr->overflow, 0, sizeof(uint32_t))); w->stale.overflow = 0; }
+        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in a tick since the last sfx_sync (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list, 32 a fused solve launch gave up waiting, 64 more than 64 large colliders over one batch of tiles)",
+                    bits);
+    }
     return SFX_OK;
 }
 
@@ -1649,7 +1672,9 @@ int sfx_stats(sfx_world* w, sfx_frame_stats* out) {
     if (rc) return rc;
     w->launches = saved;
     out->n_small = c.n_small; out->n_large = c.n_large; out->n_pairs = c.n_pairs; out->n_colors = c.n_colors;
-    out->n_leftover = c.n_leftover; out->overflow = c.overflow;
+    uint32_t dev_sticky = 0;
+    HIPCHK(w, hipMemcpy(&dev_sticky, w->sticky.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
+    out->n_leftover = c.n_leftover; out->overflow = c.overflow | dev_sticky | w->ovf_host;   // this tick's and every unreported earlier one's
     out->n_tiles = c.n_active[0];
     out->n_fallback = c.n_fb; out->max_tile_pairs = c.max_tile_pairs; out->max_tile_bodies = c.max_tile_bodies;
     out->n_solver_pairs = c.n_kept + std::min(c.n_fb, w->fb_cap);

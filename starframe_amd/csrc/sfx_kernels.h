@@ -82,6 +82,7 @@ struct Counters {
     uint32_t pad3[3];
 };
 static_assert(sizeof(Counters) % 16 == 0, "the per-tick block is cleared in 16-byte units");
+static_assert(offsetof(Counters, overflow) == 12, "k_zero / k_aabb_count fold word 3 of the block into the sticky overflow word");
 
 struct GridParams {
     float inv_cell;
@@ -107,8 +108,11 @@ __device__ __forceinline__ uint32_t bucket_of(int32_t cx, int32_t cy, const Grid
 }
 
 // clears the per-tick block (counters, cell and tile histograms) with 16-byte stores
-__global__ __launch_bounds__(kBlock) void k_zero(uint4* __restrict__ p, uint32_t n16) {
+// `sticky` (may be null): the overflow bits of the block being cleared are kept in that word, so that a capacity
+// overflow of ANY tick stays visible until a synchronising call has reported it (sfx_sync)
+__global__ __launch_bounds__(kBlock) void k_zero(uint4* __restrict__ p, uint32_t n16, uint32_t* __restrict__ sticky) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i == 0u && sticky && n16) { const uint32_t o = p[0].w; if (o) atomicOr(sticky, o); }
     if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
 
@@ -163,9 +167,12 @@ __global__ __launch_bounds__(kBlock) void k_aabb_count(uint32_t n, const float4*
                                                         uint32_t* __restrict__ bucket, int2* __restrict__ cellxy,
                                                         uint32_t* __restrict__ cell_count, uint32_t* __restrict__ large_tmp,
                                                         uint32_t large_cap, Counters* __restrict__ ctr,
-                                                        uint4* __restrict__ stale_half, uint32_t n16) {
+                                                        uint4* __restrict__ stale_half, uint32_t n16,
+                                                        uint32_t* __restrict__ sticky) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    // the zero block of the previous tick (the next tick's): cleared here, nothing in this tick reads it
+    // the zero block of the previous tick (the next tick's): cleared here, nothing in this tick reads it; its overflow
+    // bits move to the sticky word first (thread 0 clears the unit that holds them itself, after reading it)
+    if (i == 0u && n16 && sticky) { const uint32_t o = stale_half[0].w; if (o) atomicOr(sticky, o); }
     for (uint32_t k = i; k < n16; k += gridDim.x * kBlock) stale_half[k] = make_uint4(0u, 0u, 0u, 0u);
     if (i >= n) return;
     const float4 sh = shape[i];

@@ -52,7 +52,18 @@ def make(name, s):
     print(name, s.n, "bodies", len(out["pairs"]), "pairs")
 
 
+def settled_pile(n=3000, width=50, frames=600):
+    """The headline workload in small: a mixed circle / rect / capsule pile settled with damping (on the oracle)."""
+    s = scenes.mixed_pile(n=n, width=width)
+    w = OracleWorld.from_scene(s, linear_damping=3.3, angular_damping=1.0)
+    for _ in range(frames):
+        w.step(DT, ORDER_COLORED)
+    pos, rot = w.poses()
+    return s.with_state(pos, rot, name="pile%d_settled" % n)
+
+
 if __name__ == "__main__":
+    make("pile3000_settled", settled_pile())
     make("soup200", scenes.random_soup(200, seed=21, extent=3.0))
     make("pyramid6", scenes.pyramid(base=6))
     make("chains4x20", scenes.chains(n_chains=4, links=20))

@@ -408,3 +408,70 @@ def test_every_tick_starts_from_cleared_tables():
         assert np.array_equal(gk, ok) and np.array_equal(gt, ot) and np.array_equal(gc, oc), tick
         gs, os_ = g.stats(), o.stats()
         assert gs.overflow == 0 and gs.n_pairs == os_.n_pairs and gs.n_fallback == os_.n_fallback, tick
+
+
+def test_overflow_of_one_tick_among_many_is_reported_by_the_next_sync():
+    """the overflow bits live in the per-tick counter block, which is cleared two ticks later, and the host
+    samples it only every 8th tick -- a capacity overflow in tick 3 of 10 used to be lost.  The bits are folded into a
+    sticky device word when the block is cleared: the sync after the ten ticks reports it, once."""
+    from starframe_amd.world import SfxError, World
+
+    s = scenes.random_soup(600, seed=5, extent=12.0)          # sparse: few hundred pairs
+    w = World.from_scene(s, max_pairs=1024)
+    crowd = s.pos * 0.12                                     # the same bodies crammed together: thousands of pairs
+    reported = 0
+    for tick in range(10):
+        if tick == 3:
+            w.set_state(crowd, s.rot, s.vel, s.angvel, s.inv_mass, s.inv_inertia)
+        if tick == 4:
+            w.set_state(s.pos, s.rot, s.vel, s.angvel, s.inv_mass, s.inv_inertia)
+        try:
+            w.step(DT)
+        except SfxError as e:                                # the host may have seen the bit already (counter read-back)
+            assert e.code == -4
+            reported += 1
+            break
+        if tick == 2:
+            w.sync()                                         # nothing has overflowed yet
+    try:
+        w.sync()
+    except SfxError as e:
+        assert e.code == -4 and "capacity" in str(e)
+        reported += 1
+    assert reported >= 1, "the overflow of tick 3 was lost"
+    w.sync()                                                 # reported once: the condition is cleared
+    w.step(DT)
+    w.sync()
+    assert w.stats().overflow == 0
+
+
+def test_tiny_grid_and_ticket_path_equal_the_default(monkeypatch):
+    """A fused tile-solve launch hands its batches out by ticket; the default grid holds every workgroup the device
+    can run.  With a deliberately tiny grid (4 workgroups for hundreds of batches: every workgroup takes dozens of
+    tickets, later phases wait on flags set by the same few workgroups) and with every batch handed out by ticket
+    (SFX_SHARED_DEVICE semantics: a second world alive), the states are bit-identical to the default path."""
+    from starframe_amd.world import World
+
+    s = scenes.mixed_pile(n=20000, width=400)
+
+    def run(extra_world=False):
+        w = World.from_scene(s)
+        other = World.from_scene(scenes.random_soup(100, seed=1, extent=3.0)) if extra_world else None
+        for _ in range(25):
+            w.step(DT)
+        w.sync()
+        assert w.stats().overflow == 0 and w.stats().n_manifolds > 1000
+        out = (w.poses(), w.velocities())
+        w.close()
+        if other:
+            other.close()
+        return out
+
+    ref = run()
+    monkeypatch.setenv("SFX_TILE_GRID_MAX", "4")
+    for extra in (False, True):
+        (pos, rot), (vel, ang) = run(extra)
+        assert np.array_equal(pos.view(np.uint32), ref[0][0].view(np.uint32))
+        assert np.array_equal(rot.view(np.uint32), ref[0][1].view(np.uint32))
+        assert np.array_equal(vel.view(np.uint32), ref[1][0].view(np.uint32))
+        assert np.array_equal(ang.view(np.uint32), ref[1][1].view(np.uint32))

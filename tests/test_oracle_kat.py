@@ -308,3 +308,58 @@ def test_pyramid_stands():
         assert st.kinetic_energy < 1e-3
         assert st.max_depth < 5e-3
         assert np.abs(rot[:-1, 1]).max() < 5e-3
+
+
+def contact_depths(w):
+    """All positive contact-point depths at the current poses (metres)."""
+    c = w.contacts()
+    d = np.concatenate([c["depth"][:, 0][c["count"] > 0], c["depth"][:, 1][c["count"] > 1]])
+    return d[d > 0]
+
+
+@pytest.mark.parametrize("order", [ORDER_SEQUENTIAL, ORDER_COLORED], ids=["sequential", "coloured"])
+def test_deep_column_carries_its_weight(order):
+    """A 50-layer column at 4 substeps.  XPBD with one iteration per substep corrects a contact by what it finds, so
+    a contact that carries k bodies sits about k g h^2 deep (0.17 mm per body at h = 1/240 s): the column compresses
+    by a bounded amount and stays a column.  It collapses (circles overlapping by their whole diameter) when the
+    per-substep correction is clamped below that load: at the former default of 3 m/s x h = 12.5 mm a contact held
+    73 bodies at rest and, with the transient of the start, a 50-layer column lost 1.15 m of its 7.5 m
+    (scripts/penetration_study.py); the default is 10 m/s now (DESIGN.md "Position solve")."""
+    r, layers = 0.075, 50
+    b = SceneBuilder("column", substeps=4)
+    b.static_rect((0.0, -0.5), 5.0, 0.5)
+    for k in range(layers):
+        b.circle((0.0, r + 2 * r * k), r)
+    w = world(b)
+    for _ in range(400):
+        w.step(DT, order)
+    pos, _ = w.poses()
+    y = pos[1:, 1]
+    gaps = np.diff(y)
+    h = DT / 4
+    per_body = 9.81 * h * h                      # g h^2 = 0.17 mm
+    pen = 2 * r - gaps
+    assert np.abs(pos[1:, 0]).max() < 1e-3       # still a column
+    assert (gaps > 0).all()                      # nobody passed through a neighbour
+    assert pen.max() < 2.0 * layers * per_body   # <= 17 mm: the linear law with a factor 2 for the start transient
+    assert np.sort(pen)[int(0.99 * len(pen)) - 1] < 2.0 * layers * per_body
+    assert (2 * r * layers - (y[-1] + r)) < 0.25  # height loss (1.15 m with the 3 m/s clamp)
+    d = contact_depths(w)
+    assert len(d) >= layers // 2 and d.max() < 2.0 * layers * per_body  # coloured order: every other contact sits at zero
+
+
+def test_settled_pile_penetration_is_bounded():
+    """A 2000-body mixed pile (50 lattice rows) settled with damping: the distribution of contact depths, the figure
+    the bench prints beside its throughput.  Bodies are 60-200 mm across."""
+    from starframe_amd import scenes
+
+    s = scenes.mixed_pile(n=2000, width=40)
+    w = OracleWorld.from_scene(s, linear_damping=3.3, angular_damping=1.0)
+    for _ in range(500):
+        w.step(DT, ORDER_COLORED)
+    d = contact_depths(w)
+    p50, p99 = np.percentile(d, [50, 99])
+    pos, _ = w.poses()
+    assert len(d) > 3000
+    assert p50 < 0.004 and p99 < 0.020 and d.max() < 0.060, (p50, p99, d.max())
+    assert pos[:2000, 1].min() > 0.0 and np.isfinite(pos).all()
