@@ -97,8 +97,19 @@ def check_one_tick(s, min_pairs, min_manifolds, contacts=True):
 
 
 def test_mixed_pile_100k_one_tick_from_the_lattice():
-    """configs[2] as generated: 100 k bodies on the lattice (the bottom rows touch the floor, neighbours are near)."""
-    check_one_tick(scenes.mixed_pile(), min_pairs=50_000, min_manifolds=300)
+    """configs[2] as generated: 100 k bodies on the lattice (pitch 0.30 m, bodies up to 0.28 m across: a few dozen
+    candidate pairs), and the same scene 150 undamped ticks later, when the lower rows have landed on each other."""
+    from starframe_amd.world import World
+
+    s = scenes.mixed_pile()
+    check_one_tick(s, min_pairs=50, min_manifolds=0)
+    w = World.from_scene(s)
+    for _ in range(150):
+        w.step(DT)
+    w.sync()
+    (pos, rot), (vel, ang) = w.poses(), w.velocities()
+    w.close()
+    check_one_tick(s.with_state(pos, rot, vel, ang, name="mixed_pile_falling"), min_pairs=100_000, min_manifolds=30_000)
 
 
 def test_mixed_pile_100k_one_tick_from_the_settled_state():
@@ -110,7 +121,7 @@ def test_mixed_pile_100k_one_tick_from_the_settled_state():
 def test_circles_10k_one_tick_lattice_and_settled():
     """configs[1]: 10 k circles in the container."""
     s = scenes.circles_container()
-    check_one_tick(s, min_pairs=100, min_manifolds=50)
+    check_one_tick(s, min_pairs=100, min_manifolds=0)
     check_one_tick(settle_on_gpu(s, 500), min_pairs=20_000, min_manifolds=15_000)
 
 

@@ -331,14 +331,19 @@ def test_empty_and_tiny_worlds():
 
 
 def test_pair_capacity_overflow_reported():
+    """Too few pair slots: the tick drops pairs, says so in the stats, and the next synchronising call -- or the next
+    tick, once the host's counter read-back has shown it the bit -- returns SFX_ERR_CAPACITY."""
     from starframe_amd.world import SfxError, World
 
     s = scenes.random_soup(2000, seed=5, extent=8.0)
     w = World.from_scene(s, max_pairs=1024)
     w.step(DT)
     assert w.stats().overflow & 1
-    w.step(DT)
-    with pytest.raises(SfxError):
+    with pytest.raises(SfxError) as e:
+        w.step(DT)
+        w.sync()
+    assert e.value.code == -4
+    with pytest.raises(SfxError):        # the condition persists: every tick overflows again
         w.sync()
         w.step(DT)
         w.sync()
