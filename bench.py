@@ -55,6 +55,20 @@ def settle(scene, device, frames=600, damping=3.3, angular=1.0):
     return scene.with_state(pos, rot, name=scene.name + "_settled")
 
 
+def penetration_mm(w):
+    """Distribution of the positive contact-point depths at the current poses (slow parity hook: the narrowphase of every
+    candidate pair, downloaded), in millimetres: what "pile" means physically beside the throughput."""
+    w.broadphase(DT)
+    c = w.contacts()
+    d = np.concatenate([c["depth"][:, 0][c["count"] > 0], c["depth"][:, 1][c["count"] > 1]])
+    d = d[d > 0]
+    if not len(d):
+        return {"points": 0}
+    p50, p90, p99 = np.percentile(d, [50, 90, 99])
+    return {"points": int(len(d)), "p50": round(1e3 * float(p50), 2), "p90": round(1e3 * float(p90), 2),
+            "p99": round(1e3 * float(p99), 2), "max": round(1e3 * float(d.max()), 2)}
+
+
 def kernel_bytes(st):
     """Algorithmic (compulsory) bytes of ONE launch of each contact-sweep kernel (one launch per substep),
     from the tick's measured counts.  DESIGN.md "Kernels": P = solver pairs, M = touching pairs (manifolds),
@@ -132,6 +146,7 @@ def main():
     ap.add_argument("--steps", type=int, default=240)
     ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--bodies", type=int, default=100_000)
+    ap.add_argument("--width", type=int, default=1000, help="bodies per lattice row of the N = 1 pile (SURVEY.md 8d: 400)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--settle-frames", type=int, default=600)
     ap.add_argument("--live-events", default="solve_vel",
@@ -171,6 +186,7 @@ def main():
         from starframe_amd.slab import DistSlab
 
         # one pile, `world` times as wide; settled as slabs with damping, then re-cut on the settled state
+        scene_note = f"lattice {world * 1000} wide"
         scene = scenes.mixed_pile(n=world * args.bodies, width=world * 1000)
         pre = DistSlab(scene, World, dist, device_index=device, linear_damping=3.3, angular_damping=1.0)
         for _ in range(args.settle_frames):
@@ -188,7 +204,9 @@ def main():
                        f"{'RCCL device buffers' if slab.on_device else 'host staging'}")
         step = lambda: slab.step(DT)
     else:
-        scene = scenes.mixed_pile(n=args.bodies)
+        scene = scenes.mixed_pile(n=args.bodies, width=args.width)
+        scene_note = (f"lattice {args.width} wide x {args.bodies // args.width} rows, pitch 0.30 m, settled {args.settle_frames} damped ticks "
+                      f"(SURVEY.md 8d names a 400-wide lattice: figures for it in profiles/README.md)")
         parallelism = "1 GPU"
         scene = settle(scene, device, frames=args.settle_frames)
         n_dyn = scene.n_dynamic()
@@ -237,6 +255,7 @@ def main():
     kt = w.kernel_times()
     w.set_profiling(False)
     st2 = w.stats()
+    pen = penetration_mm(w) if slab is None else None   # after everything timed: it runs a broadphase of its own
     kb = kernel_bytes(st2)
     per_kernel = {}
     for cls, nbytes in kb.items():
@@ -282,6 +301,8 @@ def main():
         "config": {
             "workload": f"mixed_pile: {n_dyn} circle/rect/capsule bodies settled in a static container, "
                         f"{scene.substeps} substeps, dt=1/60 (BASELINE.json configs[2])",
+            "scene": scene_note,
+            "penetration_mm": pen,
             "bodies_per_gpu": n_rank,
             "substeps": scene.substeps,
             "parallelism": parallelism,

@@ -19,6 +19,7 @@ make = {
     "pyramid": lambda: scenes.pyramid(),
     "circles10k": lambda: scenes.circles_container(),
     "pile100k": lambda: scenes.mixed_pile(),
+    "pile100k_w400": lambda: scenes.mixed_pile(width=400),      # SURVEY.md 8d's lattice: 400 wide, 250 rows
     "chains": lambda: scenes.chains(),
     "slab500k": lambda: scenes.granular_slab(n=500_000, width=5000),
     "slab4m": lambda: scenes.granular_slab(),
@@ -62,6 +63,9 @@ for cls, nbytes in kb.items():
         per = nbytes * k * s.substeps / v["launches"]
         print(f"  {cls}: {1e6 * dur:.1f} us/launch, {per / 1e6:.1f} MB algorithmic, {per / dur / 1e9:.0f} GB/s = {100 * per / dur / 8e12:.1f} % of 8 TB/s")
 print("launches per tick:", {a: v["launches"] // k for a, v in kt.items() if v["launches"]})
+print("penetration:", bench.penetration_mm(w))
 pos, rot = w.poses()
+dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+print("pile height (99.5 % of the dynamic bodies below)", float(np.percentile(pos[dyn, 1], 99.5)))
 print("finite", bool(np.isfinite(pos).all() and np.isfinite(rot).all()), "y range", float(pos[:, 1].min()), float(pos[:, 1].max()))
 w.close()
