@@ -101,8 +101,7 @@ static void resolve_defaults(sfx_config* c) {
     else if (c->tile_cells >= 2) c->tile_cells = 2;
     if (c->restitution_threshold == 0.0f) c->restitution_threshold = 2.0f;
     if (c->vel_pad_max == 0.0f) c->vel_pad_max = 0.03f;
-    if (c->max_depenetration_velocity == 0.0f) c->max_depenetration_velocity = 10.0f;
-    if (c->max_depenetration_velocity < 0.0f) c->max_depenetration_velocity = INFINITY;
+    if (!(c->max_depenetration_velocity > 0.0f)) c->max_depenetration_velocity = INFINITY;
     if (c->vel_pad_max < 0.0f) c->vel_pad_max = 0.0f;
     if (c->speculative_margin == 0.0f) c->speculative_margin = 0.005f;
     if (c->speculative_margin < 0.0f) c->speculative_margin = 0.0f;
@@ -1228,7 +1227,16 @@ static void derive_velocities(sfo_world* w, float inv_h) {
         float pc = w->prev_rot[2 * i], ps = w->prev_rot[2 * i + 1];
         float dc = c * pc + s * ps;
         float ds = s * pc - c * ps;
-        if (dc > 1e-6f) w->angvel[i] = (ds / dc) * inv_h;
+        if (dc > 1e-6f) {
+            /* [DESIGN] tan(dtheta) has a pole at a quarter turn: what the substep's corrections add to the angular
+             * velocity is bounded by SFX_MAX_TAN_CORRECTION / h (a free spin, whose omega the substep does not
+             * change, is never touched) */
+            float wn = (ds / dc) * inv_h;
+            float dw = wn - w->angvel[i], lim = SFX_MAX_TAN_CORRECTION * inv_h;
+            if (dw > lim) wn = w->angvel[i] + lim;
+            if (dw < -lim) wn = w->angvel[i] - lim;
+            w->angvel[i] = wn;
+        }
     }
 }
 

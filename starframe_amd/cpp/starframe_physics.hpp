@@ -117,7 +117,7 @@ struct PhysicsConfig {  // "physics config" (field names of the reference's tuni
     uint32_t substeps = 4;
     Vec2 gravity{0.0f, -9.81f};
     float aabb_margin = 0.01f;
-    float max_depenetration_velocity = 10.0f;
+    float max_depenetration_velocity = 0.0f;  // 0 = unlimited
     int device = 0;
 };
 

@@ -225,8 +225,7 @@ void resolve_defaults(sfx_config& c) {
     if (c.speculative_margin < 0.0f) c.speculative_margin = 0.0f;
     if (c.restitution_threshold == 0.0f) c.restitution_threshold = 2.0f;
     if (c.vel_pad_max == 0.0f) c.vel_pad_max = 0.03f;
-    if (c.max_depenetration_velocity == 0.0f) c.max_depenetration_velocity = 10.0f;
-    if (c.max_depenetration_velocity < 0.0f) c.max_depenetration_velocity = INFINITY;
+    if (!(c.max_depenetration_velocity > 0.0f)) c.max_depenetration_velocity = INFINITY;
     if (c.vel_pad_max < 0.0f) c.vel_pad_max = 0.0f;
 }
 

@@ -155,7 +155,15 @@ __global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, const float4* __r
     v.y = (p.y - q.y) * sp.inv_h;
     float dc = p.z * q.z + p.w * q.w;
     float ds = p.w * q.z - p.z * q.w;
-    if (dc > 1e-6f) v.z = (ds / dc) * sp.inv_h;
+    if (dc > 1e-6f) {
+        // tan(dtheta) has a pole at a quarter turn: what the substep's corrections add to the angular velocity is bounded
+        // (DESIGN.md "Order"); a free spin, whose omega the substep does not change, is never touched
+        float wn = (ds / dc) * sp.inv_h;
+        const float dw = wn - v.z, lim = SFX_MAX_TAN_CORRECTION * sp.inv_h;
+        if (dw > lim) wn = v.z + lim;
+        if (dw < -lim) wn = v.z - lim;
+        v.z = wn;
+    }
     vel[i] = v;
 }
 

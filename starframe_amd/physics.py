@@ -19,7 +19,7 @@ class PhysicsConfig:
     substeps: int = 4
     gravity: tuple = (0.0, -9.81)
     aabb_margin: float = 0.01
-    max_depenetration_velocity: float = 10.0
+    max_depenetration_velocity: float = 0.0   # 0 = unlimited
     device: int = 0
 
 
