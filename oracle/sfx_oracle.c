@@ -74,6 +74,7 @@ struct sfo_world {
     uint32_t tlx, tly;   /* log2 of the tile width / height in cells */
     uint8_t* color;      /* colour of the pair inside its batch (tile or fallback list) */
     uint32_t* owner;     /* wrapped owner tile of the pair, SFO_FALLBACK for the fallback list */
+    uint8_t* pclass;     /* class of a tile-owned pair: 0 interior, 1 x seam, 2 y seam, 3 corner */
     uint32_t n_colors, n_leftover, overflow;
     uint32_t n_tiles, n_fallback, max_tile_pairs, max_tile_bodies, n_solver_pairs;
     uint32_t color_count[SFX_MAX_COLORS];
@@ -95,10 +96,10 @@ static void resolve_defaults(sfx_config* c) {
     if (c->substeps == 0) c->substeps = 1;
     if (c->color_rounds == 0) c->color_rounds = 12;
     if (c->color_rounds > 60) c->color_rounds = 60;
-    if (c->tile_cells == 0) c->tile_cells = 1;
+    /* tiles are at least two cells wide and high: the seams of one class then never share a body (tile order below) */
     if (c->tile_cells >= 8) c->tile_cells = 8;
     else if (c->tile_cells >= 4) c->tile_cells = 4;
-    else if (c->tile_cells >= 2) c->tile_cells = 2;
+    else c->tile_cells = 2;
     if (c->restitution_threshold == 0.0f) c->restitution_threshold = 2.0f;
     if (c->vel_pad_max == 0.0f) c->vel_pad_max = 0.03f;
     if (!(c->max_depenetration_velocity > 0.0f)) c->max_depenetration_velocity = INFINITY;
@@ -121,7 +122,7 @@ void sfo_destroy(sfo_world* w) {
     free(w->inv_inertia); free(w->prev_pos); free(w->prev_rot); free(w->col); free(w->poly);
     free(w->poly_nrm); free(w->mats); free(w->joints); free(w->angles); free(w->joint_perm); free(w->joint_color);
     free(w->aabb); free(w->pa); free(w->pb); free(w->color); free(w->order); free(w->rec);
-    free(w->ccx); free(w->ccy); free(w->is_small); free(w->owner); free(w->batch_end);
+    free(w->ccx); free(w->ccy); free(w->is_small); free(w->owner); free(w->pclass); free(w->batch_end);
     free(w);
 }
 
@@ -203,13 +204,13 @@ static void resolve_grid(sfo_world* w) {
         gx = gy = l;
     }
     /* at least 4 tiles per side, so that the 2x2 tile blocks of one phase never meet on the torus */
-    w->tlx = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : w->cfg.tile_cells == 2 ? 1u : 0u;
+    w->tlx = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : 1u;
     if (gx < w->tlx + 2) gx = w->tlx + 2;
-    if (gy < 2) gy = 2;
+    if (gy < 3) gy = 3;
     /* tile height: as wide by default; a power of two; the grid height at most (= strips) */
     w->tly = w->tlx;
     if (w->cfg.tile_cells_y) {
-        w->tly = 0;
+        w->tly = 1;
         while (w->tly < 31 && (2u << w->tly) <= w->cfg.tile_cells_y) w->tly++;
     } else {
         /* automatic: colliders per tile column (centre x, wrapped like the cells) at upload time */
@@ -225,9 +226,10 @@ static void resolve_grid(sfo_world* w) {
             if (two > worst) worst = two;
         }
         free(cnt);
-        if (worst <= 3u * SFX_TILE_MAX_BODIES / 4u) w->tly = gy;
+        if (worst <= 7u * SFX_TILE_MAX_BODIES / 8u) w->tly = gy;
     }
     if (w->tly > gy) w->tly = gy;
+    if (w->tly < gy && gy < w->tly + 2) w->tly = gy; /* fewer than four tile rows: one row (strips) */
     if (gx > 12) gx = 12;
     if (gy > 12) gy = 12;
     w->gxl = gx; w->gyl = gy;
@@ -257,7 +259,7 @@ int sfo_upload_colliders(sfo_world* w, uint32_t n, const sfx_collider* colliders
     }
     resolve_grid(w);
     free(w->aabb); free(w->pa); free(w->pb); free(w->color); free(w->order); free(w->rec);
-    free(w->ccx); free(w->ccy); free(w->is_small); free(w->owner); free(w->batch_end);
+    free(w->ccx); free(w->ccy); free(w->is_small); free(w->owner); free(w->pclass); free(w->batch_end);
     w->max_pairs = w->cfg.max_pairs ? w->cfg.max_pairs : 12u * n;
     if (w->max_pairs < 1024u) w->max_pairs = 1024u;
     w->aabb = (float*)calloc(4u * n + 4, sizeof(float));
@@ -267,6 +269,7 @@ int sfo_upload_colliders(sfo_world* w, uint32_t n, const sfx_collider* colliders
     w->order = (uint32_t*)malloc(w->max_pairs * sizeof(uint32_t));
     w->rec = (pair_rec*)calloc(w->max_pairs, sizeof(pair_rec));
     w->owner = (uint32_t*)malloc(w->max_pairs * sizeof(uint32_t));
+    w->pclass = (uint8_t*)calloc(w->max_pairs, 1);
     w->batch_end = (uint32_t*)malloc(((size_t)w->max_pairs + 2) * sizeof(uint32_t));
     w->ccx = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
     w->ccy = (int32_t*)calloc(n ? n : 1, sizeof(int32_t));
@@ -744,14 +747,22 @@ static int pair_in_reach(const sfo_world* w, uint32_t a, uint32_t b, float dt) {
 
 /* ------------------------------------------------------------------ tile order
  * [DESIGN] DESIGN.md "Contract / tiles".  Tiles are 2^tlx x 2^tly blocks of grid cells (true
- * cell coordinates, wrapped onto the torus like the cells).  A candidate pair of two small
- * colliders is owned by the tile (min tx, min ty) of its two home tiles; a pair of a small
- * collider and a large non-dynamic one by the small one's tile; everything else, and every
- * pair of a tile that owns more than SFX_TILE_MAX_PAIRS pairs or whose 2x2 tile block holds
- * more than SFX_TILE_MAX_BODIES small colliders, goes to the fallback list.  All bodies of a
- * tile's pairs lie inside its block (tx..tx+1, ty..ty+1), and blocks of tiles with the same
- * parity (tx & 1, ty & 1) are disjoint: the four parities are the four phases of a sweep.
- * Each tile's pairs, and the fallback list, are edge-coloured on their own. */
+ * cell coordinates, wrapped onto the torus like the cells), at least two cells wide and high.
+ * A candidate pair of two small colliders is owned by the tile (min tx, min ty) of its two home
+ * tiles; a pair of a small collider and a large non-dynamic one by the small one's tile;
+ * everything else, and every pair of a tile that owns more than SFX_TILE_MAX_PAIRS pairs or
+ * whose 2x2 tile block holds more than SFX_TILE_MAX_BODIES small colliders, goes to the
+ * fallback list.  The pairs of a tile fall into four CLASSES by where their two home tiles lie:
+ *   0 interior   both in the tile itself (and the pairs with a large non-dynamic collider)
+ *   1 x seam     they differ in x only       2 y seam     they differ in y only
+ *   3 corner     they differ in both
+ * Overlapping small colliders have home cells at most one apart, so a seam pair joins the last
+ * cell column (row) of one tile with the first of the next: with tiles of two cells or more, the
+ * units (tile, class) of ONE class never share a body.  The four classes are the four phases of
+ * a sweep -- interior first, the heavy one; the seams are short -- and every unit, like the
+ * fallback list, is edge-coloured on its own.  With one tile row (strips) classes 2 and 3 are
+ * empty. */
+#define SFO_UNIT(cls, tile) (((uint32_t)(cls) << 28) | (tile))
 
 static uint32_t wrapped_tile(const sfo_world* w, int32_t tx, int32_t ty) {
     uint32_t lx = w->gxl - w->tlx, ly = w->gyl - w->tly;
@@ -779,6 +790,11 @@ static void build_order(sfo_world* w, float frame_dt) {
         else if (w->is_small[a] && !dyn[b]) own = wrapped_tile(w, txa, tya);
         else if (w->is_small[b] && !dyn[a]) own = wrapped_tile(w, txb, tyb);
         w->owner[e] = own;
+        w->pclass[e] = 0;
+        if (own != SFO_FALLBACK && w->is_small[a] && w->is_small[b]) {
+            int ddx = txa != txb, ddy = ly ? (tya != tyb) : 0; /* one tile row: every home tile is in it */
+            w->pclass[e] = (uint8_t)(ddx ? (ddy ? 3 : 1) : (ddy ? 2 : 0));
+        }
         if (own != SFO_FALLBACK) tcnt[own]++;
     }
     w->max_tile_pairs = 0; w->max_tile_bodies = 0; w->n_tiles = 0;
@@ -817,8 +833,6 @@ static void build_order(sfo_world* w, float frame_dt) {
         for (uint32_t t = 0; t <= ntiles; ++t) {
             if (ph < 4) {
                 if (t == ntiles) continue;
-                uint32_t tx = t & ((1u << lx) - 1u), ty = t >> lx;
-                if (((tx & 1u) | ((ty & 1u) << 1)) != ph) continue;
             } else if (t != ntiles) continue;
             uint32_t s0 = tstart[t], cnt = tstart[t + 1] - s0;
             if (!cnt) continue;
@@ -827,6 +841,7 @@ static void build_order(sfo_world* w, float frame_dt) {
                 uint32_t nk = 0;
                 for (uint32_t q = 0; q < cnt; ++q) {
                     uint32_t e = bytile[s0 + q];
+                    if (w->pclass[e] != ph) continue; /* the unit (tile t, class ph) */
                     if (pair_in_reach(w, w->pa[e], w->pb[e], frame_dt)) kept[nk++] = e;
                     else w->color[e] = PRUNED_COLOR;
                 }
@@ -883,7 +898,7 @@ size_t sfo_pair_colors(const sfo_world* w, uint64_t* keys, uint8_t* colors, uint
     for (uint32_t e = 0; e < np && e < cap; ++e) {
         keys[e] = ((uint64_t)w->pa[e] << 32) | w->pb[e];
         colors[e] = w->color[e];
-        if (tiles) tiles[e] = w->owner[e];
+        if (tiles) tiles[e] = w->owner[e] == SFO_FALLBACK ? SFO_FALLBACK : SFO_UNIT(w->pclass[e], w->owner[e]);
     }
     return np;
 }

@@ -220,7 +220,7 @@ void resolve_defaults(sfx_config& c) {
     if (c.substeps == 0) c.substeps = 1;
     if (c.color_rounds == 0) c.color_rounds = 12;
     if (c.color_rounds > 60) c.color_rounds = 60;
-    c.tile_cells = c.tile_cells >= 8 ? 8u : c.tile_cells >= 4 ? 4u : c.tile_cells >= 2 ? 2u : 1u;
+    c.tile_cells = c.tile_cells >= 8 ? 8u : c.tile_cells >= 4 ? 4u : 2u;   // at least two cells: DESIGN.md "Contract / tiles"
     if (c.speculative_margin == 0.0f) c.speculative_margin = 0.005f;
     if (c.speculative_margin < 0.0f) c.speculative_margin = 0.0f;
     if (c.restitution_threshold == 0.0f) c.restitution_threshold = 2.0f;
@@ -279,13 +279,13 @@ void resolve_grid(sfx_world* w) {
         gx = gy = l;
     }
     // at least 4 tiles per side, so that the 2x2 tile blocks of one phase never meet on the torus
-    w->tlx = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : w->cfg.tile_cells == 2 ? 1u : 0u;
+    w->tlx = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : 1u;
     gx = std::min(std::max(gx, w->tlx + 2u), 12u);
-    gy = std::min(std::max(gy, 2u), 12u);
+    gy = std::min(std::max(gy, 3u), 12u);
     // tile height: as wide by default; a power of two; the grid height at most (= strips)
     w->tly = w->tlx;
     if (w->cfg.tile_cells_y) {
-        w->tly = 0;
+        w->tly = 1;
         while (w->tly < 31 && (2u << w->tly) <= w->cfg.tile_cells_y) w->tly++;
     } else {
         // automatic: colliders per tile column (centre x, wrapped like the cells) at upload time
@@ -301,9 +301,10 @@ void resolve_grid(sfx_world* w) {
         }
         uint32_t worst = 0;
         for (uint32_t c = 0; c < ncol; ++c) worst = std::max(worst, cnt[c] + cnt[(c + 1u) & (ncol - 1u)]);
-        if (worst <= 3u * SFX_TILE_MAX_BODIES / 4u) w->tly = gy;
+        if (worst <= 7u * SFX_TILE_MAX_BODIES / 8u) w->tly = gy;
     }
     w->tly = std::min(w->tly, gy);
+    if (w->tly < gy && gy < w->tly + 2u) w->tly = gy;   // fewer than four tile rows: one row (strips)
     w->gxl = gx; w->gyl = gy;
     w->ncell = (1u << gx) * (1u << gy);
     w->ntiles = w->ncell >> (w->tlx + w->tly);
@@ -315,7 +316,7 @@ GridParams grid_params(const sfx_world* w) {
     g.small_lim = 0.9f * w->cell;
     g.gxl = w->gxl; g.gyl = w->gyl; g.ncell = w->ncell;
     g.tlx = w->tlx; g.tly = w->tly; g.ntiles = w->ntiles;
-    g.pstride = (w->tly == w->gyl) ? w->ntiles / 2 : w->ntiles / 4;  // strips: phases 0 and 1 hold all tiles
+    g.pstride = w->ntiles;   // every phase (class of pairs) may have a batch per tile
     return g;
 }
 
@@ -383,7 +384,7 @@ void point_zero_block(sfx_world* w) {
     w->tile_cnt = w->cell_start + ((size_t)w->ncell + 1 + pad);
     w->tile_fill = w->tile_cnt + ((size_t)w->ntiles + 1 + pad);
     w->tile_flag = w->tile_fill + w->ntiles;
-    w->tile_batch = w->tile_flag + w->ntiles;
+    w->tile_batch = w->tile_flag + w->ntiles;   // [4 phases][ntiles]
 }
 
 // exclusive scan of data[0..count) in place (count <= 8192 * 4096); copy receives the result too
@@ -496,7 +497,7 @@ int broadphase(sfx_world* w, float dt) {
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
       hipLaunchKernelGGL(k_batch_color<kBatchP>, dim3(w->color_grid, (w->tly == w->gyl) ? 2u : 4u, w->group > 1u ? 2u : 1u), dim3(kColorThreads), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
-                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->bbody.p, (uint32_t)w->bbody.n, w->bruns.p, w->ntiles, w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
+                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->bbody.p, (uint32_t)w->bbody.n, w->bruns.p, (uint32_t)(w->bruns.n / 64), w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
     return SFX_OK;
@@ -522,8 +523,7 @@ void adopt_counters(sfx_world* w) {
         const uint32_t ntl = w->stale.n_active[0];
         if (!w->group_fixed && ntl) {
             const uint32_t per_tile = std::max(w->stale.n_tile_pairs / ntl, 1u);
-            const uint32_t phases = (w->tly == w->gyl) ? 2u : 4u;
-            const uint32_t want = cdiv(ntl / phases + 1u, kTargetBatches);
+            const uint32_t want = cdiv(ntl + 1u, kTargetBatches);   // every phase walks all the tiles
             const uint32_t fit = std::max((2u * kBatchP / 3u) / per_tile, 1u);
             w->group = std::min(std::min(std::max(want, 1u), fit), (uint32_t)kMaxGroup);
         }
@@ -531,8 +531,8 @@ void adopt_counters(sfx_world* w) {
         for (int ph = 0; ph < 4; ++ph) {
             const uint32_t b = w->stale.n_batches[ph];
             w->tile_grid[ph] = std::min(std::max(b + b / 8u + 4u, 1u), w->tile_grid_max);
-            groups = std::max(groups, cdiv(w->stale.n_listed[ph], w->group));
         }
+        groups = cdiv(w->stale.n_listed[0], w->group);
         w->color_grid = std::min(std::max(groups + groups / 8u + 4u, 1u), 8192u);
     }
 }
@@ -814,21 +814,22 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     w->fb_cap = std::max(65536u, w->max_pairs / 8u);
     const size_t pad = kScanItems;
     const size_t words = sizeof(Counters) / 4 + ((size_t)w->ncell + 1 + pad) + ((size_t)w->ntiles + 1 + pad) +
-                         3 * (size_t)w->ntiles;
+                         6 * (size_t)w->ntiles;   // tile_fill, tile_flag, tile_batch per phase
     const size_t words16 = (words + 3) & ~(size_t)3;  // cleared by k_zero in 16-byte units
     ALLOC(w, w->zero, 2 * words16);
     w->zero_bytes = words16 * 4;
     w->zero_half = 0;
     point_zero_block(w);
     ALLOC(w, w->cell_fill, (size_t)w->ncell + 1 + pad);
-    ALLOC(w, w->active, 2 * (size_t)w->ntiles); ALLOC(w, w->batches, 2 * (size_t)w->ntiles);
+    const size_t max_batches = 4 * (size_t)w->ntiles;   // per phase at most one per tile
+    ALLOC(w, w->active, 2 * (size_t)w->ntiles); ALLOC(w, w->batches, max_batches);
     ALLOC(w, w->rawp, w->max_pairs); ALLOC(w, w->tpair, w->max_pairs); ALLOC(w, w->torder, w->max_pairs);
-    ALLOC(w, w->done, 2 * (size_t)w->ntiles);
-    ALLOC(w, w->bruns, 64 * (size_t)w->ntiles);  // a batch holds at least one tile
+    ALLOC(w, w->done, max_batches);
+    ALLOC(w, w->bruns, 64 * std::min<size_t>(max_batches, w->max_pairs));  // a batch holds at least one tile and one pair
     // a collider lies in at most four tile blocks; plus the outside (large) colliders of each batch: at most kMaxExt per
     // batch, one kept pair each at least
     ALLOC(w, w->bbody, 4 * (size_t)n + 16 + std::min<size_t>((size_t)kMaxExt * w->ntiles, w->max_pairs));
-    HIPCHK(w, hipMemset(w->done.p, 0, sizeof(uint32_t) * 2 * (size_t)w->ntiles));
+    HIPCHK(w, hipMemset(w->done.p, 0, sizeof(uint32_t) * max_batches));
     ALLOC(w, w->fpairs, w->fb_cap); ALLOC(w, w->fsorted, w->fb_cap);
     const size_t mc = std::max<size_t>(w->fb_cap, w->m);
     ALLOC(w, w->pcolor, mc); ALLOC(w, w->prop, mc);
@@ -1563,7 +1564,10 @@ static int fetch_pairs(sfx_world* w, std::vector<HostPair>& out, Counters& c) {
     std::vector<uint4> tp(ntp);
     if (ntp) HIPCHK(w, hipMemcpy(tp.data(), w->tpair.p, sizeof(uint4) * ntp, hipMemcpyDeviceToHost));
     out.reserve((size_t)ntp + nfb);
-    for (uint32_t k = 0; k < ntp; ++k) out.push_back({tp[k].x, tp[k].y, tp[k].w >> 8, (uint8_t)(tp[k].w & 0xFFu)});
+    for (uint32_t k = 0; k < ntp; ++k) {   // unit = class << 28 | owner tile (include/sfx.h sfx_debug_pair_colors)
+        const uint32_t u = tp[k].w >> 8;
+        out.push_back({tp[k].x, tp[k].y, ((u >> 22) << 28) | (u & 0x3FFFFFu), (uint8_t)(tp[k].w & 0xFFu)});
+    }
     if (nfb) {
         // the raw list holds every fallback pair; colours come from the colour-major copy
         std::vector<uint2> fp(nfb), fs(c.fb_start[SFX_MAX_COLORS]);

@@ -407,6 +407,7 @@ struct PairArrays {
                              // and of stream 1 from the back, so that the fill pass copies instead of testing again
     uint32_t max_pairs, fb_cap;
 };
+constexpr uint32_t kClassShift = 30u, kSlotMask = (1u << kClassShift) - 1u;  // slots < 2^24: the class of a tile pair sits above
 constexpr uint32_t kHitTmp = 16;  // a slot with more tile pairs (or any fallback pair) is tested again by the fill pass
 
 // The eight slot groups of a wave usually belong to one or two tiles (slots are sorted
@@ -538,6 +539,14 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
             // stream: a neighbour cell in the tile to the left -> that tile's stream; a large slot's pairs and a small
             // slot's pair with a large dynamic collider -> the fallback list
             int st = (!small_slot) ? 2 : (r >= 1 && r < 5 && (ncx >> g.tlx) < txp) ? 1 : 0;
+            // class of a tile pair (DESIGN.md "Contract / tiles"): 0 interior, 1 x seam, 2 y seam, 3 corner -- where the two
+            // home tiles lie; it rides in the two top bits of the pair's second slot word
+            uint32_t cls = 0u;
+            if (small_slot && r >= 1 && r < 5) {
+                const bool ddx = (ncx >> g.tlx) != txp;
+                const bool ddy = g.tly != g.gyl && (ncy >> g.tly) != typ;   // one tile row (strips): every home tile is in it
+                cls = ddx ? (ddy ? 3u : 1u) : (ddy ? 2u : 0u);
+            }
             if (x < L) {
                 bool ok = true;
                 if (r < 5) { const int2 cq = sorted_cell[q]; ok = (cq.x == ncx && cq.y == ncy); }
@@ -554,7 +563,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                 const uint64_t bal = (__ballot(mine) >> gshift) & ((1ull << kGroup) - 1ull);
                 if (!FILL && mine && s3 < 2) {
                     const uint32_t idx = cnt[s3] + (uint32_t)__popcll(bal & below);
-                    if (idx < kHitTmp) P.hit_tmp[(size_t)p * kHitTmp + (s3 == 0 ? idx : kHitTmp - 1u - idx)] = make_uint2(j, q);
+                    if (idx < kHitTmp) P.hit_tmp[(size_t)p * kHitTmp + (s3 == 0 ? idx : kHitTmp - 1u - idx)] = make_uint2(j, q | (cls << kClassShift));
                 }
                 if (FILL && mine) {
                     const uint32_t dst = base[s3] + cnt[s3] + (uint32_t)__popcll(bal & below);
@@ -562,7 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                     if (to_fb[s3]) {
                         if (dst < P.fb_cap) P.fpairs[dst] = make_uint2(swap ? j : i, swap ? i : j);
                     } else if (dst < P.max_pairs) {
-                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, swap ? p : q);
+                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, (swap ? p : q) | (cls << kClassShift));
                     }
                 }
                 cnt[s3] += (uint32_t)__popcll(bal);
@@ -574,12 +583,12 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                 const uint32_t c = s3 == 0 ? cc0 : cc1;
                 for (uint32_t h = (uint32_t)gl; h < c; h += kGroup) {
                     const uint2 e = P.hit_tmp[(size_t)p * kHitTmp + (s3 == 0 ? h : kHitTmp - 1u - h)];
-                    const uint32_t j = e.x, q = e.y, dst = base[s3] + h;
+                    const uint32_t j = e.x, q = e.y & kSlotMask, cls = e.y >> kClassShift, dst = base[s3] + h;
                     const bool swap = j < i;
                     if (to_fb[s3]) {
                         if (dst < P.fb_cap) P.fpairs[dst] = make_uint2(swap ? j : i, swap ? i : j);
                     } else if (dst < P.max_pairs) {
-                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, swap ? p : q);
+                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, (swap ? p : q) | (cls << kClassShift));
                     }
                 }
             }
@@ -685,8 +694,8 @@ __device__ __forceinline__ void tile_list_step(uint32_t t, const GridParams& g, 
         block_ranges(t, g, cell_start, R);
         nb = R.off[4];
         const uint32_t lx = g.gxl - g.tlx;
-        if (cnt > kMaxP || nb > kMaxB) kind = 4u;
-        else kind = (t & 1u) | (((t >> lx) & 1u) << 1);
+        (void)lx;
+        kind = (cnt > kMaxP || nb > kMaxB) ? 4u : 0u;   // one list: every class (phase) of a sweep walks the same tiles
     }
     if (!__any(kind != 5u)) return;
     // one atomic per wave and list: the lanes of a kind take consecutive entries
@@ -877,10 +886,14 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
     __shared__ BatchRanges S;
     __shared__ uint32_t s_tile[kMaxGroup], s_tnb[kMaxGroup], s_tnp[kMaxGroup], s_tstart[kMaxGroup];
     __shared__ uint32_t s_bfirst[kMaxGroup + 1], s_poff[kMaxGroup + 1];
+    __shared__ uint8_t s_mark[MB];        // block bodies that a kept pair of this class touches: the batch's LDS bodies
+    __shared__ uint16_t s_remap[MB];      // block-local index -> index in the batch's (compact) body list
+    __shared__ uint32_t s_scan[kColorThreads / 64 + 1];
+    __shared__ uint32_t s_np, s_nbc;
     const uint32_t tid = threadIdx.x;
-    const uint32_t ph_list = blockIdx.y;
-    const uint32_t nlist = ctr->n_listed[ph_list];
-    const uint32_t* lst = list + ph_list * g.pstride;
+    const uint32_t cls = blockIdx.y;      // the class of pairs (= phase of the sweep) this workgroup forms batches of
+    const uint32_t nlist = ctr->n_listed[0];
+    const uint32_t* lst = list;
     group = min(max(group, 1u), (uint32_t)kMaxGroup);
     const uint32_t ngroups = (nlist + group - 1u) / group;
     for (uint32_t gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
@@ -917,33 +930,41 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                 uint32_t run = 0;
                 for (uint32_t j = 0; j < c; ++j) { s_poff[j] = run; run += s_tnp[f + j]; }
                 s_poff[c] = run;
-                s_nleft = 0u; s_ovf = 0u; s_npruned = 0u;
+                s_nleft = 0u; s_ovf = 0u; s_npruned = 0u; s_np = 0u;
             }
             if (tid < kMaxExt) s_ext[tid] = 0xFFFFFFFFu;
             if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
             if (tid < 4) s_cls[tid] = 0u;
             __syncthreads();
-            const uint32_t nb = min(S.off[4u * c], MB), np = min(s_poff[c], MP);
+            const uint32_t nb = min(S.off[4u * c], MB), np_all = min(s_poff[c], MP);
             for (uint32_t l = tid; l < nb; l += kBlock) {
                 const uint32_t gid = sorted_id[batch_slot(S, 4u * c, l)];
                 s_dyn[l] = (uint8_t)(filt[gid].w != 0u);
+                s_mark[l] = 0u;
                 s_used[l] = 0ull;
 #pragma unroll
                 for (int k = 0; k < kClaim; ++k) s_claim[l * kClaim + k] = ~0ull;
             }
+            __syncthreads();  // the marks are cleared before the pairs set them
             int open_edges = 0;
-            for (uint32_t e = tid; e < np; e += kBlock) {
+            for (uint32_t e0 = tid; e0 < np_all; e0 += kBlock) {  // the tiles' pairs of this class, in no particular order
                 uint32_t j = 0;
-                while (j + 1 < c && s_poff[j + 1] <= e) ++j;
-                const uint4 rp = rawp[s_tstart[f + j] + (e - s_poff[j])];
+                while (j + 1 < c && s_poff[j + 1] <= e0) ++j;
+                const uint4 rp = rawp[s_tstart[f + j] + (e0 - s_poff[j])];
+                if ((rp.w >> kClassShift) != cls) continue;
+                const uint32_t e = atomicAdd(&s_np, 1u);
                 s_a[e] = rp.x; s_b[e] = rp.y;
                 s_la[e] = (uint16_t)batch_local(S, j, rp.z & ~kOutOfReach);
-                s_lb[e] = (uint16_t)batch_local(S, j, rp.w);
+                s_lb[e] = (uint16_t)batch_local(S, j, rp.w & kSlotMask);
                 s_tj[e] = (uint8_t)j;
                 const bool keep = !(rp.z & kOutOfReach);
                 s_col[e] = keep ? SFX_NO_COLOR : SFX_PRUNED_COLOR;
                 if (!keep) atomicAdd(&s_npruned, 1u);
                 open_edges |= keep ? 1 : 0;
+                if (keep) {  // (plain stores of the same value: no lane minds who wins)
+                    if (s_la[e] != kExt && s_la[e] < MB) s_mark[s_la[e]] = 1u;
+                    if (s_lb[e] != kExt && s_lb[e] < MB) s_mark[s_lb[e]] = 1u;
+                }
                 if (keep && (s_la[e] == kExt || s_lb[e] == kExt)) {  // an end outside the block: give it an LDS slot of the solves
                     const uint32_t id = s_la[e] == kExt ? rp.x : rp.y;
                     uint32_t k = 0;
@@ -955,19 +976,42 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                 }
             }
             int any_open = __syncthreads_or(open_edges);
-            if (tid < 64u) {  // the batch's body list: block bodies, then the outside bodies (filled from slot 0 on)
+            const uint32_t np = s_np;
+            if (np == 0u) continue;  // no pair of this class in these tiles: no batch (uniform: s_np is read after the barrier)
+            {   // the batch's body list holds the touched block bodies only: the units of one class may share a tile's bodies
+                // in their blocks, never in their pairs -- what a batch does not touch it must not write back either
+                uint32_t m[(MB + kColorThreads - 1) / kColorThreads], cnt = 0u;
+#pragma unroll
+                for (uint32_t q = 0; q < (MB + kColorThreads - 1) / kColorThreads; ++q) {
+                    const uint32_t l = tid * ((MB + kColorThreads - 1) / kColorThreads) + q;
+                    m[q] = (l < nb && s_mark[l]) ? 1u : 0u;
+                    cnt += m[q];
+                }
+                uint32_t total;
+                uint32_t pre = block_exclusive_scan<kColorThreads>(cnt, s_scan, &total);
+#pragma unroll
+                for (uint32_t q = 0; q < (MB + kColorThreads - 1) / kColorThreads; ++q) {
+                    const uint32_t l = tid * ((MB + kColorThreads - 1) / kColorThreads) + q;
+                    if (l < nb) s_remap[l] = (uint16_t)pre;
+                    pre += m[q];
+                }
+                if (tid == 0) s_nbc = total;
+            }
+            __syncthreads();
+            const uint32_t nbc = s_nbc;
+            if (tid < 64u) {  // the batch's body list: touched block bodies, then the outside bodies (filled from slot 0 on)
                 static_assert(kMaxExt == 64, "one lane per slot");
                 const unsigned long long have = __ballot(s_ext[tid] != 0xFFFFFFFFu);
                 const uint32_t next = (uint32_t)__popcll(have);
                 uint32_t boff = 0u;
-                if (tid == 0) boff = atomicAdd(&ctr->body_cursor, nb + next);
+                if (tid == 0) boff = atomicAdd(&ctr->body_cursor, nbc + next);
                 boff = (uint32_t)__shfl((int)boff, 0, 64);
                 if (tid == 0) { s_boff = boff; s_next = next; }
-                if (tid < next && boff + nb + tid < bbody_cap) bbody[boff + nb + tid] = s_ext[tid];
+                if (tid < next && boff + nbc + tid < bbody_cap) bbody[boff + nbc + tid] = s_ext[tid];
             }
             __syncthreads();
             for (uint32_t l = tid; l < nb; l += kBlock)  // the tile solves load their bodies from this list
-                if (s_boff + l < bbody_cap) bbody[s_boff + l] = sorted_id[batch_slot(S, 4u * c, l)];
+                if (s_mark[l] && s_boff + s_remap[l] < bbody_cap) bbody[s_boff + s_remap[l]] = sorted_id[batch_slot(S, 4u * c, l)];
             SFX_TT(tc1);
 #define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
             for (uint32_t r = 0; r < rounds && any_open; ++r) {  // everything coloured: later rounds would do nothing
@@ -1068,12 +1112,10 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                 atomicAdd(&ctr->n_kept, kept);
                 const uint32_t bstart = atomicAdd(&ctr->tp_cursor, np);
                 s_bstart = bstart;
-                const uint32_t t0 = s_tile[f];
-                const uint32_t lx = g.gxl - g.tlx;
-                const uint32_t ph = (t0 & 1u) | (((t0 >> lx) & 1u) << 1);
+                const uint32_t ph = cls;
                 BatchDesc d;
                 d.first = e0 + f;
-                d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nb + s_next; d.boff = s_boff; d.roff = roff;
+                d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nbc + s_next; d.boff = s_boff; d.roff = roff;
                 const uint32_t bidx = atomicAdd(&ctr->n_batches[ph], 1u);
                 batches[ph * g.pstride + bidx] = d;
                 s_bidx = bidx;
@@ -1086,7 +1128,7 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
             // batch's histogram to one global table cost ~9000 device-scope atomics on two cache lines per tick)
             __syncthreads();
             const uint32_t bstart = s_bstart;
-            if (tid < c) tile_batch[s_tile[f + tid]] = s_bidx + 1u;
+            if (tid < c) tile_batch[cls * g.ntiles + s_tile[f + tid]] = s_bidx + 1u;
             // narrowphase order: the batch's pairs grouped by shape-pair class (circle-circle, circle-
             // polygon core, core-core, anything with a POLY), so that the lanes of a wave take the
             // same branch of the narrowphase.  s_prop is free now: it keeps the class.
@@ -1109,14 +1151,20 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                 const uint32_t dst = (cc < SFX_MAX_COLORS) ? atomicAdd(&s_base[cc], 1u)
                                      : (cc == SFX_PRUNED_COLOR) ? atomicAdd(&s_ptail, 1u) : atomicAdd(&s_nleft, 1u);
                 uint32_t la = s_la[e], lb = s_lb[e];
+                if (cc == SFX_PRUNED_COLOR) { la = 0u; lb = 0u; }  // never solved: its ends may not be on the body list
+                else {
+                    if (la != kExt) la = la < MB ? s_remap[la] : kExt;
+                    if (lb != kExt) lb = lb < MB ? s_remap[lb] : kExt;
+                }
                 if ((la == kExt || lb == kExt) && cc != SFX_PRUNED_COLOR) {  // the outside end's LDS slot (kExt stays when there was none left)
-                    const uint32_t id = la == kExt ? s_a[e] : s_b[e];
+                    const bool a_out = s_la[e] == kExt;
+                    const uint32_t id = a_out ? s_a[e] : s_b[e];
                     uint32_t k = 0;
                     while (k < s_next && s_ext[k] != id) ++k;
-                    const uint32_t lx = k < s_next ? nb + k : kExt;
-                    if (la == kExt) la = lx; else lb = lx;
+                    const uint32_t lx = k < s_next ? nbc + k : kExt;
+                    if (a_out) la = lx; else lb = lx;
                 }
-                tpair[bstart + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), cc | (s_tile[f + s_tj[e]] << 8));
+                tpair[bstart + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), cc | (((cls << 22) | s_tile[f + s_tj[e]]) << 8));
                 if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_prop[e]], 1u)] = make_uint4(s_a[e], s_b[e], bstart + dst, 0u);
             }
             for (uint32_t e = s_ptail_first + tid; e < np; e += kBlock) torder[bstart + e] = make_uint4(0u, 0u, kNoPair, 0u);  // pruned pairs: no narrowphase
@@ -1307,7 +1355,7 @@ struct TileArrays {
                                   // = record slot, -); slot kNoPair: skip.  The ids ride along so that k_narrow has one dependent load less
     const uint32_t* bbody;        // per batch (BatchDesc.boff): body ids in local-index order
     const uint32_t* bruns;        // per batch (BatchDesc.roff): 64 colour runs, first | end << 16
-    const uint32_t* tile_batch;   // per tile: 1 + index of its batch on its phase's table (0: none this tick)
+    const uint32_t* tile_batch;   // [phase][tile]: 1 + index of the tile's batch on that phase's table (0: none this tick)
     uint32_t* done;               // per batch slot: epoch of the last fused launch that finished it
     const uint2* fsorted;         // fallback list, colour-major
     uint32_t max_pairs;           // record slot of fallback pair k = max_pairs + k
@@ -1626,22 +1674,25 @@ __device__ __forceinline__ void wait_for_earlier_phases(const TileArrays& T, con
                                                         const uint32_t* __restrict__ tiles, uint32_t count, uint32_t ph,
                                                         uint32_t ph0, uint32_t epoch) {
     if (threadIdx.x < 64u) {
+        // a batch's bodies lie in the 2x2 tile blocks of its tiles; the batches of EARLIER phases (classes) that can have
+        // written them are those of the 3x3 tiles around each tile -- the tile itself included: it has a batch per class
         const uint32_t lx = g.gxl - g.tlx;
-        for (uint32_t j = threadIdx.x; j < count * 8u; j += 64u) {
-            const uint32_t t = tiles[j >> 3], dir = j & 7u;
+        const bool one_row = g.tly == g.gyl;
+        for (uint32_t j = threadIdx.x; j < count * 9u; j += 64u) {
+            const uint32_t t = tiles[j / 9u], dir = j % 9u;
+            const int dx = (int)(dir % 3u) - 1, dy = (int)(dir / 3u) - 1;
+            if (one_row && dy != 0) continue;
             const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
-            const int dx = (dir == 0 || dir == 3 || dir == 5) ? -1 : (dir == 2 || dir == 4 || dir == 7) ? 1 : 0;
-            const int dy = dir < 3 ? -1 : dir < 5 ? 0 : 1;
             const uint32_t t2 = tile_of(tx + dx, ty + dy, g);
-            const uint32_t ph2 = (t2 & 1u) | (((t2 >> lx) & 1u) << 1);
-            if (ph2 >= ph || ph2 < ph0) continue;
-            const uint32_t b2 = T.tile_batch[t2];
-            if (!b2) continue;  // that tile owns no pairs this tick: nothing touches its block in its phase
-            const uint32_t* flag = &T.done[ph2 * g.pstride + (b2 - 1u)];
-            uint32_t spins = 0;
-            while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > 400000u) { atomicOr(&ctr->overflow, kOvfStall); break; }
+            for (uint32_t ph2 = ph0; ph2 < ph; ++ph2) {
+                const uint32_t b2 = T.tile_batch[ph2 * g.ntiles + t2];
+                if (!b2) continue;  // that tile has no pairs of that class this tick
+                const uint32_t* flag = &T.done[ph2 * g.pstride + (b2 - 1u)];
+                uint32_t spins = 0;
+                while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > 400000u) { atomicOr(&ctr->overflow, kOvfStall); break; }
+                }
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1683,7 +1734,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         const PhaseItem pi = phase_item(ctr, ph0, nph, item);
         const uint32_t ph = pi.ph, it = pi.it;
         const BatchDesc d = T.batches[ph * g.pstride + it];
-        const uint32_t* tiles = T.active + ph * g.pstride + d.first;
+        const uint32_t* tiles = T.active + d.first;   // one tile list for all phases
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol, npb = min(d.np, kBatchP);
         // everything that no earlier phase of this launch writes is fetched before waiting for them: the records of
         // the first colour (it starts the batch's list), the body ids, the masses, the colour runs
@@ -1784,7 +1835,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         const PhaseItem pi = phase_item(ctr, ph0, nph, item);
         const uint32_t ph = pi.ph, it = pi.it;
         const BatchDesc d = T.batches[ph * g.pstride + it];
-        const uint32_t* tiles = T.active + ph * g.pstride + d.first;
+        const uint32_t* tiles = T.active + d.first;   // one tile list for all phases
         SFX_TT(tv0);
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol;
         RawSlot nxt;  // as in k_tile_pos: what earlier phases do not write is fetched before waiting for them

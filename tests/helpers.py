@@ -51,25 +51,22 @@ def coloring_valid(keys, colors, dynamic, tiles=None):
     return len(np.unique(code, axis=0)) == len(code)
 
 
-def tile_phases_disjoint(keys, tiles, dynamic, grid_log2, tile_cells):
-    """Tiles of one phase (same parity of tile x, y) never share a dynamic body."""
+def unit_class(tiles):
+    """Solver units are reported as class << 28 | owner tile (0 interior, 1 x seam, 2 y seam, 3 corner)."""
+    return (tiles >> np.uint32(28)).astype(np.int64)
+
+
+def tile_phases_disjoint(keys, tiles, dynamic, grid_log2=None, tile_cells=None):
+    """The units (tile, class) of one class -- one phase of a sweep -- never share a dynamic body."""
     a = (keys >> np.uint64(32)).astype(np.int64)
     b = (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
-    lx = grid_log2[0] - int(tile_cells).bit_length() + 1
     ok = tiles != 0xFFFFFFFF
     t = tiles[ok].astype(np.int64)
-    ph = (t & 1) | (((t >> lx) & 1) << 1)
-    for end in (a[ok], b[ok]):
-        d = dynamic[end]
-        code = np.unique(np.stack([ph[d], end[d], t[d]], axis=1), axis=0)
-        # a (phase, body) may appear with one tile only
-        pb = code[:, :2]
-        if len(np.unique(pb, axis=0)) != len(pb):
-            return False
-    # both ends together
+    ph = unit_class(tiles[ok])
     e2 = np.concatenate([a[ok], b[ok]])
     t2 = np.concatenate([t, t])
     p2 = np.concatenate([ph, ph])
     d = dynamic[e2]
     code = np.unique(np.stack([p2[d], e2[d], t2[d]], axis=1), axis=0)
+    # a (phase, body) may appear with one unit only
     return len(np.unique(code[:, :2], axis=0)) == len(code)

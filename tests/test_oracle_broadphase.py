@@ -91,10 +91,11 @@ def test_colouring_is_valid_and_deterministic(rounds):
     assert np.array_equal(k1, k2) and np.array_equal(c1, c2) and np.array_equal(t1, t2)
 
 
-@pytest.mark.parametrize("tile_cells,cell", [(1, 0.0), (2, 0.0), (4, 0.0), (8, 0.0), (1, 0.2)])
+@pytest.mark.parametrize("tile_cells,cell", [(2, 0.0), (4, 0.0), (8, 0.0), (2, 0.2)])
 def test_tile_ownership_keeps_phases_disjoint(tile_cells, cell):
     """Every tile size, and a cell size that makes big dynamic bodies 'large' (fallback list):
-    tiles of one phase never share a dynamic body, colours are valid per tile."""
+    the units (tile, class) of one class -- one phase -- never share a dynamic body, colours are valid per unit;
+    all four classes occur, the interior class holds most pairs."""
     s = scenes.random_soup(1500, seed=9, extent=7.0)
     dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
     w = OracleWorld.from_scene(s, tile_cells=tile_cells, tile_cells_y=tile_cells, cell_size=cell)
@@ -104,39 +105,46 @@ def test_tile_ownership_keeps_phases_disjoint(tile_cells, cell):
     assert rc.tile_cells == tile_cells
     assert coloring_valid(k, c, dyn, t)
     assert tile_phases_disjoint(k, t, dyn, tuple(rc.grid_log2), rc.tile_cells)
+    cls = (t[t != 0xFFFFFFFF] >> np.uint32(28)).astype(int)
+    hist = np.bincount(cls, minlength=4)
+    assert cell or (hist > 0).all(), hist
+    assert cell or tile_cells <= 2 or hist[0] == hist.max()
     st = w.stats()
     assert st.max_tile_pairs <= 2048 and st.max_tile_bodies <= 1024
     if cell:
         assert st.n_fallback > 0 and st.n_large > 3
 
 
+def test_a_tile_is_at_least_two_cells_wide_and_high():
+    """tile_cells = 1 is raised to 2: with one-cell tiles a body would sit in the last and the first cell column of
+    its tile at once and two x seams could share it."""
+    s = scenes.random_soup(300, seed=1)
+    rc = OracleWorld.from_scene(s, tile_cells=1, tile_cells_y=1).resolved_config()
+    assert rc.tile_cells == 2 and rc.tile_cells_y == 2
+
+
 def test_strip_tiles_have_two_phases():
-    """tile_cells_y >= grid height: full-height strips, only phases 0 and 1 (tile x parity)."""
+    """tile_cells_y >= grid height: full-height strips, only the classes 0 (interior) and 1 (x seam)."""
     s = scenes.random_soup(1500, seed=9, extent=7.0)
     dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
     w = OracleWorld.from_scene(s, tile_cells_y=4096)
     w.broadphase(DT)
     rc = w.resolved_config()
-    assert rc.tile_cells == 1 and rc.tile_cells_y == 1 << rc.grid_log2[1]
+    assert rc.tile_cells == 2 and rc.tile_cells_y == 1 << rc.grid_log2[1]
     k, c, t = w.pair_colors()
     ok = t != 0xFFFFFFFF
     assert ok.sum() > 1000
-    assert t[ok].max() < (1 << rc.grid_log2[0])            # one tile row
+    assert (t[ok] & 0x0FFFFFFF).max() < (1 << (rc.grid_log2[0] - 1))   # one tile row
+    assert set(np.unique(t[ok] >> np.uint32(28)).tolist()) == {0, 1}
     assert coloring_valid(k, c, dyn, t)
-    # tiles of one parity never share a dynamic body
-    a = (k >> np.uint64(32)).astype(np.int64)[ok]
-    b = (k & np.uint64(0xFFFFFFFF)).astype(np.int64)[ok]
-    tt = t[ok].astype(np.int64)
-    seen = {}
-    for body, tile in zip(np.concatenate([a, b]), np.concatenate([tt, tt])):
-        if dyn[body]:
-            assert seen.setdefault((tile & 1, body), tile) == tile
+    assert tile_phases_disjoint(k, t, dyn)
+    # a seam joins a tile with its right neighbour: every seam pair has one body homed in each
     w2 = OracleWorld.from_scene(s, tile_cells=2, tile_cells_y=4)
     w2.broadphase(DT)
     rc2 = w2.resolved_config()
     assert (rc2.tile_cells, rc2.tile_cells_y) == (2, 4)
     k2, c2, t2 = w2.pair_colors()
-    assert coloring_valid(k2, c2, dyn, t2)
+    assert coloring_valid(k2, c2, dyn, t2) and tile_phases_disjoint(k2, t2, dyn)
     for _ in range(3):
         w.step(DT)
         w2.step(DT)
@@ -158,7 +166,7 @@ def test_overfull_tiles_fall_back():
     dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
     w = OracleWorld.from_scene(s)
     rc = w.resolved_config()
-    assert rc.tile_cells_y == rc.tile_cells == 1   # 1600 colliders in two columns: no automatic strips
+    assert rc.tile_cells_y == rc.tile_cells == 2   # 1600 colliders in two columns: no automatic strips
     w.broadphase(DT)
     k, c, t = w.pair_colors()
     st = w.stats()
@@ -191,7 +199,7 @@ def test_auto_grid_and_cell_resolution():
     assert rc.cell_size > 0.4
     assert rc.grid_log2[0] == rc.grid_log2[1] == 5
     assert rc.max_pairs == 12 * s.n
-    assert rc.tile_cells == 1 and rc.tile_cells_y == 32   # sparse scene: automatic full-height strips
+    assert rc.tile_cells == 2 and rc.tile_cells_y == 32   # sparse scene: automatic full-height strips
 
 
 @pytest.mark.parametrize("speed", [0.0, 1.5])
