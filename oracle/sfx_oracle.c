@@ -202,6 +202,32 @@ static void resolve_grid(sfo_world* w) {
         uint32_t l = ceil_log2(side);
         if (l > 12) l = 12;
         gx = gy = l;
+        /* [DESIGN] the 2^(2l) buckets take the shape of the scene: a wide, shallow pile on a square torus wraps
+         * round it and stacks several cell columns into one (denser tiles, for nothing).  Extent of the dynamic
+         * colliders' centres at upload, in cells, rounded up to powers of two; then at least 2^(2l) buckets (the
+         * shorter side grows) and at most four times as many (the longer side shrinks). */
+        float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        for (uint32_t i = 0; i < w->n; ++i) {
+            if (!is_dynamic(w, i) || w->col[i].type == SFX_SHAPE_NONE) continue;
+            float x = w->pos[2 * i], y = w->pos[2 * i + 1];
+            if (x < xmin) xmin = x;
+            if (x > xmax) xmax = x;
+            if (y < ymin) ymin = y;
+            if (y > ymax) ymax = y;
+        }
+        if (xmax >= xmin && ymax >= ymin) {
+            float ex = floorf((xmax - xmin) * w->inv_cell) + 3.0f, ey = floorf((ymax - ymin) * w->inv_cell) + 3.0f;
+            if (!(ex < 8192.0f)) ex = 8192.0f;
+            if (!(ey < 8192.0f)) ey = 8192.0f;
+            uint32_t bx = ceil_log2((uint32_t)ex), by = ceil_log2((uint32_t)ey), tot = 2u * l;
+            if (bx < 2) bx = 2;
+            if (bx > 12) bx = 12;
+            if (by < 2) by = 2;
+            if (by > 12) by = 12;
+            while (bx + by < tot) { if (by <= bx && by < 12) ++by; else if (bx < 12) ++bx; else break; }
+            while (bx + by > tot + 2u) { if (bx >= by && bx > 2) --bx; else if (by > 2) --by; else break; }
+            gx = bx; gy = by;
+        }
     }
     /* at least 4 tiles per side, so that the 2x2 tile blocks of one phase never meet on the torus */
     w->tlx = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : 1u;

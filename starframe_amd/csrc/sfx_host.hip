@@ -79,7 +79,7 @@ struct sfx_world {
     // scene
     uint32_t n = 0, m = 0, n_mats = 0, n_poly = 0;
     bool have_bodies = false, have_colliders = false, have_mats = false;
-    std::vector<float> h_inv_mass, h_inv_inertia, h_pos_x;
+    std::vector<float> h_inv_mass, h_inv_inertia, h_pos_x, h_pos_y;
     std::vector<sfx_collider> h_col;
     std::vector<float> h_poly;
     DevBuf<float4> pose, prev, vel, shape, poly, mats, aabb, sorted_aabb;
@@ -277,6 +277,30 @@ void resolve_grid(sfx_world* w) {
         uint32_t l = ceil_log2(side);
         if (l > 12) l = 12;
         gx = gy = l;
+        // the 2^(2l) buckets take the shape of the scene (DESIGN.md "Contract / grid"): extent of the dynamic colliders'
+        // centres at upload, in cells, rounded up to powers of two; then at least 2^(2l) buckets (the shorter side
+        // grows) and at most four times as many (the longer side shrinks).  Same rule, same operations as the oracle's.
+        float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
+        for (uint32_t i = 0; i < w->n; ++i) {
+            if (!is_dynamic(w, i) || w->h_col[i].type == SFX_SHAPE_NONE) continue;
+            const float x = w->h_pos_x[i], y = w->h_pos_y[i];
+            if (x < xmin) xmin = x;
+            if (x > xmax) xmax = x;
+            if (y < ymin) ymin = y;
+            if (y > ymax) ymax = y;
+        }
+        if (xmax >= xmin && ymax >= ymin) {
+            float ex = floorf((xmax - xmin) * w->inv_cell) + 3.0f, ey = floorf((ymax - ymin) * w->inv_cell) + 3.0f;
+            if (!(ex < 8192.0f)) ex = 8192.0f;
+            if (!(ey < 8192.0f)) ey = 8192.0f;
+            uint32_t bx = ceil_log2((uint32_t)ex), by = ceil_log2((uint32_t)ey);
+            const uint32_t tot = 2u * l;
+            bx = std::min(std::max(bx, 2u), 12u);
+            by = std::min(std::max(by, 2u), 12u);
+            while (bx + by < tot) { if (by <= bx && by < 12) ++by; else if (bx < 12) ++bx; else break; }
+            while (bx + by > tot + 2u) { if (bx >= by && bx > 2) --bx; else if (by > 2) --by; else break; }
+            gx = bx; gy = by;
+        }
     }
     // at least 4 tiles per side, so that the 2x2 tile blocks of one phase never meet on the torus
     w->tlx = w->cfg.tile_cells == 8 ? 3u : w->cfg.tile_cells == 4 ? 2u : 1u;
@@ -734,8 +758,8 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
     std::vector<float2> hm(std::max(n, 1u));
     w->h_inv_mass.assign(inv_mass, inv_mass + n);
     w->h_inv_inertia.assign(inv_inertia, inv_inertia + n);
-    w->h_pos_x.resize(n);
-    for (uint32_t i = 0; i < n; ++i) w->h_pos_x[i] = pos[2 * i];
+    w->h_pos_x.resize(n); w->h_pos_y.resize(n);
+    for (uint32_t i = 0; i < n; ++i) { w->h_pos_x[i] = pos[2 * i]; w->h_pos_y[i] = pos[2 * i + 1]; }
     for (uint32_t i = 0; i < n; ++i) {
         hp[i] = make_float4(pos[2 * i], pos[2 * i + 1], rot[2 * i], rot[2 * i + 1]);
         hv[i] = make_float4(vel[2 * i], vel[2 * i + 1], angvel[i], 0.0f);
