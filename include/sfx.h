@@ -263,6 +263,12 @@ int sfx_tick_begin(sfx_world* w, float frame_dt);   /* broadphase + tiles + colo
 int sfx_tick_substep(sfx_world* w);                 /* one substep of the tick begun */
 int sfx_set_stream(sfx_world* w, void* hip_stream); /* NULL = back to the world's own stream */
 int sfx_halo_set(sfx_world* w, const uint32_t* send_idx, uint32_t n_send, const uint32_t* recv_idx, uint32_t n_recv);
+/* Halo lists are cut for the bodies' positions at sfx_halo_set: a body that was not ghosted lay more than the halo
+ * width from the boundary.  sfx_halo_guard(w, d), d > 0, makes every later tick check (in its first kernel, no extra
+ * launch) that no body has moved further than d on x since sfx_halo_set; when one has, overflow bit 128 is set and
+ * the next sfx_sync / sfx_step returns SFX_ERR_CAPACITY -- cut the slabs again -- instead of seam contacts going
+ * missing silently.  The slab drivers set d = halo / 4.  0 switches the guard off. */
+int sfx_halo_guard(sfx_world* w, float max_move);
 int sfx_halo_pack(sfx_world* w);
 int sfx_halo_unpack(sfx_world* w);
 int sfx_halo_buffers(sfx_world* w, float** send_dev, float** recv_dev);

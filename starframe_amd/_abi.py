@@ -198,7 +198,7 @@ SFX_SYMBOLS = [
     "sfx_step", "sfx_sync", "sfx_download_poses", "sfx_download_velocities",
     "sfx_readback_begin", "sfx_readback_wait",
     "sfx_tick_begin", "sfx_tick_substep", "sfx_set_stream", "sfx_halo_set", "sfx_halo_pack", "sfx_halo_unpack",
-    "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy",
+    "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy", "sfx_halo_guard",
     "sfx_query_points", "sfx_query_aabbs", "sfx_query_rays", "sfx_query_points_static",
     "sfx_debug_aabbs", "sfx_debug_pairs", "sfx_debug_pair_colors", "sfx_debug_broadphase",
     "sfx_debug_contacts", "sfx_debug_joint_order",
@@ -258,6 +258,8 @@ def load_libsfx(path=None):
     lib.sfx_set_stream.argtypes = [vp, vp]
     lib.sfx_halo_set.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     lib.sfx_halo_pack.argtypes = [vp]
+    lib.sfx_halo_guard.argtypes = [vp, C.c_float]
+    lib.sfx_halo_guard.restype = C.c_int
     lib.sfx_halo_unpack.argtypes = [vp]
     lib.sfx_halo_buffers.argtypes = [vp, P(vp), P(vp)]
     lib.sfx_halo_download.argtypes = [vp, P(C.c_float)]

@@ -120,6 +120,8 @@ struct sfx_world {
     DevBuf<uint32_t> halo_send_idx, halo_recv_idx;
     DevBuf<float4> halo_send, halo_recv;
     uint32_t n_halo_send = 0, n_halo_recv = 0;
+    DevBuf<float> halo_x0;         // x of every body when the halo lists were set
+    float halo_guard = 0.0f;       // > 0: k_aabb_count flags a body further than this from halo_x0 (kOvfHalo)
     // spatial query index (allocated at the first query; DESIGN.md "Contract / spatial queries")
     DevBuf<uint32_t> q_zero, q_bucket, q_cell_fill, q_tmp_id, q_sorted_id, q_large_tmp, q_bounds, q_nhits;
     DevBuf<unsigned char> q_in, q_out;   // query transfer buffers, grown on demand and kept
@@ -473,7 +475,8 @@ int broadphase(sfx_world* w, float dt) {
     { Prof p(w, SFX_K_AABB_COUNT, n);
       hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p,
                          w->poly.p, w->cfg.aabb_margin, w->cfg.vel_pad_max, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start,
-                         w->large_tmp.p, w->large_cap, w->ctr, stale_half, n16, w->sticky.p); }
+                         w->large_tmp.p, w->large_cap, w->ctr, stale_half, n16, w->sticky.p,
+                         (w->halo_guard > 0.0f && w->halo_x0.n == n) ? w->halo_x0.p : (const float*)nullptr, w->halo_guard); }
     int rc = scan_u32(w, w->cell_start, w->ncell + 1, w->cell_fill.p);
     if (rc) return rc;
     { Prof p(w, SFX_K_SCATTER, n);
@@ -695,7 +698,7 @@ void sfx_destroy(sfx_world* w) {
     w->cellxy.release(); w->sorted_cell.release();
     w->used.release(); w->claim.release(); w->left_list.release();
     w->pcolor.release(); w->prop.release(); w->jctr.release(); w->sticky.release(); w->dbg.release();
-    w->halo_send_idx.release(); w->halo_recv_idx.release(); w->halo_send.release(); w->halo_recv.release();
+    w->halo_send_idx.release(); w->halo_recv_idx.release(); w->halo_send.release(); w->halo_recv.release(); w->halo_x0.release();
     w->q_zero.release(); w->q_bucket.release(); w->q_cell_fill.release(); w->q_tmp_id.release(); w->q_sorted_id.release();
     w->q_large_tmp.release(); w->q_bounds.release(); w->q_nhits.release(); w->q_aabb.release(); w->q_sorted_aabb.release();
     w->q_cellxy.release(); w->q_sorted_cell.release(); w->q_in.release(); w->q_out.release();
@@ -746,6 +749,8 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
         w->m = 0;
         w->h_dist.clear(); w->h_angle.clear(); w->joint_damped = false;
         w->joint_perm.clear(); w->joint_color_sorted.clear(); w->joint_color_start.assign(1, 0);
+        w->n_halo_send = w->n_halo_recv = 0;   // the halo lists index the old bodies
+        w->halo_guard = 0.0f;
         const size_t c = std::max(n, 1u);
         ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
         ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
@@ -1165,6 +1170,18 @@ int sfx_halo_set(sfx_world* w, const uint32_t* send_idx, uint32_t n_send, const 
     if (n_send) HIPCHK(w, hipMemcpy(w->halo_send_idx.p, send_idx, sizeof(uint32_t) * n_send, hipMemcpyHostToDevice));
     if (n_recv) HIPCHK(w, hipMemcpy(w->halo_recv_idx.p, recv_idx, sizeof(uint32_t) * n_recv, hipMemcpyHostToDevice));
     w->n_halo_send = n_send; w->n_halo_recv = n_recv;
+    // the guard's reference: where every body is now, when the lists are cut
+    ALLOC(w, w->halo_x0, std::max(w->n, 1u));
+    hipLaunchKernelGGL(k_halo_snapshot, dim3(cdiv(std::max(w->n, 1u), kBlock)), dim3(kBlock), 0, w->stream, w->n, w->pose.p, w->halo_x0.p);
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return SFX_OK;
+}
+
+int sfx_halo_guard(sfx_world* w, float max_move) {
+    if (!w) return SFX_ERR_INVALID;
+    if (!(max_move >= 0.0f)) return fail(w, SFX_ERR_INVALID, "sfx_halo_guard: max_move must be >= 0");
+    if (max_move > 0.0f && w->halo_x0.n != std::max(w->n, 1u)) return fail(w, SFX_ERR_INVALID, "sfx_halo_guard: call sfx_halo_set first");
+    w->halo_guard = max_move;
     return SFX_OK;
 }
 
@@ -1276,7 +1293,7 @@ int build_query_index(sfx_world* w, const QueryBuffers& Q) {
     { Prof p(w, SFX_K_QUERY, n);
       hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p, w->poly.p,
                          0.0f, 0.0f, 0.0f, g, Q.aabb, Q.bucket, Q.cellxy, qcs, Q.large_tmp, w->large_cap, qctr,
-                         (uint4*)nullptr, 0u, (uint32_t*)nullptr); }
+                         (uint4*)nullptr, 0u, (uint32_t*)nullptr, (const float*)nullptr, 0.0f); }
     int rc = scan_u32(w, qcs, w->ncell + 1, Q.cell_fill);
     if (rc) return rc;
     { Prof p(w, SFX_K_QUERY, n);
@@ -1483,7 +1500,7 @@ int sfx_sync(sfx_world* w) {
         w->ovf_host = 0;
         HIPCHK(w, hipMemset(w->sticky.p, 0, sizeof(uint32_t)));
         if (w->ticked && w->have_colliders && !w->tick_open) { HIPCHK(w, hipMemset(&w->ctr->overflow, 0, sizeof(uint32_t))); w->stale.overflow = 0; }
-        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in a tick since the last sfx_sync (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list, 32 a fused solve launch gave up waiting, 64 more than 64 large colliders over one batch of tiles)",
+        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in a tick since the last sfx_sync (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list, 32 a fused solve launch gave up waiting, 64 more than 64 large colliders over one batch of tiles, 128 a body moved beyond the halo guard: cut the slabs again)",
                     bits);
     }
     return SFX_OK;

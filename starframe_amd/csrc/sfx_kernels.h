@@ -37,7 +37,7 @@ constexpr uint32_t kMaxBX = kMaxB + kMaxExt;        // LDS body slots of a tile 
 constexpr int kScanItems = 16;                      // items per thread in the block scan
 constexpr int kScanTile = kBlock * kScanItems;      // 4096 items per block
 constexpr uint32_t kLeftCap = 4096;                 // leftover edges the serial finish takes
-constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u, kOvfFallback = 16u, kOvfStall = 32u, kOvfExt = 64u;
+constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u, kOvfFallback = 16u, kOvfStall = 32u, kOvfExt = 64u, kOvfHalo = 128u;
 
 // stage timing of the tile kernels and the colouring (development builds with -DSFX_TILE_TIMING; `T.dbg` or `dbg` in scope)
 #ifdef SFX_TILE_TIMING
@@ -176,7 +176,8 @@ __global__ __launch_bounds__(kBlock) void k_aabb_count(uint32_t n, const float4*
                                                         uint32_t* __restrict__ cell_count, uint32_t* __restrict__ large_tmp,
                                                         uint32_t large_cap, Counters* __restrict__ ctr,
                                                         uint4* __restrict__ stale_half, uint32_t n16,
-                                                        uint32_t* __restrict__ sticky) {
+                                                        uint32_t* __restrict__ sticky, const float* __restrict__ guard_x0,
+                                                        float guard_limit) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     // the zero block of the previous tick (the next tick's): cleared here, nothing in this tick reads it; its overflow
     // bits move to the sticky word first (thread 0 clears the unit that holds them itself, after reading it)
@@ -184,7 +185,10 @@ __global__ __launch_bounds__(kBlock) void k_aabb_count(uint32_t n, const float4*
     for (uint32_t k = i; k < n16; k += gridDim.x * kBlock) stale_half[k] = make_uint4(0u, 0u, 0u, 0u);
     if (i >= n) return;
     const float4 sh = shape[i];
-    const float4 A = compute_aabb(pose[i], vel[i], sh, poly, margin, vel_pad_max, dt);
+    const float4 ps = pose[i];
+    // slab worlds: a body that has moved further on x than the halo lists allow for since they were cut (sfx_halo_guard)
+    if (guard_x0 && fabsf(ps.x - guard_x0[i]) > guard_limit) atomicOr(&ctr->overflow, kOvfHalo);
+    const float4 A = compute_aabb(ps, vel[i], sh, poly, margin, vel_pad_max, dt);
     aabb[i] = A;
     uint32_t bk = SFX_NO_BUCKET;
     if (shape_type(sh) != SFX_SHAPE_NONE) {
@@ -1962,6 +1966,12 @@ __global__ __launch_bounds__(kBlock) void k_halo_unpack(uint32_t n, const uint32
     const uint32_t i = idx[k];
     pose[i] = in[2 * k];
     vel[i] = in[2 * k + 1];
+}
+
+// x of every body at the moment the halo lists were cut (the reference of the halo guard)
+__global__ __launch_bounds__(kBlock) void k_halo_snapshot(uint32_t n, const float4* __restrict__ pose, float* __restrict__ x0) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) x0[i] = pose[i].x;
 }
 
 // ---------------------------------------------------------------- reporting / parity hooks

@@ -150,10 +150,31 @@ def needs_replan(counts, moved, halo, tol):
     """Re-cut when the slabs' populations differ by more than `tol` of the mean (10 %) or
     when a body has moved so far on x since the cut that the ghost lists may miss a contact: a body that
     was not ghosted lay more than `halo` = 4 r_max + pads beyond the boundary and touches nothing further
-    than 2 r_max away, so the lists are good while no body has moved more than a quarter of the halo."""
+    than 2 r_max away, so the lists are good while no body has moved more than a quarter of the halo (where the
+    halo guard stops the run); the re-cut is taken at an eighth, so that a check every few frames comes in time."""
     mean = counts.sum() / max(len(counts), 1)
     imbalance = float(counts.max() / mean - 1.0) if mean > 0 else 0.0
-    return imbalance > tol or moved > 0.25 * halo, imbalance
+    return imbalance > tol or moved > 0.125 * halo, imbalance
+
+
+class StaleHalo(RuntimeError):
+    """A body has moved more than a quarter of the halo since the slabs were cut: ghost lists may miss contacts."""
+
+
+def arm_guard(world, halo):
+    """Device-side guard where the engine has one (libsfx: checked by every tick's first kernel, reported as
+    SFX_ERR_CAPACITY bit 128 by the next sync or tick); returns False for engines that need the host check."""
+    if hasattr(world, "halo_guard"):
+        world.halo_guard(0.25 * halo)
+        return True
+    return False
+
+
+def host_guard(world, plan, scene, halo):
+    """The same check on the host, for engines without the device guard (the CPU oracle in the tests)."""
+    k = plan.n_owned
+    if k and float(np.abs(world.poses()[0][:k, 0] - scene.pos[plan.ids[:k], 0]).max()) > 0.25 * halo:
+        raise StaleHalo("a body moved more than halo / 4 since the slabs were cut: rebalance (rebalance_every > 0)")
 
 
 def local_scene(scene, plan):
@@ -177,8 +198,10 @@ class LocalSlabs:
         self.scene = scene
         self.plans, self.bounds = plan_slabs(scene, self.nslabs, self.halo)
         self.worlds = [self.engine.from_scene(local_scene(scene, p), **self.cfg_kw) for p in self.plans]
+        self.device_guard = True
         for w, p in zip(self.worlds, self.plans):
             w.halo_set(p.send_idx, p.recv_idx)
+            self.device_guard = arm_guard(w, self.halo) and self.device_guard
         self.device_copies = all(hasattr(w, "halo_copy_from") for w in self.worlds)
 
     def rebalance(self, force=False):
@@ -230,6 +253,9 @@ class LocalSlabs:
         self.frames += 1
         if self.rebalance_every and self.frames % self.rebalance_every == 0:
             self.rebalance()
+        elif not self.device_guard:   # never silently: without the device guard the host looks every frame
+            for w, p in zip(self.worlds, self.plans):
+                host_guard(w, p, self.scene, self.halo)
 
     def gather(self):
         """Global (pos, rot, vel, angvel): every body from its owner (fixed bodies from any copy)."""
@@ -290,6 +316,7 @@ class DistSlab:
         self.all_plans = plans
         self.world = self.engine.from_scene(local_scene(scene, self.plan), **self.cfg_kw)
         self.world.halo_set(self.plan.send_idx, self.plan.recv_idx)
+        self.device_guard = arm_guard(self.world, self.halo)
         self.on_device = dist.get_backend() == "nccl" and hasattr(self.world, "halo_buffer_pointers")
         p = self.plan
         self.n_sl, self.n_sr, self.n_rl, self.n_rr = len(p.send_left), len(p.send_right), len(p.recv_left), len(p.recv_right)
@@ -387,6 +414,8 @@ class DistSlab:
         self.frames += 1
         if self.rebalance_every and self.frames % self.rebalance_every == 0:
             self.rebalance()
+        elif not self.device_guard:
+            host_guard(self.world, self.plan, self.scene, self.halo)
 
     def sync(self):
         self.world.sync()

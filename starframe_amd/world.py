@@ -147,6 +147,10 @@ class World(WorldBase):
         self.n_halo_send, self.n_halo_recv = len(s), len(r)
         self._check(self.lib.sfx_halo_set(self.handle, vptr(s), len(s), vptr(r), len(r)))
 
+    def halo_guard(self, max_move):
+        """Ticks flag (overflow bit 128 -> SFX_ERR_CAPACITY) a body that moved further than max_move on x since halo_set."""
+        self._check(self.lib.sfx_halo_guard(self.handle, float(max_move)))
+
     def halo_get(self):
         """Host copy of the send bodies' (pose, velocity): [n_send, 8]."""
         out = np.empty((self.n_halo_send, 8), np.float32)

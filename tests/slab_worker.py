@@ -21,12 +21,12 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
     s = scenes.circles_container(n=600, width=60, floor_hw=8.0, wall_hh=8.0)
-    if drifting:   # the pile slides to the right wall: bodies change slab, the cut is renewed every 5 frames
+    if drifting:   # the pile slides to the right wall: bodies change slab, the cut is renewed every 3 frames
         dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
         vel = np.zeros_like(s.pos)
         vel[dyn, 0] = 2.0
         s = s.with_state(s.pos, s.rot, vel, s.angvel)
-    slab = DistSlab(s, OracleWorld, dist, rebalance_every=5 if drifting else 0)
+    slab = DistSlab(s, OracleWorld, dist, halo=1.5, rebalance_every=2)
     for _ in range(ticks):
         slab.step(1.0 / 60.0)
     pos, rot, vel, ang = slab.gather()

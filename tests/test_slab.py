@@ -78,7 +78,7 @@ def test_logical_slabs_match_undecomposed_pile_statistically():
     from oracle.oracle import OracleWorld
 
     s = small_scene()
-    L = LocalSlabs(s, 3, OracleWorld)
+    L = LocalSlabs(s, 3, OracleWorld, halo=1.5, rebalance_every=2)   # landing circles shoot sideways at 3 m/s: a wide halo, frequent re-cuts
     W = OracleWorld.from_scene(s)
     for _ in range(360):
         L.step(DT)
@@ -113,13 +113,13 @@ def test_two_ranks_over_gloo_equal_logical_slabs(tmp_path):
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_worker.py"), out, "40"], env=env))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_worker.py"), out, "41"], env=env))
     for p in procs:
         assert p.wait(timeout=240) == 0
     z = np.load(out)
     s = small_scene()
-    L = LocalSlabs(s, 2, OracleWorld)
-    for _ in range(40):
+    L = LocalSlabs(s, 2, OracleWorld, halo=1.5, rebalance_every=2)
+    for _ in range(41):   # odd: the last frame is not one that may rebuild the worlds (fresh worlds have no statistics)
         L.step(DT)
     pos, rot, vel, ang = L.gather()
     assert np.array_equal(z["pos"].view(np.uint32), pos.view(np.uint32))
@@ -153,15 +153,18 @@ def test_rebalancing_recuts_the_slabs_when_bodies_migrate():
 
     s = drifting_scene()
     dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
-    L = LocalSlabs(s, 3, OracleWorld, rebalance_every=5)
+    L = LocalSlabs(s, 3, OracleWorld, halo=1.5, rebalance_every=2)
     frozen = LocalSlabs(s, 3, OracleWorld)            # never re-cut: its populations drift apart
     W = OracleWorld.from_scene(s)
     b0 = L.bounds.copy()
     for _ in range(240):
         L.step(DT)
         W.step(DT)
-    for _ in range(60):
-        frozen.step(DT)
+    from starframe_amd.slab import StaleHalo
+    with pytest.raises(StaleHalo):                    # ... and never silently: the halo guard stops it
+        for _ in range(60):
+            frozen.step(DT)
+    assert frozen.frames < 40
     assert L.replans >= 2
     assert not np.array_equal(b0, L.bounds)
     # right after a cut every dynamic body is owned once and the populations are equal
@@ -171,11 +174,6 @@ def test_rebalancing_recuts_the_slabs_when_bodies_migrate():
     counts = [p.n_owned for p in L.plans]
     assert max(counts) - min(counts) <= 1
     assert not L.rebalance() and L.imbalance <= 0.10   # nothing moved since: no new cut
-    # the frozen cut has drifted out of balance by now (that is what the re-cut is for)
-    from starframe_amd.slab import needs_replan, slab_counts
-    x = frozen.gather()[0][dyn, 0]
-    need, imb = needs_replan(slab_counts(x, frozen.bounds, 3), 0.0, frozen.halo, 0.10)
-    assert need and imb > 0.10
     pos, rot, vel, ang = L.gather()
     ref = W.poses()[0]
     assert np.isfinite(pos).all()
@@ -199,7 +197,7 @@ def test_two_ranks_over_gloo_rebalance_like_logical_slabs(tmp_path):
     for p in procs:
         assert p.wait(timeout=240) == 0
     z = np.load(out)
-    L = LocalSlabs(drifting_scene(), 2, OracleWorld, rebalance_every=5)
+    L = LocalSlabs(drifting_scene(), 2, OracleWorld, halo=1.5, rebalance_every=2)
     for _ in range(60):
         L.step(DT)
     pos, rot, vel, ang = L.gather()
@@ -226,8 +224,8 @@ def test_gpu_logical_slabs_match_oracle_slabs_and_undecomposed():
     gp, gr, gv, ga = G.gather()
     s2 = s.with_state(gp, gr, gv, ga)
     G.close()
-    G = LocalSlabs(s2, 4, World)
-    O = LocalSlabs(s2, 4, OracleWorld)
+    G = LocalSlabs(s2, 4, World, rebalance_every=25)   # the settling circles roll further than the halo guard allows
+    O = LocalSlabs(s2, 4, OracleWorld, rebalance_every=25)
     G.step(DT)
     O.step(DT)
     assert sum(w.stats().n_manifolds for w in G.worlds) > 500
@@ -246,6 +244,33 @@ def test_gpu_logical_slabs_match_oracle_slabs_and_undecomposed():
     assert pos[dyn, 1].min() > -0.1
     # deepest overlap of the still settling pile: no worse than the undecomposed world's by more than 3 cm
     assert max(w.stats().max_depth for w in G.worlds) < W.stats().max_depth + 0.03
+
+
+@pytest.mark.gpu
+def test_gpu_halo_guard_reports_a_stale_cut():
+    """rebalance_every = 0 and a pile that slides sideways: the first kernel of every tick compares each body's x
+    with where it was when the halo lists were cut (sfx_halo_guard, halo / 4); the tick after a body has moved
+    further sets overflow bit 128 and the next sync -- or tick -- returns SFX_ERR_CAPACITY.  Nothing else changes:
+    with the guard off the same run goes through."""
+    from starframe_amd.world import SfxError, World
+
+    L = LocalSlabs(drifting_scene(), 3, World)
+    with pytest.raises(SfxError) as e:
+        for _ in range(120):
+            L.step(DT)
+            for w in L.worlds:
+                w.sync()
+    assert e.value.code == -4 and "128" in str(e.value) or "capacity" in str(e.value)
+    assert 2 < L.frames < 60
+    L.close()
+    L = LocalSlabs(drifting_scene(), 3, World)
+    for w in L.worlds:
+        w.halo_guard(0.0)
+    for _ in range(60):
+        L.step(DT)
+    for w in L.worlds:
+        w.sync()
+    L.close()
 
 
 @pytest.mark.gpu
