@@ -9,10 +9,13 @@ workload; value = dynamic bodies x substeps x K / seconds, summed over all ranks
 
 N = 1 : the headline config (BASELINE.json configs[2]): 100k mixed circle/rect/capsule pile,
         4 substeps, settled on the GPU before anything is timed.
-N > 1 : weak scaling, one process per GPU: a pile N times as wide (N x 100k bodies) cut into N
-        slabs on x (starframe_amd/slab.py); every substep the boundary bodies go to the two
-        neighbours with RCCL send/recv (torch.distributed "nccl") straight from the library's
-        device buffers.  value = all bodies x substeps x K / max-over-ranks seconds.
+N > 1 : weak scaling, one process per GPU, BASELINE.json configs[4]: a granular slab of 500 k circles per
+        GPU (4 M at N = 8), N times as wide, cut into N slabs on x (starframe_amd/slab.py); every
+        substep the boundary bodies go to the two neighbours with plain RCCL ncclSend / ncclRecv
+        (libsfx_rccl.so) straight from the library's device buffers on the world's stream.
+        value = all bodies x substeps x K / max-over-ranks seconds; scaling_reference = rank 0's
+        share of the same settled slab alone on one GPU (the denominator of an efficiency figure:
+        the N = 1 line of this script is the 100 k pile, another workload).
 
 The JSON line also carries
   roofline     : the kernel the tick spends most time in (one of the contact-sweep kernels k_narrow,
@@ -147,6 +150,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--bodies", type=int, default=100_000)
     ap.add_argument("--width", type=int, default=1000, help="bodies per lattice row of the N = 1 pile (SURVEY.md 8d: 400)")
+    ap.add_argument("--slab-bodies", type=int, default=500_000, help="N > 1: circles per GPU of the granular slab (configs[4]: 500 k)")
+    ap.add_argument("--no-single-reference", dest="single_reference", action="store_false",
+                    help="N > 1: skip rank 0's one-GPU run of its share of the slab (reported as scaling_reference)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--settle-frames", type=int, default=600)
     ap.add_argument("--live-events", default="solve_vel",
@@ -185,15 +191,39 @@ def main():
 
         from starframe_amd.slab import DistSlab
 
-        # one pile, `world` times as wide; settled as slabs with damping, then re-cut on the settled state
-        scene_note = f"lattice {world * 1000} wide"
-        scene = scenes.mixed_pile(n=world * args.bodies, width=world * 1000)
-        pre = DistSlab(scene, World, dist, device_index=device, linear_damping=3.3, angular_damping=1.0)
-        for _ in range(args.settle_frames):
+        # BASELINE.json configs[4] in its weak-scaling form: a granular slab of `slab_bodies` circles per
+        # GPU (500 k: 4 M at N = 8), 100 lattice rows, `world` times as wide; settled as slabs with damping (untimed; the
+        # halo guard is off while the circles roll into place, re-cuts every 50 frames), then cut again on the settled state
+        per_gpu = args.slab_bodies
+        scene = scenes.granular_slab(n=world * per_gpu, width=world * (per_gpu // 100))
+        scene_note = f"granular_slab: lattice {world * (per_gpu // 100)} wide x 100 rows of circles r ~ U[0.05, 0.10], pitch 0.22 m"
+        pre = DistSlab(scene, World, dist, device_index=device, rebalance_every=50, linear_damping=3.3, angular_damping=1.0)
+        for k in range(args.settle_frames):
+            if k % 50 == 0:
+                pre.world.halo_guard(0.0)
             pre.step(DT)
         pos, rot, _, _ = pre.gather()
         pre.close()
         scene = scene.with_state(pos, rot, name=scene.name + "_settled")
+        single = None
+        if args.single_reference:   # rank 0's share of the same workload on one GPU alone: the denominator of a scaling figure
+            if rank == 0:
+                dyn = np.nonzero((scene.inv_mass > 0) | (scene.inv_inertia > 0))[0]
+                order = dyn[np.argsort(scene.pos[dyn, 0], kind="stable")][:per_gpu]
+                fixed = np.nonzero(~((scene.inv_mass > 0) | (scene.inv_inertia > 0)))[0]
+                alone = scene.subset(np.concatenate([np.sort(order), fixed]), name="granular_slab_one_gpu")
+                w1 = World.from_scene(alone, device=device)
+                for _ in range(20):
+                    w1.step(DT)
+                w1.sync()
+                t1 = time.perf_counter()
+                for _ in range(100):
+                    w1.step(DT)
+                w1.sync()
+                single = {"n_gpus": 1, "value": per_gpu * scene.substeps * 100 / (time.perf_counter() - t1), "unit": "body-substeps/s",
+                          "workload": f"the leftmost {per_gpu} bodies of the same settled slab alone on one GPU (no halo, an open right side), 100 ticks"}
+                w1.close()
+            dist.barrier()
         slab = DistSlab(scene, World, dist, device_index=device)
         w = slab.world
         n_dyn = scene.n_dynamic()            # all ranks together
@@ -201,7 +231,7 @@ def main():
         halo = len(slab.plan.send_idx)
         parallelism = (f"{world} slabs on x, {n_local} owned + {len(slab.plan.recv_idx)} ghost bodies on rank 0, "
                        f"halo of {halo} bodies x 32 B to <= 2 neighbours per substep over "
-                       f"{'RCCL device buffers' if slab.on_device else 'host staging'}")
+                       f"{'libsfx_rccl (plain rccl.h ncclSend / ncclRecv on the world stream)' if slab.native else 'torch.distributed nccl on the library buffers' if slab.on_device else 'host staging'}")
         step = lambda: slab.step(DT)
     else:
         scene = scenes.mixed_pile(n=args.bodies, width=args.width)
@@ -286,7 +316,8 @@ def main():
     bpbs = tick_bytes_per_body_substep(st2, n_rank, scene.substeps)
 
     out = {
-        "metric": "body-substeps/sec (100k-body pile, 4 substeps)",
+        "metric": "body-substeps/sec (100k-body pile, 4 substeps)" if slab is None else
+                  f"body-substeps/sec (granular slab, {args.slab_bodies // 1000}k bodies per GPU, 4 substeps)",
         "value": value,
         "unit": "body-substeps/s",
         "n_gpus": world,
@@ -299,8 +330,10 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"mixed_pile: {n_dyn} circle/rect/capsule bodies settled in a static container, "
-                        f"{scene.substeps} substeps, dt=1/60 (BASELINE.json configs[2])",
+            "workload": (f"mixed_pile: {n_dyn} circle/rect/capsule bodies settled in a static container, "
+                         f"{scene.substeps} substeps, dt=1/60 (BASELINE.json configs[2])") if slab is None else
+                        (f"granular_slab: {n_dyn} circles settled in a static container, cut into {world} slabs on x, "
+                         f"{scene.substeps} substeps, dt=1/60 (BASELINE.json configs[4] at {args.slab_bodies} bodies per GPU: 4 M at 8 GPUs)"),
             "scene": scene_note,
             "penetration_mm": pen,
             "bodies_per_gpu": n_rank,
@@ -338,6 +371,8 @@ def main():
                     "rocprofv3 --pmc passes of the native driver on the same settled scene (profiles/)",
         },
     }
+    if slab is not None and single is not None:
+        out["scaling_reference"] = single
     if dist is not None:
         dist.barrier()
     w.close()

@@ -262,6 +262,8 @@ int sfx_sync(sfx_world* w);
 int sfx_tick_begin(sfx_world* w, float frame_dt);   /* broadphase + tiles + colouring */
 int sfx_tick_substep(sfx_world* w);                 /* one substep of the tick begun */
 int sfx_set_stream(sfx_world* w, void* hip_stream); /* NULL = back to the world's own stream */
+int sfx_get_stream(sfx_world* w, void** hip_stream); /* the hipStream_t everything is enqueued on (what RCCL work is ordered against) */
+int sfx_halo_counts(sfx_world* w, uint32_t* n_send, uint32_t* n_recv); /* what sfx_halo_set was given */
 int sfx_halo_set(sfx_world* w, const uint32_t* send_idx, uint32_t n_send, const uint32_t* recv_idx, uint32_t n_recv);
 /* Halo lists are cut for the bodies' positions at sfx_halo_set: a body that was not ghosted lay more than the halo
  * width from the boundary.  sfx_halo_guard(w, d), d > 0, makes every later tick check (in its first kernel, no extra
@@ -364,4 +366,21 @@ const char* sfx_last_error(sfx_world* w); /* w may be NULL: last create error */
 #ifdef __cplusplus
 }
 #endif
+
+/* Sizes of every struct that crosses the boundary: a binding in any language checks its mirrors against these
+ * (bindings/rust/src/lib.rs has the same numbers as const assertions). */
+#if defined(__cplusplus)
+#define SFX_STATIC_ASSERT(cond, msg) static_assert(cond, msg)
+#else
+#define SFX_STATIC_ASSERT(cond, msg) _Static_assert(cond, msg)
+#endif
+SFX_STATIC_ASSERT(sizeof(sfx_config) == 80, "sfx_config");
+SFX_STATIC_ASSERT(sizeof(sfx_collider) == 40, "sfx_collider");
+SFX_STATIC_ASSERT(sizeof(sfx_material) == 12, "sfx_material");
+SFX_STATIC_ASSERT(sizeof(sfx_distance_constraint) == 40, "sfx_distance_constraint");
+SFX_STATIC_ASSERT(sizeof(sfx_angle_constraint) == 24, "sfx_angle_constraint");
+SFX_STATIC_ASSERT(sizeof(sfx_contact) == 60, "sfx_contact");
+SFX_STATIC_ASSERT(sizeof(sfx_frame_stats) == 76 + 4 * SFX_MAX_COLORS, "sfx_frame_stats");
+SFX_STATIC_ASSERT(sizeof(sfx_ray_hit) == 16, "sfx_ray_hit");
+SFX_STATIC_ASSERT(sizeof(sfx_kernel_time) == 24, "sfx_kernel_time");
 #endif /* SFX_H */

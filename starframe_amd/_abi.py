@@ -198,7 +198,7 @@ SFX_SYMBOLS = [
     "sfx_step", "sfx_sync", "sfx_download_poses", "sfx_download_velocities",
     "sfx_readback_begin", "sfx_readback_wait",
     "sfx_tick_begin", "sfx_tick_substep", "sfx_set_stream", "sfx_halo_set", "sfx_halo_pack", "sfx_halo_unpack",
-    "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy", "sfx_halo_guard",
+    "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy", "sfx_halo_guard", "sfx_get_stream", "sfx_halo_counts",
     "sfx_query_points", "sfx_query_aabbs", "sfx_query_rays", "sfx_query_points_static",
     "sfx_debug_aabbs", "sfx_debug_pairs", "sfx_debug_pair_colors", "sfx_debug_broadphase",
     "sfx_debug_contacts", "sfx_debug_joint_order",
@@ -259,6 +259,10 @@ def load_libsfx(path=None):
     lib.sfx_halo_set.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32]
     lib.sfx_halo_pack.argtypes = [vp]
     lib.sfx_halo_guard.argtypes = [vp, C.c_float]
+    lib.sfx_get_stream.argtypes = [vp, P(vp)]
+    lib.sfx_get_stream.restype = C.c_int
+    lib.sfx_halo_counts.argtypes = [vp, P(C.c_uint32), P(C.c_uint32)]
+    lib.sfx_halo_counts.restype = C.c_int
     lib.sfx_halo_guard.restype = C.c_int
     lib.sfx_halo_unpack.argtypes = [vp]
     lib.sfx_halo_buffers.argtypes = [vp, P(vp), P(vp)]
@@ -298,4 +302,37 @@ def load_libsfx(path=None):
         getattr(lib, n).restype = C.c_int
     if path is None:
         _lib = lib
+    return lib
+
+
+# ---- libsfx_rccl.so (include/sfx_rccl.h): the slab halo exchange over plain RCCL
+LIBSFX_RCCL_PATH = os.path.join(HERE, "csrc", "libsfx_rccl.so")
+SFX_RCCL_SYMBOLS = ["sfx_rccl_unique_id", "sfx_rccl_comm_create", "sfx_rccl_comm_destroy", "sfx_rccl_halo_exchange", "sfx_rccl_sendrecv",
+                    "sfx_rccl_allreduce_stats", "sfx_rccl_last_error"]
+RCCL_ID_BYTES = 128
+_rccl = None
+
+
+def load_libsfx_rccl():
+    """Loads libsfx_rccl.so (after libsfx.so, which it links).  Raises when it has not been built."""
+    global _rccl
+    if _rccl is not None:
+        return _rccl
+    load_libsfx()
+    if not os.path.exists(LIBSFX_RCCL_PATH):
+        raise RuntimeError(f"libsfx_rccl.so not found at {LIBSFX_RCCL_PATH}: build it with __graft_entry__.build()")
+    lib = C.CDLL(LIBSFX_RCCL_PATH)
+    vp, u32 = C.c_void_p, C.c_uint32
+    lib.sfx_rccl_unique_id.argtypes = [vp]
+    lib.sfx_rccl_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.sfx_rccl_comm_destroy.argtypes = [vp]
+    lib.sfx_rccl_comm_destroy.restype = None
+    lib.sfx_rccl_halo_exchange.argtypes = [vp, vp, C.c_int, C.c_int, u32, u32, u32, u32]
+    lib.sfx_rccl_sendrecv.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int]
+    lib.sfx_rccl_sendrecv.restype = C.c_int
+    lib.sfx_rccl_allreduce_stats.argtypes = [vp, C.POINTER(C.c_double), u32, C.POINTER(C.c_double), u32]
+    lib.sfx_rccl_last_error.restype = C.c_char_p
+    for n in ("sfx_rccl_unique_id", "sfx_rccl_comm_create", "sfx_rccl_halo_exchange", "sfx_rccl_allreduce_stats"):
+        getattr(lib, n).restype = C.c_int
+    _rccl = lib
     return lib

@@ -1156,6 +1156,19 @@ int sfx_set_stream(sfx_world* w, void* hip_stream) {
     return SFX_OK;
 }
 
+int sfx_get_stream(sfx_world* w, void** hip_stream) {
+    if (!w || !hip_stream) return SFX_ERR_INVALID;
+    *hip_stream = reinterpret_cast<void*>(w->stream);
+    return SFX_OK;
+}
+
+int sfx_halo_counts(sfx_world* w, uint32_t* n_send, uint32_t* n_recv) {
+    if (!w) return SFX_ERR_INVALID;
+    if (n_send) *n_send = w->n_halo_send;
+    if (n_recv) *n_recv = w->n_halo_recv;
+    return SFX_OK;
+}
+
 int sfx_halo_set(sfx_world* w, const uint32_t* send_idx, uint32_t n_send, const uint32_t* recv_idx, uint32_t n_recv) {
     if (!w || (n_send && !send_idx) || (n_recv && !recv_idx)) return fail(w, SFX_ERR_INVALID, "null argument");
     if (!w->have_bodies) return fail(w, SFX_ERR_INVALID, "upload bodies before the halo lists");

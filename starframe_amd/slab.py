@@ -292,7 +292,10 @@ class DistSlab:
     Any other backend ("gloo"): the halo goes through host memory (tests, CPU engines)."""
 
     def __init__(self, scene, engine, dist, halo=None, device_index=None, rebalance_every=0, imbalance_tol=0.10,
-                 **cfg_kw):
+                 transport="auto", **cfg_kw):
+        """transport (device path only): "native" = libsfx_rccl.so, plain rccl.h ncclSend / ncclRecv on the world's own
+        stream through a communicator of its own (the path a host without torch uses; include/sfx_rccl.h);
+        "torch" = torch.distributed batch_isend_irecv on tensors that alias the library's buffers; "auto" = native."""
         import torch
 
         self.torch, self.dist = torch, dist
@@ -306,6 +309,8 @@ class DistSlab:
             cfg_kw = dict(cfg_kw, device=device_index)
         self.cfg_kw = cfg_kw
         self.stream = None
+        self.transport = transport
+        self.rccl = self.comm = None
         self._build(scene)
 
     def _build(self, scene):
@@ -321,7 +326,11 @@ class DistSlab:
         p = self.plan
         self.n_sl, self.n_sr, self.n_rl, self.n_rr = len(p.send_left), len(p.send_right), len(p.recv_left), len(p.recv_right)
         self.send = self.recv = None
-        if self.on_device:
+        self.native = False
+        if self.on_device and self.transport in ("auto", "native"):
+            self._native_comm()
+            self.native = True
+        if self.on_device and not self.native:
             try:
                 dev = torch.device("cuda", device_index if device_index is not None else torch.cuda.current_device())
                 torch.cuda.set_device(dev)
@@ -339,6 +348,29 @@ class DistSlab:
                 warnings.warn(f"device halo buffers unavailable ({e!r}); staging the halo through host memory")
                 self.on_device = False
                 self.world.set_stream(0)
+
+    def _native_comm(self):
+        """A RCCL communicator of the library's own (once per driver; it outlives re-cuts): rank 0 makes the id, the
+        existing process group carries its 128 bytes to the others."""
+        import ctypes as C
+
+        from . import _abi
+
+        if self.comm is not None:
+            return
+        self.rccl = _abi.load_libsfx_rccl()
+        buf = (C.c_ubyte * _abi.RCCL_ID_BYTES)()
+        if self.rank == 0 and self.rccl.sfx_rccl_unique_id(buf) != 0:
+            raise RuntimeError("sfx_rccl_unique_id: " + self.rccl.sfx_rccl_last_error().decode())
+        box = [bytes(buf)]
+        self.dist.broadcast_object_list(box, src=0)
+        comm = C.c_void_p()
+        dev = self.device_index if self.device_index is not None else self.torch.cuda.current_device()
+        rc = self.rccl.sfx_rccl_comm_create((C.c_ubyte * _abi.RCCL_ID_BYTES).from_buffer_copy(box[0]), self.rank, self.nranks, dev,
+                                            C.byref(comm))
+        if rc != 0:
+            raise RuntimeError("sfx_rccl_comm_create: " + self.rccl.sfx_rccl_last_error().decode())
+        self.comm = comm
 
     def drift(self):
         """The per-frame count exchange: every rank bins its owned bodies' current x into the
@@ -388,6 +420,13 @@ class DistSlab:
         return ops
 
     def exchange(self):
+        if self.native:   # pack, grouped ncclSend / ncclRecv, unpack: all enqueued on the world's stream by libsfx_rccl
+            left = self.rank - 1 if self.rank > 0 else -1
+            right = self.rank + 1 if self.rank + 1 < self.nranks else -1
+            rc = self.rccl.sfx_rccl_halo_exchange(self.comm, self.world.handle, left, right, self.n_sl, self.n_sr, self.n_rl, self.n_rr)
+            if rc != 0:
+                raise RuntimeError("sfx_rccl_halo_exchange: " + self.rccl.sfx_rccl_last_error().decode())
+            return
         if self.on_device:
             self.world.halo_pack()
             ops = self._ops(self.send, self.recv)
@@ -461,3 +500,6 @@ class DistSlab:
 
     def close(self):
         self.world.close()
+        if self.comm is not None:
+            self.rccl.sfx_rccl_comm_destroy(self.comm)
+            self.comm = None

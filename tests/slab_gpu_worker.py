@@ -59,9 +59,36 @@ def main():
         assert np.array_equal(pos3[idx[::-1]], sent[:, 0:2]), "RCCL self send/recv did not carry the packed halo"
         w.close()
 
+        # the same exchange through libsfx_rccl (plain rccl.h, a communicator of the library's own): rank 0 names itself
+        # as its left neighbour, so its "left" send block lands in its own "from the left" ghosts
+        import ctypes as C
+
+        from starframe_amd import _abi
+        rl = _abi.load_libsfx_rccl()
+        uid = (C.c_ubyte * _abi.RCCL_ID_BYTES)()
+        assert rl.sfx_rccl_unique_id(uid) == 0, rl.sfx_rccl_last_error()
+        comm = C.c_void_p()
+        assert rl.sfx_rccl_comm_create(uid, 0, 1, 0, C.byref(comm)) == 0, rl.sfx_rccl_last_error()
+        w2 = World.from_scene(s)
+        w2.halo_set(idx, idx[::-1].copy())
+        for _ in range(4):
+            w2.step(DT)
+        w2.sync()
+        before, _ = w2.poses()
+        assert rl.sfx_rccl_halo_exchange(comm, w2.handle, 0, -1, len(idx), 0, len(idx), 0) == 0, rl.sfx_rccl_last_error()
+        w2.sync()
+        after, _ = w2.poses()
+        assert np.array_equal(after[idx[::-1]], before[idx]), "native RCCL self exchange did not carry the packed halo"
+        assert rl.sfx_rccl_halo_exchange(comm, w2.handle, 0, -1, 3, 0, len(idx), 0) != 0      # counts must match sfx_halo_set
+        sums = (C.c_double * 2)(1.5, 2.0)
+        maxs = (C.c_double * 1)(7.0)
+        assert rl.sfx_rccl_allreduce_stats(comm, sums, 2, maxs, 1) == 0 and (sums[0], sums[1], maxs[0]) == (1.5, 2.0, 7.0)
+        rl.sfx_rccl_comm_destroy(comm)
+        w2.close()
+
         slab = DistSlab(s, World, dist, device_index=0)
         ref = World.from_scene(s)
-        assert slab.on_device
+        assert slab.on_device and slab.native
         for _ in range(20):
             slab.step(DT)
             ref.step(DT)

@@ -31,6 +31,18 @@ def test_header_symbols_all_exported(libsfx):
     assert libsfx.sfx_abi_version() == 7
 
 
+def test_rccl_library_exports_its_header():
+    """libsfx_rccl.so (the halo exchange over plain rccl.h) exports every symbol include/sfx_rccl.h declares.  Loading it
+    pulls in librccl and libamdhip64; no call is made without a GPU."""
+    src = open(os.path.join(ROOT, "include", "sfx_rccl.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    syms = sorted(set(re.findall(r"\b(sfx_rccl_[a-z_0-9]+)\s*\(", src)))
+    assert sorted(_abi.SFX_RCCL_SYMBOLS) == syms
+    lib = _abi.load_libsfx_rccl()
+    for s in syms:
+        assert hasattr(lib, s), s
+
+
 def test_struct_layouts_match_header():
     prog = r"""
 #include <stdio.h>

@@ -50,6 +50,43 @@ def test_cpp_host_api_example_builds_and_runs(tmp_path):
     assert "ray from above hits body" in out.stdout
 
 
+def test_plain_c_driver_of_one_tick(tmp_path):
+    """tools/sfx_c_tick.c, compiled as C11 (no C++): upload, 180 ticks, download -- a ball rests on the floor, a bob
+    hangs on its rope.  What a Rust / Go / Java FFI sees of include/sfx.h, struct sizes asserted at compile time."""
+    exe = str(tmp_path / "sfx_c_tick")
+    csrc = os.path.join(ROOT, "starframe_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tools", "sfx_c_tick.c"), "-L", csrc, "-lsfx", "-lm", "-Wl,-rpath," + csrc, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    sys.stdout.write(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_native_rccl_slab_driver_send_to_self(tmp_path):
+    """tools/sfx_slab_run --self (C++, no torch, include/sfx_rccl.h): two logical slabs of a settled circle pile on this
+    GPU exchange their halos through ncclSend / ncclRecv from rank 0 to itself every substep; the final owned states equal,
+    bit for bit, the same slabs exchanging through sfx_halo_copy.  Then the one-process-per-GPU path with one rank."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import bench
+    from dump_scene import dump
+    from starframe_amd import scenes
+
+    s = bench.settle(scenes.circles_container(n=3000, width=150, floor_hw=20.0, wall_hh=8.0), 0, frames=300)
+    scene_file = str(tmp_path / "circles_settled.bin")
+    dump(s, scene_file)
+    exe = os.path.join(ROOT, "tools", "sfx_slab_run")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "sfx_slab_run"])
+    out = subprocess.run([exe, scene_file, "30", "--self"], capture_output=True, text=True, timeout=200)
+    sys.stdout.write(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "self test ok" in out.stdout and "rccl send-to-self" in out.stdout
+    out = subprocess.run([exe, scene_file, "30", "1"], capture_output=True, text=True, timeout=200)
+    sys.stdout.write(out.stdout)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ranks 1 bodies 3000" in out.stdout
+
+
 def test_pose_readback_overlaps_the_next_tick():
     """sfx_readback_begin / _wait (include/sfx.h): the snapshot is the state at begin, whatever is enqueued after
     it; two may be in flight, a third is refused; a view stays valid until the second begin after its own."""
