@@ -197,14 +197,18 @@ def main():
         per_gpu = args.slab_bodies
         scene = scenes.granular_slab(n=world * per_gpu, width=world * (per_gpu // 100))
         scene_note = f"granular_slab: lattice {world * (per_gpu // 100)} wide x 100 rows of circles r ~ U[0.05, 0.10], pitch 0.22 m"
-        pre = DistSlab(scene, World, dist, device_index=device, rebalance_every=50, linear_damping=3.3, angular_damping=1.0)
-        for k in range(args.settle_frames):
-            if k % 50 == 0:
-                pre.world.halo_guard(0.0)
-            pre.step(DT)
-        pos, rot, _, _ = pre.gather()
-        pre.close()
-        scene = scene.with_state(pos, rot, name=scene.name + "_settled")
+        def untimed(sc, frames, **kw):   # slabs that re-cut every 50 frames, halo guard off (bodies are on their way)
+            pre = DistSlab(sc, World, dist, device_index=device, rebalance_every=50, **kw)
+            for k in range(frames):
+                if k % 50 == 0:
+                    pre.world.halo_guard(0.0)
+                pre.step(DT)
+            pos, rot, _, _ = pre.gather()
+            pre.close()
+            return sc.with_state(pos, rot, name=scene.name + "_settled")
+
+        scene = untimed(scene, args.settle_frames, linear_damping=3.3, angular_damping=1.0)
+        scene = untimed(scene, 120)    # ... and relaxed without damping, so that the cut below is made on a pile at rest
         single = None
         if args.single_reference:   # rank 0's share of the same workload on one GPU alone: the denominator of a scaling figure
             if rank == 0:
@@ -224,7 +228,9 @@ def main():
                           "workload": f"the leftmost {per_gpu} bodies of the same settled slab alone on one GPU (no halo, an open right side), 100 ticks"}
                 w1.close()
             dist.barrier()
-        slab = DistSlab(scene, World, dist, device_index=device)
+        # an 8 m halo (0.7 % more bodies per slab): surface circles roll, and the halo guard stops the run -- loudly --
+        # when a body has moved halo / 4 = 2 m since this cut; no re-cut inside the timed region (it rebuilds the worlds)
+        slab = DistSlab(scene, World, dist, device_index=device, halo=8.0)
         w = slab.world
         n_dyn = scene.n_dynamic()            # all ranks together
         n_local = slab.plan.n_owned

@@ -217,15 +217,15 @@ def test_gpu_logical_slabs_match_oracle_slabs_and_undecomposed():
     from tests.helpers import rel_err
 
     s = scenes.circles_container(n=3000, width=150, floor_hw=20.0, wall_hh=8.0)
-    G = LocalSlabs(s, 4, World)
+    G = LocalSlabs(s, 4, World, halo=1.5, rebalance_every=5)
     O = LocalSlabs(s, 4, OracleWorld)
     for _ in range(60):          # fall until the first layers touch
         G.step(DT)
     gp, gr, gv, ga = G.gather()
     s2 = s.with_state(gp, gr, gv, ga)
     G.close()
-    G = LocalSlabs(s2, 4, World, rebalance_every=25)   # the settling circles roll further than the halo guard allows
-    O = LocalSlabs(s2, 4, OracleWorld, rebalance_every=25)
+    G = LocalSlabs(s2, 4, World, halo=1.5, rebalance_every=5)   # the settling circles roll further than the halo guard allows
+    O = LocalSlabs(s2, 4, OracleWorld, halo=1.5, rebalance_every=5)
     G.step(DT)
     O.step(DT)
     assert sum(w.stats().n_manifolds for w in G.worlds) > 500
@@ -278,8 +278,8 @@ def test_gpu_halo_host_path_equals_device_path():
     from starframe_amd.world import World
 
     s = scenes.circles_container(n=1000, width=100, floor_hw=14.0, wall_hh=6.0)
-    A = LocalSlabs(s, 2, World)
-    B = LocalSlabs(s, 2, World)
+    A = LocalSlabs(s, 2, World, halo=3.0)      # a wide halo: the guard (halo / 4) outlasts the 30 frames without a re-cut
+    B = LocalSlabs(s, 2, World, halo=3.0)
     B.device_copies = False      # through sfx_halo_download / sfx_halo_upload
     for _ in range(30):
         A.step(DT)

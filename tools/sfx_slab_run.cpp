@@ -84,7 +84,9 @@ static bool plan_slab(const Scene& s, int rank, int nranks, Plan& p) {
     }
     if ((int)xd.size() < nranks) return false;
     std::sort(xd.begin(), xd.end());
-    p.halo = 4.0f * rmax + 4.0f * (0.01f + 0.03f);
+    // slab.py's default halo plus 1.5 m: surface bodies of a pile roll, and the halo guard (a quarter of this) should not
+    // stop a run of a few hundred ticks; the extra ghosts are a fraction of a percent of a slab
+    p.halo = 4.0f * rmax + 4.0f * (0.01f + 0.03f) + 1.5f;
     std::vector<double> bounds(nranks + 1);
     bounds[0] = -INFINITY; bounds[nranks] = INFINITY;
     for (int k = 1; k < nranks; ++k) { const size_t j = (size_t)k * xd.size() / nranks; bounds[k] = 0.5 * (xd[j - 1] + xd[j]); }
