@@ -1012,8 +1012,8 @@ int sfx_tick_begin(sfx_world* w, float frame_dt) {
     HIPCHK(w, hipSetDevice(w->device));
     poll_counters(w);
     if (w->ovf_host)
-        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u, see sfx_sync): its results are incomplete; "
-                    "sfx_sync reports and clears the condition, raise the capacity (sfx_config.max_pairs) and upload again", w->ovf_host);
+        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u, listed by sfx_sync): its results are incomplete; sfx_sync reports "
+                    "and clears the condition (bit 1: raise sfx_config.max_pairs; bit 128: the halo guard, cut the slabs again)", w->ovf_host);
     w->launches = 0;
     rc = broadphase(w, frame_dt);
     if (rc) return rc;

@@ -86,7 +86,7 @@ def main():
         rl.sfx_rccl_comm_destroy(comm)
         w2.close()
 
-        slab = DistSlab(s, World, dist, device_index=0)
+        slab = DistSlab(s, World, dist, device_index=0, halo=3.0)   # falling circles: the halo guard (halo / 4) must outlast the run
         ref = World.from_scene(s)
         assert slab.on_device and slab.native
         for _ in range(20):
