@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 7u
+#define SFX_ABI_VERSION 8u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -96,8 +96,12 @@ typedef struct sfx_config {
 #define SFX_CFG_RESERVED 1u      /* not used: the tick is not launch-bound (host enqueue 0.08 ms of a 1 ms tick) */
 #define SFX_CFG_NO_FRICTION 2u   /* skip static + dynamic friction (debug)          */
 
-/* collider component (BASELINE.json:5 "body/collider/material components").
- * Collider k belongs to body k (one collider per body, no local offset). */
+/* collider component (BASELINE.json:5 "body/collider/material components"; SURVEY.md section 8a row a4: shape,
+ * local offset, layer mask).  Collider k belongs to body k (one collider per body).  The shape sits at a LOCAL
+ * POSE in the body's frame: local_pos (metres) and local_angle (radians); both 0 = centred on the body origin.
+ * Mass and inertia are the body's (the caller's: a shape off the centre of mass has the inertia of the parallel
+ * axis theorem); AABB, narrowphase and queries use the shape where it is, contact anchors are taken about the
+ * body origin. */
 typedef struct sfx_collider {
     uint32_t type;      /* sfx_shape_type                                   */
     uint32_t material;  /* index into the material table                    */
@@ -107,6 +111,8 @@ typedef struct sfx_collider {
     float p[3];         /* shape parameters, see sfx_shape_type             */
     uint32_t poly_offset; /* first vertex in the pool (SFX_SHAPE_POLY)      */
     uint32_t poly_count;  /* vertex count (SFX_SHAPE_POLY)                  */
+    float local_pos[2];   /* shape origin in the body frame                 */
+    float local_angle;    /* shape rotation in the body frame (radians)     */
 } sfx_collider;
 
 typedef struct sfx_material {
@@ -375,7 +381,7 @@ const char* sfx_last_error(sfx_world* w); /* w may be NULL: last create error */
 #define SFX_STATIC_ASSERT(cond, msg) _Static_assert(cond, msg)
 #endif
 SFX_STATIC_ASSERT(sizeof(sfx_config) == 80, "sfx_config");
-SFX_STATIC_ASSERT(sizeof(sfx_collider) == 40, "sfx_collider");
+SFX_STATIC_ASSERT(sizeof(sfx_collider) == 52, "sfx_collider");
 SFX_STATIC_ASSERT(sizeof(sfx_material) == 12, "sfx_material");
 SFX_STATIC_ASSERT(sizeof(sfx_distance_constraint) == 40, "sfx_distance_constraint");
 SFX_STATIC_ASSERT(sizeof(sfx_angle_constraint) == 24, "sfx_angle_constraint");

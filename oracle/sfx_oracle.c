@@ -52,6 +52,7 @@ struct sfo_world {
     uint32_t n;
     float *pos, *rot, *vel, *angvel, *inv_mass, *inv_inertia, *prev_pos, *prev_rot;
     sfx_collider* col;
+    float* lrot;   /* (cos, sin) of every collider's local_angle, computed once at upload */
     float *poly, *poly_nrm;
     uint32_t n_poly;
     sfx_material* mats;
@@ -119,7 +120,7 @@ sfo_world* sfo_create(const sfx_config* cfg) {
 void sfo_destroy(sfo_world* w) {
     if (!w) return;
     free(w->pos); free(w->rot); free(w->vel); free(w->angvel); free(w->inv_mass);
-    free(w->inv_inertia); free(w->prev_pos); free(w->prev_rot); free(w->col); free(w->poly);
+    free(w->inv_inertia); free(w->prev_pos); free(w->prev_rot); free(w->col); free(w->lrot); free(w->poly);
     free(w->poly_nrm); free(w->mats); free(w->joints); free(w->angles); free(w->joint_perm); free(w->joint_color);
     free(w->aabb); free(w->pa); free(w->pb); free(w->color); free(w->order); free(w->rec);
     free(w->ccx); free(w->ccy); free(w->is_small); free(w->owner); free(w->pclass); free(w->batch_end);
@@ -264,9 +265,14 @@ static void resolve_grid(sfo_world* w) {
 int sfo_upload_colliders(sfo_world* w, uint32_t n, const sfx_collider* colliders,
                          const float* poly_verts, uint32_t n_poly_verts) {
     if (n != w->n) return SFX_ERR_INVALID;
-    free(w->col); free(w->poly); free(w->poly_nrm);
+    free(w->col); free(w->poly); free(w->poly_nrm); free(w->lrot);
     w->col = (sfx_collider*)malloc((n ? n : 1) * sizeof(sfx_collider));
     memcpy(w->col, colliders, n * sizeof(sfx_collider));
+    w->lrot = (float*)malloc((n ? n : 1) * 2 * sizeof(float));
+    for (uint32_t i = 0; i < n; ++i) { /* the only trigonometry of the contract: once, on the host, at upload */
+        w->lrot[2 * i] = w->col[i].local_angle == 0.0f ? 1.0f : cosf(w->col[i].local_angle);
+        w->lrot[2 * i + 1] = w->col[i].local_angle == 0.0f ? 0.0f : sinf(w->col[i].local_angle);
+    }
     w->n_poly = n_poly_verts;
     w->poly = dupf(poly_verts, 2u * n_poly_verts);
     w->poly_nrm = (float*)calloc(2u * n_poly_verts + 1, sizeof(float));
@@ -510,12 +516,44 @@ int sfo_upload_angle_constraints(sfo_world* w, uint32_t m, const sfx_angle_const
     return rebuild_joints(w);
 }
 
+/* ------------------------------------------------------------------ collider pose
+ * [DESIGN] DESIGN.md "Contract / collider pose" (SURVEY.md section 8a row a4 "local offset").  The shape of body i
+ * sits at local_pos, turned by local_angle, in the body's frame.  A collider without a local pose (both zero)
+ * has the body's pose, bit for bit. */
+static int has_local(const sfo_world* w, uint32_t i) {
+    const sfx_collider* c = &w->col[i];
+    return c->local_pos[0] != 0.0f || c->local_pos[1] != 0.0f || c->local_angle != 0.0f;
+}
+
+static void collider_pose(const sfo_world* w, uint32_t i, float* px, float* py, float* rc, float* rs) {
+    float bx = w->pos[2 * i], by = w->pos[2 * i + 1], bc = w->rot[2 * i], bs = w->rot[2 * i + 1];
+    if (!has_local(w, i)) { *px = bx; *py = by; *rc = bc; *rs = bs; return; }
+    float ox = w->col[i].local_pos[0], oy = w->col[i].local_pos[1], lc = w->lrot[2 * i], ls = w->lrot[2 * i + 1];
+    *px = bx + (bc * ox - bs * oy);
+    *py = by + (bs * ox + bc * oy);
+    *rc = bc * lc - bs * ls;
+    *rs = bs * lc + bc * ls;
+}
+
+/* how far the collider may travel per axis before the next broadphase: the body's speed, plus -- for a shape off the
+ * body origin -- what the spin adds at that distance */
+static void motion_pads(const sfo_world* w, uint32_t i, float dt, float margin, float vel_pad_max, float* padx, float* pady) {
+    float sx = fabsf(w->vel[2 * i]), sy = fabsf(w->vel[2 * i + 1]);
+    if (has_local(w, i)) {
+        float ox = w->col[i].local_pos[0], oy = w->col[i].local_pos[1];
+        float swing = fabsf(w->angvel[i]) * sqrtf(ox * ox + oy * oy);
+        sx = sx + swing; sy = sy + swing;
+    }
+    *padx = margin + fminf(sx * dt, vel_pad_max);
+    *pady = margin + fminf(sy * dt, vel_pad_max);
+}
+
 /* ------------------------------------------------------------------ AABB
  * [DESIGN] DESIGN.md "Contract / AABB".  Operation order is part of the contract. */
 static void compute_aabb_ex(const sfo_world* w, uint32_t i, float dt, float margin, float vel_pad_max, float* out) {
     const sfx_collider* c = &w->col[i];
-    float px = w->pos[2 * i], py = w->pos[2 * i + 1];
-    float rc = w->rot[2 * i], rs = w->rot[2 * i + 1];
+    float px, py, rc, rs;
+    collider_pose(w, i, &px, &py, &rc, &rs);
     float minx, maxx, miny, maxy;
     switch (c->type) {
     case SFX_SHAPE_CIRCLE:
@@ -548,8 +586,8 @@ static void compute_aabb_ex(const sfo_world* w, uint32_t i, float dt, float marg
         out[0] = out[1] = INFINITY; out[2] = out[3] = -INFINITY;
         return;
     }
-    float padx = margin + fminf(fabsf(w->vel[2 * i]) * dt, vel_pad_max);
-    float pady = margin + fminf(fabsf(w->vel[2 * i + 1]) * dt, vel_pad_max);
+    float padx, pady;
+    motion_pads(w, i, dt, margin, vel_pad_max, &padx, &pady);
     out[0] = (px + minx) - padx;
     out[1] = (py + miny) - pady;
     out[2] = (px + maxx) + padx;
@@ -706,7 +744,9 @@ static void grid_pairs(sfo_world* w) {
  * is a lower bound of the distance, so the test never drops a pair that could touch. */
 static void support_extents(const sfo_world* w, uint32_t i, float nx, float ny, float* hp, float* hm) {
     const sfx_collider* c = &w->col[i];
-    float rc = w->rot[2 * i], rs = w->rot[2 * i + 1];
+    float cpx, cpy, rc, rs;
+    collider_pose(w, i, &cpx, &cpy, &rc, &rs);
+    (void)cpx; (void)cpy;
     switch (c->type) {
     case SFX_SHAPE_CIRCLE:
         *hp = *hm = c->p[2];
@@ -746,13 +786,16 @@ static float axis_gap(const sfo_world* w, uint32_t a, uint32_t b, float nx, floa
 }
 
 static float reach_of(const sfo_world* w, uint32_t i, float dt) {
-    float px = w->cfg.aabb_margin + fminf(fabsf(w->vel[2 * i]) * dt, w->cfg.vel_pad_max);
-    float py = w->cfg.aabb_margin + fminf(fabsf(w->vel[2 * i + 1]) * dt, w->cfg.vel_pad_max);
+    float px, py;
+    motion_pads(w, i, dt, w->cfg.aabb_margin, w->cfg.vel_pad_max, &px, &py);
     return sqrtf(px * px + py * py);
 }
 
 static int pair_in_reach(const sfo_world* w, uint32_t a, uint32_t b, float dt) {
-    float dx = w->pos[2 * b] - w->pos[2 * a], dy = w->pos[2 * b + 1] - w->pos[2 * a + 1];
+    float ax, ay, ac, as, bx, by, bc, bs; /* the shapes' poses: the gaps are measured between the shapes */
+    collider_pose(w, a, &ax, &ay, &ac, &as);
+    collider_pose(w, b, &bx, &by, &bc, &bs);
+    float dx = bx - ax, dy = by - ay;
     float d2 = dx * dx + dy * dy;
     float gap = -INFINITY;
     if (d2 > 1e-12f) {
@@ -763,7 +806,7 @@ static int pair_in_reach(const sfo_world* w, uint32_t a, uint32_t b, float dt) {
         uint32_t i = k ? b : a;
         uint32_t t = w->col[i].type;
         if (t != SFX_SHAPE_RECT && t != SFX_SHAPE_CAPSULE) continue;
-        float rc = w->rot[2 * i], rs = w->rot[2 * i + 1];
+        float rc = k ? bc : ac, rs = k ? bs : as;
         gap = fmaxf(gap, axis_gap(w, a, b, rc, rs, dx, dy));
         gap = fmaxf(gap, axis_gap(w, a, b, -rs, rc, dx, dy));
     }
@@ -944,8 +987,8 @@ size_t sfo_joint_order(const sfo_world* w, uint32_t* perm, uint8_t* colors, size
 
 static void build_core(const sfo_world* w, uint32_t i, core_t* c) {
     const sfx_collider* col = &w->col[i];
-    float px = w->pos[2 * i], py = w->pos[2 * i + 1];
-    float rc = w->rot[2 * i], rs = w->rot[2 * i + 1];
+    float px, py, rc, rs;
+    collider_pose(w, i, &px, &py, &rc, &rs);
     c->r = col->p[2];
     switch (col->type) {
     case SFX_SHAPE_CIRCLE:

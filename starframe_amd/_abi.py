@@ -96,6 +96,8 @@ collider_dtype = np.dtype(
         ("p", "<f4", (3,)),
         ("poly_offset", "<u4"),
         ("poly_count", "<u4"),
+        ("local_pos", "<f4", (2,)),
+        ("local_angle", "<f4"),
     ]
 )
 material_dtype = np.dtype([("restitution", "<f4"), ("static_friction", "<f4"), ("dynamic_friction", "<f4")])
@@ -132,7 +134,7 @@ contact_dtype = np.dtype(
         ("point_b", "<f4", (2, 2)),
     ]
 )
-assert collider_dtype.itemsize == 40
+assert collider_dtype.itemsize == 52
 assert material_dtype.itemsize == 12
 assert constraint_dtype.itemsize == 40
 assert angle_constraint_dtype.itemsize == 24

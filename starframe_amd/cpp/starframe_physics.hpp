@@ -90,6 +90,13 @@ public:
         }
     }
 
+    // the shape's pose in the body frame (the reference's collider "local offset"); the body's inertia then follows the
+    // parallel axis theorem (Body::new_dynamic)
+    Collider with_offset(Vec2 offset, float angle = 0.0f) const {
+        Collider c = *this; c.raw_.local_pos[0] = offset.x; c.raw_.local_pos[1] = offset.y; c.raw_.local_angle = angle; return c;
+    }
+    float offset2() const { return raw_.local_pos[0] * raw_.local_pos[0] + raw_.local_pos[1] * raw_.local_pos[1]; }
+
     sfx_collider raw_{};
     std::vector<Vec2> verts_;
     PhysicsMaterial material_;
@@ -102,10 +109,10 @@ class Body {
 public:
     static Body new_dynamic(const Collider& c, float density) {
         Body b; float m = density * c.area(); b.inv_mass = m > 0 ? 1 / m : 0;
-        float i = m * c.unit_inertia(); b.inv_inertia = i > 0 ? 1 / i : 0; return b;
+        float i = m * (c.unit_inertia() + c.offset2()); b.inv_inertia = i > 0 ? 1 / i : 0; return b;
     }
     static Body new_dynamic_const_mass(const Collider& c, float mass) {
-        Body b; b.inv_mass = mass > 0 ? 1 / mass : 0; float i = mass * c.unit_inertia(); b.inv_inertia = i > 0 ? 1 / i : 0; return b;
+        Body b; b.inv_mass = mass > 0 ? 1 / mass : 0; float i = mass * (c.unit_inertia() + c.offset2()); b.inv_inertia = i > 0 ? 1 / i : 0; return b;
     }
     static Body new_particle(float mass) { Body b; b.inv_mass = mass > 0 ? 1 / mass : 0; return b; }
     static Body new_kinematic() { return Body(); }

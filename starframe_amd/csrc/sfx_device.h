@@ -35,13 +35,41 @@ struct BodyArrays {
     float4* vel;
     const float2* mass;
     const float4* shape;
+    const float4* lpose; // local pose of the shape in the body frame (ox, oy, cos, sin); read only where shape_local() says so
     const uint4* filt;
     const float4* poly;  // (vx, vy, nx, ny) per pool vertex
     const float4* mats;  // (restitution, mu_s, mu_d, 0)
 };
 
+// shape.x bits: type (8) | material (23) << 8 | has a local pose << 31
 __device__ __forceinline__ uint32_t shape_type(const float4& s) { return __float_as_uint(s.x) & 0xFFu; }
-__device__ __forceinline__ uint32_t shape_material(const float4& s) { return __float_as_uint(s.x) >> 8; }
+__device__ __forceinline__ uint32_t shape_material(const float4& s) { return (__float_as_uint(s.x) >> 8) & 0x7FFFFFu; }
+__device__ __forceinline__ bool shape_local(const float4& s) { return (__float_as_uint(s.x) >> 31) != 0u; }
+
+// DESIGN.md "Contract / collider pose": where the shape is = body pose o local pose.  A shape without a local pose has
+// the body's pose bit for bit (callers branch on shape_local and do not even load lp then).
+__device__ __forceinline__ float4 collider_pose(const float4& pose, const float4& lp) {
+    return make_float4(pose.x + (pose.z * lp.x - pose.w * lp.y), pose.y + (pose.w * lp.x + pose.z * lp.y),
+                       pose.z * lp.z - pose.w * lp.w, pose.w * lp.z + pose.z * lp.w);
+}
+
+__device__ __forceinline__ float4 shape_pose(const float4& pose, const float4& shape, const float4* __restrict__ lpose, uint32_t i) {
+    return shape_local(shape) ? collider_pose(pose, lpose[i]) : pose;
+}
+
+// how far the collider may travel per axis before the next broadphase: the body's speed plus, for a shape off the body
+// origin, what the spin adds at that distance (lp is read only for such shapes)
+__device__ __forceinline__ void motion_pads(const float4& vel, const float4& shape, const float4* __restrict__ lpose, uint32_t i,
+                                            float margin, float vel_pad_max, float dt, float& padx, float& pady) {
+    float sx = fabsf(vel.x), sy = fabsf(vel.y);
+    if (shape_local(shape)) {
+        const float4 lp = lpose[i];
+        const float swing = fabsf(vel.z) * sqrtf(lp.x * lp.x + lp.y * lp.y);
+        sx = sx + swing; sy = sy + swing;
+    }
+    padx = margin + fminf(sx * dt, vel_pad_max);
+    pady = margin + fminf(sy * dt, vel_pad_max);
+}
 
 __device__ __forceinline__ void rotate_by(float& c, float& s, float dth) {
     float nc = c - dth * s;
@@ -52,9 +80,8 @@ __device__ __forceinline__ void rotate_by(float& c, float& s, float dth) {
 }
 
 // ---- AABB (DESIGN.md "Contract / AABB") --------------------------------------------
-__device__ __forceinline__ float4 compute_aabb(const float4& pose, const float4& vel, const float4& shape,
-                                               const float4* __restrict__ poly, float margin, float vel_pad_max,
-                                               float dt) {
+__device__ __forceinline__ float4 compute_aabb(const float4& pose /* of the shape */, const float4& shape,
+                                               const float4* __restrict__ poly, float padx, float pady) {
     const float px = pose.x, py = pose.y, rc = pose.z, rs = pose.w;
     float minx, maxx, miny, maxy;
     const uint32_t type = shape_type(shape);
@@ -81,8 +108,6 @@ __device__ __forceinline__ float4 compute_aabb(const float4& pose, const float4&
     } else {
         return make_float4(INFINITY, INFINITY, -INFINITY, -INFINITY);
     }
-    float padx = margin + fminf(fabsf(vel.x) * dt, vel_pad_max);
-    float pady = margin + fminf(fabsf(vel.y) * dt, vel_pad_max);
     return make_float4((px + minx) - padx, (py + miny) - pady, (px + maxx) + padx, (py + maxy) + pady);
 }
 
@@ -130,15 +155,9 @@ __device__ __forceinline__ float axis_gap(const float4& pa, const float4& sa, co
     return t >= 0.0f ? t - (hap + hbm) : (-t) - (ham + hbp);
 }
 
-__device__ __forceinline__ float reach_of(const float4& vel, float margin, float vel_pad_max, float dt) {
-    const float px = margin + fminf(fabsf(vel.x) * dt, vel_pad_max);
-    const float py = margin + fminf(fabsf(vel.y) * dt, vel_pad_max);
-    return sqrtf(px * px + py * py);
-}
-
-__device__ __forceinline__ bool pair_in_reach(const float4& pa, const float4& sa, const float4& va, const float4& pb,
-                                              const float4& sb, const float4& vb, const float4* __restrict__ poly,
-                                              float margin, float vel_pad_max, float dt, float sm) {
+// pa, pb: the SHAPES' poses; ra, rb: the two colliders' reaches, sqrt(padx^2 + pady^2) of motion_pads
+__device__ __forceinline__ bool pair_in_reach(const float4& pa, const float4& sa, float ra, const float4& pb,
+                                              const float4& sb, float rb, const float4* __restrict__ poly, float sm) {
     const float dx = pb.x - pa.x, dy = pb.y - pa.y;
     const float d2 = dx * dx + dy * dy;
     float gap = -INFINITY;
@@ -155,7 +174,7 @@ __device__ __forceinline__ bool pair_in_reach(const float4& pa, const float4& sa
         gap = fmaxf(gap, axis_gap(pa, sa, pb, sb, poly, pb.z, pb.w, dx, dy));
         gap = fmaxf(gap, axis_gap(pa, sa, pb, sb, poly, -pb.w, pb.z, dx, dy));
     }
-    const float thr = (reach_of(va, margin, vel_pad_max, dt) + reach_of(vb, margin, vel_pad_max, dt)) + sm;
+    const float thr = (ra + rb) + sm;
     return !(gap > thr);
 }
 
@@ -580,10 +599,11 @@ struct PairRec {
 // batches"): manifold, body-local anchors, pre-solve normal velocities, combined material.
 __device__ __forceinline__ void prepare_pair(const float4& pa, const float4& sa, const float4& va,
                                              const float4& pb, const float4& sb, const float4& vb,
+                                             const float4& ca /* pose of a's shape */, const float4& cb,
                                              const float4* __restrict__ poly, const float4* __restrict__ mats,
                                              float sm, PairRec& r) {
     Manifold m;
-    manifold(pa, sa, pb, sb, poly, sm, m);
+    manifold(ca, sa, cb, sb, poly, sm, m);
     r.count = m.count;
     r.l0 = 0.0f; r.l1 = 0.0f;
     r.nx = 0.0f; r.ny = 0.0f; r.mu_s = 0.0f; r.mu_d = 0.0f; r.rest = 0.0f;

@@ -82,7 +82,7 @@ struct sfx_world {
     std::vector<float> h_inv_mass, h_inv_inertia, h_pos_x, h_pos_y;
     std::vector<sfx_collider> h_col;
     std::vector<float> h_poly;
-    DevBuf<float4> pose, prev, vel, shape, poly, mats, aabb, sorted_aabb;
+    DevBuf<float4> pose, prev, vel, shape, lpose, poly, mats, aabb, sorted_aabb;
     DevBuf<float2> mass;
     DevBuf<uint4> filt;
     // broadphase.  `zero` is one allocation cleared by a single memset per tick:
@@ -390,7 +390,7 @@ int collect_profile(sfx_world* w) {
 BodyArrays body_arrays(sfx_world* w) {
     BodyArrays B;
     B.pose = w->pose.p; B.prev = w->prev.p; B.vel = w->vel.p; B.mass = w->mass.p;
-    B.shape = w->shape.p; B.filt = w->filt.p; B.poly = w->poly.p; B.mats = w->mats.p;
+    B.shape = w->shape.p; B.lpose = w->lpose.p; B.filt = w->filt.p; B.poly = w->poly.p; B.mats = w->mats.p;
     return B;
 }
 
@@ -474,7 +474,7 @@ int broadphase(sfx_world* w, float dt) {
     }
     { Prof p(w, SFX_K_AABB_COUNT, n);
       hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p,
-                         w->poly.p, w->cfg.aabb_margin, w->cfg.vel_pad_max, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start,
+                         w->lpose.p, w->poly.p, w->cfg.aabb_margin, w->cfg.vel_pad_max, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start,
                          w->large_tmp.p, w->large_cap, w->ctr, stale_half, n16, w->sticky.p,
                          (w->halo_guard > 0.0f && w->halo_x0.n == n) ? w->halo_x0.p : (const float*)nullptr, w->halo_guard); }
     int rc = scan_u32(w, w->cell_start, w->ncell + 1, w->cell_fill.p);
@@ -515,7 +515,7 @@ int broadphase(sfx_world* w, float dt) {
       hipLaunchKernelGGL(k_pairs<true>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
                          w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }
     ReachParams RP;
-    RP.pose = w->pose.p; RP.vel = w->vel.p; RP.poly = w->poly.p;
+    RP.pose = w->pose.p; RP.vel = w->vel.p; RP.lpose = w->lpose.p; RP.poly = w->poly.p;
     RP.margin = w->cfg.aabb_margin; RP.vel_pad_max = w->cfg.vel_pad_max; RP.dt = dt; RP.sm = w->cfg.speculative_margin;
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
       const uint32_t est = w->ctr_valid ? w->stale.n_tile_pairs + w->stale.n_tile_pairs / 4u + 4096u : w->max_pairs;
@@ -689,7 +689,7 @@ void sfx_destroy(sfx_world* w) {
     (void)hipStreamSynchronize(w->stream);
     for (auto& e : w->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : w->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    w->pose.release(); w->prev.release(); w->vel.release(); w->shape.release(); w->poly.release();
+    w->pose.release(); w->prev.release(); w->vel.release(); w->shape.release(); w->lpose.release(); w->poly.release();
     w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release();
     w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
     w->active.release(); w->batches.release(); w->torder.release(); w->done.release(); w->bbody.release(); w->bruns.release(); w->rawp.release(); w->tpair.release();
@@ -753,7 +753,7 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
         w->halo_guard = 0.0f;
         const size_t c = std::max(n, 1u);
         ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
-        ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
+        ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->lpose, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
         ALLOC(w, w->bucket, c); ALLOC(w, w->tmp_id, c); ALLOC(w, w->sorted_id, c); ALLOC(w, w->large_tmp, c);
         ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->slot_off, 2 * ((size_t)n + 1)); ALLOC(w, w->hit_tmp, kHitTmp * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
         ALLOC(w, w->used, c); ALLOC(w, w->claim, c * kClaim);
@@ -808,14 +808,20 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     w->h_poly.assign(poly_verts, poly_verts + 2 * (size_t)n_poly_verts);
     w->n_poly = n_poly_verts;
     std::vector<float4> hpoly(std::max(n_poly_verts, 1u), make_float4(0, 0, 0, 0));
-    std::vector<float4> hs(std::max(n, 1u));
+    std::vector<float4> hs(std::max(n, 1u)), hl(std::max(n, 1u));
     for (uint32_t i = 0; i < n; ++i) {
         const sfx_collider& c = col[i];
         if (c.type > SFX_SHAPE_POLY) return fail(w, SFX_ERR_INVALID, "collider %u: unknown shape type %u", i, c.type);
         if (c.type != SFX_SHAPE_NONE && w->have_mats && c.material >= w->n_mats)
             return fail(w, SFX_ERR_INVALID, "collider %u: material %u out of range", i, c.material);
-        if (c.material >= (1u << 24)) return fail(w, SFX_ERR_INVALID, "collider %u: material index too large", i);
-        const uint32_t bits = c.type | (c.material << 8);
+        if (c.material >= (1u << 23)) return fail(w, SFX_ERR_INVALID, "collider %u: material index too large", i);
+        if (!std::isfinite(c.local_pos[0]) || !std::isfinite(c.local_pos[1]) || !std::isfinite(c.local_angle))
+            return fail(w, SFX_ERR_INVALID, "collider %u: local pose is not finite", i);
+        // the shape's local pose (DESIGN.md "Contract / collider pose"); the only trigonometry of the contract, once, on the host
+        const bool local = c.local_pos[0] != 0.0f || c.local_pos[1] != 0.0f || c.local_angle != 0.0f;
+        hl[i] = make_float4(c.local_pos[0], c.local_pos[1], c.local_angle == 0.0f ? 1.0f : cosf(c.local_angle),
+                            c.local_angle == 0.0f ? 0.0f : sinf(c.local_angle));
+        const uint32_t bits = c.type | (c.material << 8) | (local ? 0x80000000u : 0u);
         float4 s = make_float4(0, c.p[0], c.p[1], c.p[2]);
         memcpy(&s.x, &bits, 4);
         if (c.type == SFX_SHAPE_POLY) {
@@ -835,6 +841,7 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     ALLOC(w, w->poly, hpoly.size());
     HIPCHK(w, hipMemcpy(w->poly.p, hpoly.data(), sizeof(float4) * hpoly.size(), hipMemcpyHostToDevice));
     HIPCHK(w, hipMemcpy(w->shape.p, hs.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
+    HIPCHK(w, hipMemcpy(w->lpose.p, hl.data(), sizeof(float4) * n, hipMemcpyHostToDevice));
     w->have_colliders = true;
     resolve_grid(w);
     w->max_pairs = w->cfg.max_pairs ? w->cfg.max_pairs : 12u * n;
@@ -1304,7 +1311,7 @@ int build_query_index(sfx_world* w, const QueryBuffers& Q) {
       hipLaunchKernelGGL(k_zero, dim3(cdiv(n16, kBlock)), dim3(kBlock), 0, w->stream, reinterpret_cast<uint4*>(Q.zero), n16, (uint32_t*)nullptr); }
     HIPCHK(w, hipMemsetAsync(Q.bounds, 0, 4 * sizeof(uint32_t), w->stream));
     { Prof p(w, SFX_K_QUERY, n);
-      hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p, w->poly.p,
+      hipLaunchKernelGGL(k_aabb_count, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->vel.p, w->shape.p, w->lpose.p, w->poly.p,
                          0.0f, 0.0f, 0.0f, g, Q.aabb, Q.bucket, Q.cellxy, qcs, Q.large_tmp, w->large_cap, qctr,
                          (uint4*)nullptr, 0u, (uint32_t*)nullptr, (const float*)nullptr, 0.0f); }
     int rc = scan_u32(w, qcs, w->ncell + 1, Q.cell_fill);

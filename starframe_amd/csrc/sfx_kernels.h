@@ -170,6 +170,7 @@ __global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, const float4* __r
 // ---------------------------------------------------------------- K2 AABB + histogram
 __global__ __launch_bounds__(kBlock) void k_aabb_count(uint32_t n, const float4* __restrict__ pose,
                                                         const float4* __restrict__ vel, const float4* __restrict__ shape,
+                                                        const float4* __restrict__ lpose,
                                                         const float4* __restrict__ poly, float margin, float vel_pad_max,
                                                         float dt, GridParams g, float4* __restrict__ aabb,
                                                         uint32_t* __restrict__ bucket, int2* __restrict__ cellxy,
@@ -188,7 +189,9 @@ __global__ __launch_bounds__(kBlock) void k_aabb_count(uint32_t n, const float4*
     const float4 ps = pose[i];
     // slab worlds: a body that has moved further on x than the halo lists allow for since they were cut (sfx_halo_guard)
     if (guard_x0 && fabsf(ps.x - guard_x0[i]) > guard_limit) atomicOr(&ctr->overflow, kOvfHalo);
-    const float4 A = compute_aabb(ps, vel[i], sh, poly, margin, vel_pad_max, dt);
+    float padx, pady;
+    motion_pads(vel[i], sh, lpose, i, margin, vel_pad_max, dt, padx, pady);
+    const float4 A = compute_aabb(shape_pose(ps, sh, lpose, i), sh, poly, padx, pady);
     aabb[i] = A;
     uint32_t bk = SFX_NO_BUCKET;
     if (shape_type(sh) != SFX_SHAPE_NONE) {
@@ -825,6 +828,7 @@ __device__ __forceinline__ uint32_t batch_local(const BatchRanges& S, uint32_t j
 struct ReachParams {
     const float4* pose;
     const float4* vel;
+    const float4* lpose;
     const float4* poly;
     float margin, vel_pad_max, dt, sm;
 };
@@ -839,8 +843,12 @@ __global__ __launch_bounds__(kBlock) void k_reach(const uint32_t* __restrict__ t
     const uint32_t total = min(tile_start[ntiles], max_pairs);
     for (uint32_t k = blockIdx.x * kBlock + threadIdx.x; k < total; k += gridDim.x * kBlock) {
         const uint4 rp = rawp[k];
-        const bool keep = pair_in_reach(RP.pose[rp.x], shape[rp.x], RP.vel[rp.x], RP.pose[rp.y], shape[rp.y], RP.vel[rp.y],
-                                        RP.poly, RP.margin, RP.vel_pad_max, RP.dt, RP.sm);
+        const float4 sa = shape[rp.x], sb = shape[rp.y];
+        float pax, pay, pbx, pby;
+        motion_pads(RP.vel[rp.x], sa, RP.lpose, rp.x, RP.margin, RP.vel_pad_max, RP.dt, pax, pay);
+        motion_pads(RP.vel[rp.y], sb, RP.lpose, rp.y, RP.margin, RP.vel_pad_max, RP.dt, pbx, pby);
+        const bool keep = pair_in_reach(shape_pose(RP.pose[rp.x], sa, RP.lpose, rp.x), sa, sqrtf(pax * pax + pay * pay),
+                                        shape_pose(RP.pose[rp.y], sb, RP.lpose, rp.y), sb, sqrtf(pbx * pbx + pby * pby), RP.poly, RP.sm);
         if (!keep) rawp[k].z = rp.z | kOutOfReach;
     }
 }
@@ -1422,7 +1430,8 @@ __global__ __launch_bounds__(kBlock, SFX_NARROW_WAVES) void k_narrow(TileArrays 
             a = ab.x; b = ab.y; slot = T.max_pairs + (j - ntp);
         }
         PairRec r;
-        prepare_pair(B.pose[a], B.shape[a], B.vel[a], B.pose[b], B.shape[b], B.vel[b], B.poly, B.mats, sm, r);
+        const float4 pa = B.pose[a], pb = B.pose[b], sa = B.shape[a], sb = B.shape[b];
+        prepare_pair(pa, sa, B.vel[a], pb, sb, B.vel[b], shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, r);
         store_record(C, slot, r);
     }
 }
@@ -2018,7 +2027,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restri
             a = ab.x; b = ab.y; slot = T.max_pairs + (k - ntp);
         }
         Manifold m;
-        manifold(B.pose[a], B.shape[a], B.pose[b], B.shape[b], B.poly, sm, m);
+        manifold(shape_pose(B.pose[a], B.shape[a], B.lpose, a), B.shape[a], shape_pose(B.pose[b], B.shape[b], B.lpose, b), B.shape[b], B.poly, sm, m);
         for (int q = 0; q < m.count; ++q) md = fmaxf(md, m.depth[q]);
         const uint32_t cnt = __float_as_uint(C.rec[4u * (size_t)slot + 3u].y);
         if (cnt) {
@@ -2043,7 +2052,8 @@ __global__ __launch_bounds__(kBlock) void k_contacts_debug(uint32_t np, const ui
     if (k >= np) return;
     const uint2 ab = pairs[k];
     Manifold m;
-    manifold(B.pose[ab.x], B.shape[ab.x], B.pose[ab.y], B.shape[ab.y], B.poly, sm, m);
+    manifold(shape_pose(B.pose[ab.x], B.shape[ab.x], B.lpose, ab.x), B.shape[ab.x], shape_pose(B.pose[ab.y], B.shape[ab.y], B.lpose, ab.y),
+             B.shape[ab.y], B.poly, sm, m);
     sfx_contact c;
     c.body_a = ab.x; c.body_b = ab.y; c.count = (uint32_t)m.count;
     c.normal[0] = m.count ? m.nx : 0.0f; c.normal[1] = m.count ? m.ny : 0.0f;
@@ -2126,7 +2136,7 @@ __global__ __launch_bounds__(kBlock) void k_query_points(uint32_t nq, const floa
         if (!(B.filt[i].x & mask)) return;
         const float4 A = Q.sorted_aabb[slot];
         if (p.x < A.x || p.x > A.z || p.y < A.y || p.y > A.w) return;
-        if (!collider_contains(B.pose[i], B.shape[i], B.poly, p.x, p.y)) return;
+        if (!collider_contains(shape_pose(B.pose[i], B.shape[i], B.lpose, i), B.shape[i], B.poly, p.x, p.y)) return;
         lowest = min(lowest, i);
         ++cnt;
     };
@@ -2203,7 +2213,7 @@ __global__ __launch_bounds__(kBlock) void k_query_rays(uint32_t nq, const float4
             if (!(B.filt[i].x & mask)) return;
             if (!ray_box(Q.sorted_aabb[slot], ray.x, ray.y, ray.z, ray.w, mt)) return;
             float t, nx, ny;
-            if (!collider_ray(B.pose[i], B.shape[i], B.poly, ray.x, ray.y, ray.z, ray.w, t, nx, ny)) return;
+            if (!collider_ray(shape_pose(B.pose[i], B.shape[i], B.lpose, i), B.shape[i], B.poly, ray.x, ray.y, ray.z, ray.w, t, nx, ny)) return;
             if (!(t <= mt)) return;
             if (bbody == SFX_NO_BODY || t < bt || (t == bt && i < bbody)) { bbody = i; bt = t; bnx = nx; bny = ny; }
         };

@@ -41,6 +41,12 @@ class Collider:
     category: int = 1
     mask: int = 0xFFFFFFFF
     group: int = 0
+    offset: tuple = (0.0, 0.0)   # the shape's origin in the body frame (the reference's collider "local offset")
+    local_angle: float = 0.0     # and its rotation there
+
+    def with_offset(self, offset, angle=0.0):
+        from dataclasses import replace
+        return replace(self, offset=tuple(offset), local_angle=float(angle))
 
     @staticmethod
     def circle(r, **kw):
@@ -92,7 +98,7 @@ class Physics:
         if self._world is not None:
             raise RuntimeError("add bodies before the first tick")
         kw = dict(angle=angle, material=self._mat(collider.material), category=collider.category,
-                  mask=collider.mask, group=collider.group)
+                  mask=collider.mask, group=collider.group, local_pos=collider.offset, local_angle=collider.local_angle)
         dens = body.density if body.kind == "dynamic" else 0.0
         dyn = dict(density=dens, vel=velocity, angvel=angular_velocity)
         if collider.kind == "circle":

@@ -90,6 +90,9 @@ class SceneBuilder:
         self.materials = materials or [(0.1, 0.5, 0.4)]
 
     def _add(self, pos, angle, vel, angvel, mass, inertia, col):
+        lp = col[8]
+        if mass > 0 and (lp[0] or lp[1]):   # the shape sits off the body origin: parallel axis theorem
+            inertia = inertia + mass * (lp[0] ** 2 + lp[1] ** 2)
         self.pos.append(pos)
         self.rot.append((np.cos(angle), np.sin(angle)))
         self.vel.append(vel)
@@ -100,8 +103,9 @@ class SceneBuilder:
         return len(self.pos) - 1
 
     @staticmethod
-    def _col(type_, p, material=0, category=1, mask=0xFFFFFFFF, group=0, poly_offset=0, poly_count=0):
-        return (type_, material, category, mask, group, tuple(p), poly_offset, poly_count)
+    def _col(type_, p, material=0, category=1, mask=0xFFFFFFFF, group=0, poly_offset=0, poly_count=0, local_pos=(0.0, 0.0),
+             local_angle=0.0):
+        return (type_, material, category, mask, group, tuple(p), poly_offset, poly_count, tuple(local_pos), local_angle)
 
     def circle(self, pos, r, density=1.0, angle=0.0, vel=(0, 0), angvel=0.0, **kw):
         m = density * np.pi * r * r
@@ -336,7 +340,7 @@ def granular_slab(n=4_000_000, seed=0x5EED0005, width=40000, pitch=0.22, wall_hh
 
 # ------------------------------------------------------------------ small test scenes
 
-def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, speed=1.0):
+def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, speed=1.0, offsets=0.0):
     """Overlapping random shapes of every type with random velocities: a broadphase and
     narrowphase stress scene for parity tests."""
     rng = np.random.default_rng(seed)
@@ -352,6 +356,9 @@ def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, sp
             kw["group"] = int(rng.integers(1, 4))
         if rng.random() < 0.1:
             kw["category"], kw["mask"] = 2, 0xFFFFFFFD
+        if offsets and rng.random() < offsets:   # the shape off the body origin, turned in the body frame
+            kw["local_pos"] = tuple(rng.uniform(-0.15, 0.15, 2))
+            kw["local_angle"] = float(rng.uniform(-np.pi, np.pi)) if rng.random() < 0.7 else 0.0
         if t == 0:
             b.circle(p, rng.uniform(0.05, 0.2), **kw)
         elif t == 1:

@@ -38,6 +38,8 @@ def bounding_radius(scene):
         for i in np.nonzero(t == SHAPE_POLY)[0]:
             o, k = int(c["poly_offset"][i]), int(c["poly_count"][i])
             r[i] = vr[o:o + k].max() + p[i, 2]
+    if "local_pos" in (c.dtype.names or ()):   # a shape off the body origin reaches further from the body's centre
+        r = r + np.sqrt((c["local_pos"].astype(np.float32) ** 2).sum(1))
     return r.astype(np.float32)
 
 
@@ -49,6 +51,9 @@ def x_half_extent(scene):
     e = bounding_radius(scene)
     e = np.where(t == SHAPE_RECT, co * p[:, 0] + si * p[:, 1] + p[:, 2], e)
     e = np.where(t == SHAPE_CAPSULE, co * p[:, 0] + p[:, 2], e)
+    if "local_pos" in (c.dtype.names or ()):
+        off = np.sqrt((c["local_pos"].astype(np.float32) ** 2).sum(1))
+        e = np.where(off > 0, bounding_radius(scene), e)   # turned and shifted: the bounding circle
     return e.astype(np.float32)
 
 

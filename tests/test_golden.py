@@ -25,7 +25,7 @@ def load(path):
 
 
 def test_fixtures_present():
-    assert len(FIXTURES) >= 5
+    assert len(FIXTURES) >= 6
 
 
 @pytest.mark.parametrize("path", FIXTURES, ids=os.path.basename)

@@ -480,3 +480,42 @@ def test_tiny_grid_and_ticket_path_equal_the_default(monkeypatch):
         assert np.array_equal(rot.view(np.uint32), ref[0][1].view(np.uint32))
         assert np.array_equal(vel.view(np.uint32), ref[1][0].view(np.uint32))
         assert np.array_equal(ang.view(np.uint32), ref[1][1].view(np.uint32))
+
+
+def test_colliders_with_a_local_pose_match_oracle():
+    """sfx_collider.local_pos / local_angle (SURVEY.md section 8a row a4 "local offset"): half the shapes of a soup sit off
+    their body's origin, turned in the body frame.  AABBs (with the swing pad), pair set, tiles, colours bit-exact;
+    contacts and five ticks of poses within tolerance; spatial queries see the shapes where they are."""
+    from oracle.oracle import ORDER_COLORED
+    from tests.test_oracle_queries import query_inputs
+
+    s = scenes.random_soup(2000, seed=31, extent=9.0, offsets=0.5)
+    assert (np.abs(s.colliders["local_pos"]).sum(1) > 0).sum() > 800
+    g, o = make_pair(s)
+    g.broadphase(DT)
+    o.broadphase(DT)
+    assert np.array_equal(g.aabbs().view(np.uint32), o.aabbs().view(np.uint32)), "AABBs differ bitwise"
+    assert np.array_equal(g.pairs(), o.pairs())
+    gk, gc, gt = colors_by_key(*g.pair_colors())
+    ok, oc, ot = colors_by_key(*o.pair_colors())
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot) and np.array_equal(gc, oc)
+    gcon, ocon = g.contacts(), o.contacts()
+    assert np.array_equal(gcon["count"], ocon["count"]) and (gcon["count"] > 0).sum() > 300
+    assert rel_err(gcon["normal"], ocon["normal"], floor=1.0) <= TOL
+    assert rel_err(gcon["depth"], ocon["depth"], floor=1e-2) <= TOL
+    assert rel_err(gcon["point_a"], ocon["point_a"], floor=1.0) <= TOL
+    pts, boxes, rays, max_t = query_inputs(31, 9.0, n=500, near=s.pos)
+    gb, gn = g.query_points(pts)
+    ob, on = o.query_points(pts)
+    assert np.array_equal(gb, ob) and np.array_equal(gn, on) and (on > 0).sum() > 50
+    assert np.array_equal(g.query_aabbs(boxes), o.query_aabbs(boxes))
+    gh, oh = g.query_rays(rays, max_t), o.query_rays(rays, max_t)
+    assert np.array_equal(gh["body"], oh["body"])
+    for _ in range(5):
+        g.step(DT)
+        o.step(DT, ORDER_COLORED)
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= TOL
+    assert rel_err(g.poses()[1], o.poses()[1], floor=1.0) <= TOL
+    assert rel_err(g.velocities()[0], o.velocities()[0], floor=1.0) <= 1e-4
+    assert rel_err(g.velocities()[1], o.velocities()[1], floor=10.0) <= 1e-4
+    assert g.stats().overflow == 0

@@ -391,3 +391,77 @@ def test_unclamped_drop_does_not_explode():
     assert w.stats().kinetic_energy < 2.0
     d = contact_depths(w)
     assert np.percentile(d, 99) < 0.03
+
+
+# ---- collider local pose (include/sfx.h sfx_collider.local_pos / local_angle)
+
+def test_offset_circle_contact_is_where_the_shape_is():
+    """A circle 0.3 m off its body's origin, on a body turned by 90 degrees: the shape sits at body + R(90) (0.3, 0) =
+    (0, 0.3) above the body origin; a second circle touching it there gives the closed-form manifold, and the AABB
+    is the shape's."""
+    b = SceneBuilder("off", substeps=1)
+    b.circle((0.0, 0.0), 0.1, angle=math.pi / 2, local_pos=(0.3, 0.0))
+    b.circle((0.0, 0.45), 0.1)
+    w = world(b, gravity=(0.0, 0.0))
+    w.broadphase(DT)
+    A = w.aabbs()
+    np.testing.assert_allclose(A[0], (-0.11, 0.19, 0.11, 0.41), atol=1e-6)     # radius + margin 0.01 around (0, 0.3)
+    c = w.contact_pair(0, 1)
+    assert c["count"] == 1
+    np.testing.assert_allclose(c["normal"], (0.0, 1.0), atol=1e-6)
+    assert c["depth"][0] == pytest.approx(0.05, abs=1e-6)                       # centres 0.15 apart, radii 0.2
+    np.testing.assert_allclose(c["point_a"][0], (0.0, 0.4), atol=1e-6)
+
+
+def test_local_angle_turns_the_shape_in_the_body_frame():
+    """A 2 x 0.2 bar turned by 90 degrees in its body's frame stands upright on an unturned body: it touches a floor
+    1 m below the body origin, which the same bar without local_angle (lying flat) does not."""
+    for local_angle, touches in ((math.pi / 2, True), (0.0, False)):
+        b = SceneBuilder("bar", substeps=1)
+        b.rect((0.0, 0.0), 1.0, 0.1, local_angle=local_angle)
+        b.static_rect((0.0, -1.5), 5.0, 0.52)
+        w = world(b, gravity=(0.0, 0.0))
+        w.broadphase(DT)
+        c = w.contact_pair(0, 1)
+        assert (c["count"] == 2) == touches
+        if touches:
+            np.testing.assert_allclose(c["normal"], (0.0, -1.0), atol=1e-6)
+            np.testing.assert_allclose(c["depth"], (0.02, 0.02), atol=1e-5)
+
+
+def test_off_centre_wheel_swings_like_a_pendulum_about_its_contact():
+    """A disc whose shape is centred 0.1 m beside the body origin (= the centre of mass) stands on the floor with the
+    heavy point sideways: it rocks like a pendulum (rolling without slipping dissipates nothing).  The centre of
+    mass swings below the geometric centre and comes back no higher than it started, the kinetic energy never
+    exceeds the potential energy m g e it can draw on, and the rim stays on the floor: contact anchors about the
+    body origin, shape where it is."""
+    r, e = 0.3, 0.1
+    b = SceneBuilder("wheel", substeps=8, materials=[(0.0, 0.9, 0.8)])
+    b.circle((0.0, r), r, local_pos=(e, 0.0))            # shape centre at (e, r): touching the floor at y = 0
+    b.static_rect((0.0, -0.5), 10.0, 0.5)
+    w = world(b)
+    mass = math.pi * r * r
+    rim, com_y, ke = [], [], []
+    for _ in range(360):
+        w.step(DT, ORDER_SEQUENTIAL)
+        pos, rot = w.poses()
+        rim.append(pos[0, 1] + rot[0, 1] * e - r)          # lowest point of the shape
+        com_y.append(pos[0, 1])
+        ke.append(w.stats().kinetic_energy)
+    assert min(rim) > -5e-3 and max(rim[30:]) < 5e-3       # rolling on the floor, neither sinking nor hopping
+    assert min(com_y) < r - 0.9 * e                        # the centre of mass swings (nearly) under the centre
+    assert max(com_y) < r + 2e-3                           # and never comes back higher than it started
+    assert max(ke) < 1.05 * mass * 9.81 * e and max(ke) > 0.5 * mass * 9.81 * e
+
+
+def test_swinging_offset_shape_widens_its_aabb_pad():
+    """The velocity pad of the AABB covers what the spin adds at the shape's distance from the body origin."""
+    b = SceneBuilder("spin", substeps=1)
+    b.circle((0.0, 0.0), 0.05, angvel=10.0, local_pos=(0.2, 0.0))
+    b.circle((5.0, 0.0), 0.05, angvel=10.0)
+    w = world(b, gravity=(0.0, 0.0), vel_pad_max=1.0)
+    w.broadphase(DT)
+    A = w.aabbs()
+    pad = 10.0 * 0.2 * DT                                  # |omega| |offset| dt
+    np.testing.assert_allclose(A[0], (0.2 - 0.06 - pad, -0.06 - pad, 0.2 + 0.06 + pad, 0.06 + pad), atol=1e-6)
+    np.testing.assert_allclose(A[1], (5.0 - 0.06, -0.06, 5.0 + 0.06, 0.06), atol=1e-6)

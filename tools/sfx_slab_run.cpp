@@ -43,7 +43,7 @@ static bool load(const char* path, Scene& s) {
     FILE* f = fopen(path, "rb");
     if (!f) return false;
     uint32_t hdr[6];
-    bool ok = fread(hdr, 4, 6, f) == 6 && hdr[0] == 0x31584653u && hdr[3] == 0 && hdr[4] == 0;  // no polygons, no joints
+    bool ok = fread(hdr, 4, 6, f) == 6 && hdr[0] == 0x32584653u && hdr[3] == 0 && hdr[4] == 0;  // no polygons, no joints
     if (ok) {
         s.n = hdr[1]; s.n_mat = hdr[2]; s.substeps = hdr[5];
         ok = rd(f, s.pos, 2 * (size_t)s.n) && rd(f, s.rot, 2 * (size_t)s.n) && rd(f, s.vel, 2 * (size_t)s.n) &&
@@ -63,15 +63,17 @@ struct Plan {
 };
 
 static bool dynamic(const Scene& s, uint32_t i) { return s.inv_mass[i] > 0.0f || s.inv_inertia[i] > 0.0f; }
-static float radius(const Scene& s, uint32_t i) {
+static float radius(const Scene& s, uint32_t i) {   // about the body origin: a shape off it reaches further
     const sfx_collider& c = s.col[i];
-    if (c.type == SFX_SHAPE_CIRCLE) return c.p[2];
-    if (c.type == SFX_SHAPE_RECT) return std::sqrt(c.p[0] * c.p[0] + c.p[1] * c.p[1]) + c.p[2];
+    const float off = std::sqrt(c.local_pos[0] * c.local_pos[0] + c.local_pos[1] * c.local_pos[1]);
+    if (c.type == SFX_SHAPE_CIRCLE) return c.p[2] + off;
+    if (c.type == SFX_SHAPE_RECT) return std::sqrt(c.p[0] * c.p[0] + c.p[1] * c.p[1]) + c.p[2] + off;
     return 0.0f;
 }
 static float xext(const Scene& s, uint32_t i) {   // half width of a non-turning rect's box
     const sfx_collider& c = s.col[i];
-    if (c.type == SFX_SHAPE_RECT) return std::fabs(s.rot[2 * i]) * c.p[0] + std::fabs(s.rot[2 * i + 1]) * c.p[1] + c.p[2];
+    if (c.type == SFX_SHAPE_RECT && c.local_pos[0] == 0.0f && c.local_pos[1] == 0.0f && c.local_angle == 0.0f)
+        return std::fabs(s.rot[2 * i]) * c.p[0] + std::fabs(s.rot[2 * i + 1]) * c.p[1] + c.p[2];
     return radius(s, i);
 }
 
