@@ -73,13 +73,14 @@ typedef struct sfx_config {
     uint32_t grid_log2[2];  /* wrapped grid is 2^gx by 2^gy cells; 0 = auto          */
     uint32_t max_pairs;     /* candidate pair capacity; 0 = 12 * bodies              */
     uint32_t color_rounds;  /* parallel colouring rounds before the serial finish; 0 = 12 */
-    uint32_t tile_cells;    /* solver tile width in grid cells: 1, 2, 4 or 8; 0 = 1       */
-    uint32_t tile_cells_y;  /* solver tile height in grid cells, a power of two; anything >= the
+    uint32_t tile_cells;    /* solver tile width in grid cells: 2, 4 or 8; 0 = 2 (a tile is at least two
+                               cells wide and high: DESIGN.md "Tiles, classes, phases")            */
+    uint32_t tile_cells_y;  /* solver tile height in grid cells, a power of two >= 2; anything >= the
                                grid height makes full-height strips: then a sweep has two
-                               phases instead of four.  0 = automatic, decided when the colliders
-                               are uploaded: strips if no two neighbouring tile columns hold more
-                               than 3/4 SFX_TILE_MAX_BODIES colliders at that time (wide, shallow
-                               scenes), else as high as wide                                     */
+                               phases (interior pairs, seam pairs) instead of four.  0 = automatic,
+                               decided when the colliders are uploaded: strips if no two neighbouring
+                               tile columns hold more than 7/8 SFX_TILE_MAX_BODIES colliders at that
+                               time (wide, shallow scenes), else as high as wide                   */
     float restitution_threshold; /* restitution is dropped when |vn_pre| <= this * |g| * h; 0 = 2.0 */
     float max_depenetration_velocity; /* > 0: a contact corrects at most this * h of penetration per
                                substep (m/s).  0 (default) or negative = unlimited, as published:

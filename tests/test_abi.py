@@ -43,6 +43,37 @@ def test_rccl_library_exports_its_header():
         assert hasattr(lib, s), s
 
 
+def test_rust_mirror_declares_every_symbol_and_size():
+    """bindings/rust/src/lib.rs cannot be compiled here (no rustc): its text is held against the headers instead.
+    Every function of sfx.h / sfx_rccl.h is declared, with as many parameters as the header gives it; every struct
+    size the header asserts is asserted there with the same number; every field of every struct appears in order."""
+    rs = open(os.path.join(ROOT, "bindings", "rust", "src", "lib.rs")).read()
+    rs_nc = re.sub(r"//[^\n]*", "", rs)
+    for header in ("sfx.h", "sfx_rccl.h"):
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", header)).read(), flags=re.S)
+        for name, args in re.findall(r"\b(sfx_[a-z_0-9]+)\s*\(([^)]*)\)\s*;", src):
+            m = re.search(r"pub fn %s\(([^)]*)\)" % name, rs_nc)
+            assert m, f"{name} is not declared in the Rust mirror"
+            n_c = 0 if args.strip() in ("", "void") else args.count(",") + 1
+            n_rs = 0 if not m.group(1).strip() else m.group(1).count(",") + 1
+            assert n_c == n_rs, f"{name}: {n_c} parameters in {header}, {n_rs} in lib.rs"
+    src = open(HEADER).read()
+    abi = int(re.search(r"SFX_ABI_VERSION (\d+)u", src).group(1))
+    assert f"SFX_ABI_VERSION: u32 = {abi};" in rs
+    sizes = re.findall(r"SFX_STATIC_ASSERT\(sizeof\((\w+)\) == ([^,]+),", src)
+    assert len(sizes) >= 9
+    for name, expr in sizes:
+        expr = expr.strip()
+        assert f"size_of::<{name}>() == {expr})" in rs, f"size of {name} ({expr}) is not asserted in lib.rs"
+    body = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    for name, fields in re.findall(r"typedef struct (\w+) \{(.*?)\} \1;", body, flags=re.S):
+        m = re.search(r"pub struct %s \{(.*?)\n\}" % name, rs_nc, flags=re.S)
+        assert m, name
+        c_fields = [f for decl in fields.split(";") for f in re.findall(r"(\w+)(?:\[[^\]]*\])*\s*(?:,|$)", decl.strip())]
+        rs_fields = [f.rstrip("_") for f in re.findall(r"pub (\w+):", m.group(1))]
+        assert rs_fields == c_fields, f"{name}: {c_fields} in sfx.h, {rs_fields} in lib.rs"
+
+
 def test_struct_layouts_match_header():
     prog = r"""
 #include <stdio.h>
