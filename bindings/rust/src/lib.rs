@@ -1,5 +1,5 @@
 //! sfx-sys: the thin `extern "C"` FFI crate BASELINE.json:5 asks for, mirroring include/sfx.h and
-//! include/sfx_rccl.h declaration by declaration (ABI 8).
+//! include/sfx_rccl.h declaration by declaration (ABI 9).
 //! UNCOMPILED: no rustc/cargo in the build image and no upstream source to test against; the C and C++
 //! harnesses (tools/sfx_c_tick.c, starframe_amd/cpp, tools/sfx_slab_run.cpp) and ctypes exercise the identical
 //! ABI, and tests/test_abi.py::test_rust_mirror_declares_every_symbol_and_size checks this file's text against
@@ -7,7 +7,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const SFX_ABI_VERSION: u32 = 8;
+pub const SFX_ABI_VERSION: u32 = 9;
 
 // sfx_status
 pub const SFX_OK: c_int = 0;
@@ -92,6 +92,7 @@ pub struct sfx_collider {
     pub poly_count: u32,
     pub local_pos: [f32; 2], // the shape's origin in the body frame
     pub local_angle: f32,    // and its rotation there (radians)
+    pub body: u32,           // colliders beyond the body count: the body this one belongs to
 }
 
 #[repr(C)]
@@ -193,7 +194,7 @@ pub const SFX_RCCL_ID_BYTES: usize = 128;
 
 // The sizes include/sfx.h asserts (SFX_STATIC_ASSERT at its end): a mismatch fails the build of this crate.
 const _: () = assert!(std::mem::size_of::<sfx_config>() == 80);
-const _: () = assert!(std::mem::size_of::<sfx_collider>() == 52);
+const _: () = assert!(std::mem::size_of::<sfx_collider>() == 56);
 const _: () = assert!(std::mem::size_of::<sfx_material>() == 12);
 const _: () = assert!(std::mem::size_of::<sfx_distance_constraint>() == 40);
 const _: () = assert!(std::mem::size_of::<sfx_angle_constraint>() == 24);

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 8u
+#define SFX_ABI_VERSION 9u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -98,11 +98,16 @@ typedef struct sfx_config {
 #define SFX_CFG_NO_FRICTION 2u   /* skip static + dynamic friction (debug)          */
 
 /* collider component (BASELINE.json:5 "body/collider/material components"; SURVEY.md section 8a row a4: shape,
- * local offset, layer mask).  Collider k belongs to body k (one collider per body).  The shape sits at a LOCAL
- * POSE in the body's frame: local_pos (metres) and local_angle (radians); both 0 = centred on the body origin.
- * Mass and inertia are the body's (the caller's: a shape off the centre of mass has the inertia of the parallel
- * axis theorem); AABB, narrowphase and queries use the shape where it is, contact anchors are taken about the
- * body origin. */
+ * local offset, layer mask).  The shape sits at a LOCAL POSE in the body's frame: local_pos (metres) and
+ * local_angle (radians); both 0 = centred on the body origin.  Mass and inertia are the body's (the caller's: a
+ * shape off the centre of mass has the inertia of the parallel axis theorem); AABB, narrowphase and queries use
+ * the shape where it is, contact anchors are taken about the body origin.
+ * SEVERAL COLLIDERS PER BODY: sfx_upload_colliders takes n >= body count colliders.  Collider k < bodies is the
+ * first collider of body k (SFX_SHAPE_NONE: none; its `body` field is ignored); every collider k >= bodies is a
+ * further collider of body colliders[k].body.  Colliders of one body never collide with each other.  The further
+ * colliders of a non-dynamic body (level geometry) cost what any static collider costs; those of a DYNAMIC body are
+ * solved on the fallback list (one workgroup, global memory): meant for a few compound bodies, not for thousands
+ * (DESIGN.md "Several colliders per body"). */
 typedef struct sfx_collider {
     uint32_t type;      /* sfx_shape_type                                   */
     uint32_t material;  /* index into the material table                    */
@@ -114,6 +119,7 @@ typedef struct sfx_collider {
     uint32_t poly_count;  /* vertex count (SFX_SHAPE_POLY)                  */
     float local_pos[2];   /* shape origin in the body frame                 */
     float local_angle;    /* shape rotation in the body frame (radians)     */
+    uint32_t body;        /* colliders beyond the body count: the body this one belongs to */
 } sfx_collider;
 
 typedef struct sfx_material {
@@ -229,7 +235,8 @@ void sfx_default_config(sfx_config* cfg);
 int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* rot,
                       const float* vel, const float* angvel, const float* inv_mass,
                       const float* inv_inertia);
-/* n must equal the body count.  poly_verts is the [n_poly_verts][2] vertex pool. */
+/* n >= the body count (see sfx_collider: the first `bodies` colliders are the bodies' own, the rest name their
+ * body); bodies + further colliders <= 16 M.  poly_verts is the [n_poly_verts][2] vertex pool. */
 int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* colliders,
                          const float* poly_verts, uint32_t n_poly_verts);
 int sfx_upload_materials(sfx_world* w, uint32_t n, const sfx_material* materials);
@@ -382,7 +389,7 @@ const char* sfx_last_error(sfx_world* w); /* w may be NULL: last create error */
 #define SFX_STATIC_ASSERT(cond, msg) _Static_assert(cond, msg)
 #endif
 SFX_STATIC_ASSERT(sizeof(sfx_config) == 80, "sfx_config");
-SFX_STATIC_ASSERT(sizeof(sfx_collider) == 52, "sfx_collider");
+SFX_STATIC_ASSERT(sizeof(sfx_collider) == 56, "sfx_collider");
 SFX_STATIC_ASSERT(sizeof(sfx_material) == 12, "sfx_material");
 SFX_STATIC_ASSERT(sizeof(sfx_distance_constraint) == 40, "sfx_distance_constraint");
 SFX_STATIC_ASSERT(sizeof(sfx_angle_constraint) == 24, "sfx_angle_constraint");

@@ -171,7 +171,7 @@ class OracleWorld(WorldBase):
         self._check(self.lib.sfo_broadphase(self.handle, dt))
 
     def aabbs(self):
-        out = np.empty((self.n, 4), np.float32)
+        out = np.empty((self.nc, 4), np.float32)   # one box per collider
         self.lib.sfo_aabbs(self.handle, fptr(out))
         return out
 

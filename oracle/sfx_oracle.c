@@ -49,7 +49,11 @@ struct sfo_world {
     sfx_config cfg;
     float cell, inv_cell;
     uint32_t gxl, gyl;
-    uint32_t n;
+    /* [DESIGN] DESIGN.md "Contract / several colliders per body".  n counts ENTRIES: the nb bodies (entry k < nb is
+     * body k with its first collider), then one entry per further collider.  Every per-entry array below has n
+     * elements; an entry e >= nb MIRRORS the pose and velocity of its body cbody[e] (mirror_entries) and has no mass. */
+    uint32_t n, nb;
+    uint32_t* cbody; /* [n] the body an entry belongs to; identity for e < nb */
     float *pos, *rot, *vel, *angvel, *inv_mass, *inv_inertia, *prev_pos, *prev_rot;
     sfx_collider* col;
     float* lrot;   /* (cos, sin) of every collider's local_angle, computed once at upload */
@@ -124,6 +128,7 @@ void sfo_destroy(sfo_world* w) {
     free(w->poly_nrm); free(w->mats); free(w->joints); free(w->angles); free(w->joint_perm); free(w->joint_color);
     free(w->aabb); free(w->pa); free(w->pb); free(w->color); free(w->order); free(w->rec);
     free(w->ccx); free(w->ccy); free(w->is_small); free(w->owner); free(w->pclass); free(w->batch_end);
+    free(w->cbody);
     free(w);
 }
 
@@ -133,22 +138,69 @@ static float* dupf(const float* src, size_t n) {
     return p;
 }
 
+/* entries beyond the bodies take the pose and the velocity of their body (and never a mass): after an upload, after
+ * every integration (+ joints), at the end of every substep */
+static void mirror_entries(sfo_world* w) {
+    for (uint32_t e = w->nb; e < w->n; ++e) {
+        uint32_t b = w->cbody[e];
+        w->pos[2 * e] = w->pos[2 * b]; w->pos[2 * e + 1] = w->pos[2 * b + 1];
+        w->rot[2 * e] = w->rot[2 * b]; w->rot[2 * e + 1] = w->rot[2 * b + 1];
+        w->vel[2 * e] = w->vel[2 * b]; w->vel[2 * e + 1] = w->vel[2 * b + 1];
+        w->angvel[e] = w->angvel[b];
+    }
+}
+
+static float* growf(float* p, size_t n_old, size_t n_new) {
+    float* q = (float*)realloc(p, (n_new ? n_new : 1) * sizeof(float));
+    if (q && n_new > n_old) memset(q + n_old, 0, (n_new - n_old) * sizeof(float));
+    return q;
+}
+
+/* the per-entry arrays get n_new elements; the bodies' part is kept */
+static void resize_entries(sfo_world* w, uint32_t n_new) {
+    uint32_t n_old = w->n;
+    w->pos = growf(w->pos, 2u * n_old, 2u * n_new); w->rot = growf(w->rot, 2u * n_old, 2u * n_new);
+    w->vel = growf(w->vel, 2u * n_old, 2u * n_new); w->angvel = growf(w->angvel, n_old, n_new);
+    w->inv_mass = growf(w->inv_mass, n_old, n_new); w->inv_inertia = growf(w->inv_inertia, n_old, n_new);
+    w->prev_pos = growf(w->prev_pos, 2u * n_old, 2u * n_new); w->prev_rot = growf(w->prev_rot, 2u * n_old, 2u * n_new);
+    w->cbody = (uint32_t*)realloc(w->cbody, (n_new ? n_new : 1) * sizeof(uint32_t));
+    for (uint32_t e = w->nb; e < n_new; ++e) { w->inv_mass[e] = 0.0f; w->inv_inertia[e] = 0.0f; }
+    w->n = n_new;
+}
+
 int sfo_upload_bodies(sfo_world* w, uint32_t n, const float* pos, const float* rot,
                       const float* vel, const float* angvel, const float* inv_mass,
                       const float* inv_inertia) {
+    if (w->col && n == w->nb) { /* same bodies, new state: colliders (and their entries) stay */
+        memcpy(w->pos, pos, 2u * n * sizeof(float)); memcpy(w->rot, rot, 2u * n * sizeof(float));
+        memcpy(w->vel, vel, 2u * n * sizeof(float)); memcpy(w->angvel, angvel, n * sizeof(float));
+        memcpy(w->inv_mass, inv_mass, n * sizeof(float)); memcpy(w->inv_inertia, inv_inertia, n * sizeof(float));
+        memcpy(w->prev_pos, pos, 2u * n * sizeof(float)); memcpy(w->prev_rot, rot, 2u * n * sizeof(float));
+        mirror_entries(w);
+        return SFX_OK;
+    }
     free(w->pos); free(w->rot); free(w->vel); free(w->angvel); free(w->inv_mass);
-    free(w->inv_inertia); free(w->prev_pos); free(w->prev_rot);
-    w->n = n;
+    free(w->inv_inertia); free(w->prev_pos); free(w->prev_rot); free(w->cbody);
+    free(w->col); w->col = NULL; /* another body count: the colliders are uploaded again */
+    w->n = w->nb = n;
     w->pos = dupf(pos, 2u * n); w->rot = dupf(rot, 2u * n); w->vel = dupf(vel, 2u * n);
     w->angvel = dupf(angvel, n); w->inv_mass = dupf(inv_mass, n);
     w->inv_inertia = dupf(inv_inertia, n);
     w->prev_pos = dupf(pos, 2u * n); w->prev_rot = dupf(rot, 2u * n);
+    w->cbody = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
+    for (uint32_t i = 0; i < n; ++i) w->cbody[i] = i;
     return SFX_OK;
 }
 
 static int is_dynamic(const sfo_world* w, uint32_t i) {
     return w->inv_mass[i] > 0.0f || w->inv_inertia[i] > 0.0f;
 }
+
+/* of an entry: is the body it belongs to dynamic (an entry beyond the bodies has no mass of its own) */
+static int owner_dynamic(const sfo_world* w, uint32_t e) { return is_dynamic(w, w->cbody[e]); }
+
+/* a further collider of a DYNAMIC body: its pairs go to the fallback list (solved on the body, not on the entry) */
+static int dynamic_secondary(const sfo_world* w, uint32_t e) { return e >= w->nb && owner_dynamic(w, e); }
 
 /* [DESIGN] bounding diameter of a shape, used only for the automatic cell size */
 static float shape_diameter(const sfo_world* w, const sfx_collider* c) {
@@ -189,7 +241,7 @@ static void resolve_grid(sfo_world* w) {
     if (!(cell > 0.0f)) {
         float dmax = 0.0f;
         for (uint32_t i = 0; i < w->n; ++i) {
-            if (!is_dynamic(w, i) || w->col[i].type == SFX_SHAPE_NONE) continue;
+            if (!owner_dynamic(w, i) || w->col[i].type == SFX_SHAPE_NONE) continue;
             float d = shape_diameter(w, &w->col[i]);
             if (d > dmax) dmax = d;
         }
@@ -209,7 +261,7 @@ static void resolve_grid(sfo_world* w) {
          * shorter side grows) and at most four times as many (the longer side shrinks). */
         float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
         for (uint32_t i = 0; i < w->n; ++i) {
-            if (!is_dynamic(w, i) || w->col[i].type == SFX_SHAPE_NONE) continue;
+            if (!owner_dynamic(w, i) || w->col[i].type == SFX_SHAPE_NONE) continue;
             float x = w->pos[2 * i], y = w->pos[2 * i + 1];
             if (x < xmin) xmin = x;
             if (x > xmax) xmax = x;
@@ -264,7 +316,13 @@ static void resolve_grid(sfo_world* w) {
 
 int sfo_upload_colliders(sfo_world* w, uint32_t n, const sfx_collider* colliders,
                          const float* poly_verts, uint32_t n_poly_verts) {
-    if (n != w->n) return SFX_ERR_INVALID;
+    /* collider k < nb is body k's first; a collider k >= nb belongs to colliders[k].body */
+    if (n < w->nb) return SFX_ERR_INVALID;
+    for (uint32_t k = w->nb; k < n; ++k)
+        if (colliders[k].body >= w->nb) return SFX_ERR_INVALID;
+    resize_entries(w, n);
+    for (uint32_t k = 0; k < n; ++k) w->cbody[k] = k < w->nb ? k : colliders[k].body;
+    mirror_entries(w);
     free(w->col); free(w->poly); free(w->poly_nrm); free(w->lrot);
     w->col = (sfx_collider*)malloc((n ? n : 1) * sizeof(sfx_collider));
     memcpy(w->col, colliders, n * sizeof(sfx_collider));
@@ -488,7 +546,7 @@ static int rebuild_joints(sfo_world* w) {
     return ovf ? SFX_ERR_CAPACITY : SFX_OK;
 }
 
-static int body_ok(const sfo_world* w, uint32_t b) { return b == SFX_WORLD_BODY || b < w->n; }
+static int body_ok(const sfo_world* w, uint32_t b) { return b == SFX_WORLD_BODY || b < w->nb; }
 
 int sfo_upload_constraints(sfo_world* w, uint32_t m, const sfx_distance_constraint* c) {
     for (uint32_t k = 0; k < m; ++k) {
@@ -599,7 +657,8 @@ static void compute_aabb(const sfo_world* w, uint32_t i, float dt, float* out) {
 }
 
 static int pair_filter(const sfo_world* w, uint32_t i, uint32_t j) {
-    if (!is_dynamic(w, i) && !is_dynamic(w, j)) return 0;
+    if (!owner_dynamic(w, i) && !owner_dynamic(w, j)) return 0;
+    if (w->cbody[i] == w->cbody[j]) return 0; /* two colliders of one body */
     const sfx_collider *a = &w->col[i], *b = &w->col[j];
     if (!(a->category & b->mask) || !(b->category & a->mask)) return 0;
     if (a->group != 0 && a->group == b->group) return 0;
@@ -855,7 +914,8 @@ static void build_order(sfo_world* w, float frame_dt) {
         uint32_t a = w->pa[e], b = w->pb[e], own = SFO_FALLBACK;
         int32_t txa = tile_coord(w->ccx[a], w->tlx), tya = tile_coord(w->ccy[a], w->tly);
         int32_t txb = tile_coord(w->ccx[b], w->tlx), tyb = tile_coord(w->ccy[b], w->tly);
-        if (w->is_small[a] && w->is_small[b]) own = wrapped_tile(w, txa < txb ? txa : txb, tya < tyb ? tya : tyb);
+        if (dynamic_secondary(w, a) || dynamic_secondary(w, b)) own = SFO_FALLBACK;
+        else if (w->is_small[a] && w->is_small[b]) own = wrapped_tile(w, txa < txb ? txa : txb, tya < tyb ? tya : tyb);
         else if (w->is_small[a] && !dyn[b]) own = wrapped_tile(w, txa, tya);
         else if (w->is_small[b] && !dyn[a]) own = wrapped_tile(w, txb, tyb);
         w->owner[e] = own;
@@ -896,6 +956,11 @@ static void build_order(sfo_world* w, float frame_dt) {
     w->n_colors = 0; w->n_leftover = 0; w->n_batches = 0; w->n_order = 0;
     uint32_t ovf = 0;
     uint32_t* kept = (uint32_t*)malloc((np ? np : 1) * sizeof(uint32_t));
+    /* the colouring's conflicts are between BODIES (the ends of an edge are the bodies its two colliders belong to);
+     * its keys stay the pair's two collider ids, unique per edge */
+    uint32_t* ba = (uint32_t*)malloc((np ? np : 1) * sizeof(uint32_t));
+    uint32_t* bb = (uint32_t*)malloc((np ? np : 1) * sizeof(uint32_t));
+    for (uint32_t e = 0; e < np; ++e) { ba[e] = w->cbody[w->pa[e]]; bb[e] = w->cbody[w->pb[e]]; }
     /* batches: phase by phase, inside a phase tile by tile (independent of each other), the
      * fallback list last; inside a batch colour-major */
     for (uint32_t ph = 0; ph <= 4; ++ph) {
@@ -917,7 +982,7 @@ static void build_order(sfo_world* w, float frame_dt) {
                 idx = kept; cnt = nk;
                 if (!cnt) continue;
             }
-            uint32_t nc = color_edges(&cs, cnt, idx, w->pa, w->pb, w->pa, w->pb, dyn, w->cfg.color_rounds,
+            uint32_t nc = color_edges(&cs, cnt, idx, ba, bb, w->pa, w->pb, dyn, w->cfg.color_rounds,
                                       w->color, &w->n_leftover, &ovf);
             if (nc > w->n_colors) w->n_colors = nc;
             for (uint32_t c = 0; c < nc; ++c)
@@ -933,6 +998,7 @@ static void build_order(sfo_world* w, float frame_dt) {
     w->order_valid = 1;
     w->n_solver_pairs = w->n_order;
     free(tbodies); free(tcnt); free(tover); free(dyn); free(tstart); free(bytile); free(fill); free(kept);
+    free(ba); free(bb);
 }
 
 static void broadphase_core(sfo_world* w, float frame_dt) {
@@ -1283,7 +1349,7 @@ static void rotate_by(float* c, float* s, float dth) {
 static void integrate(sfo_world* w, float h) {
     float gx = w->cfg.gravity[0], gy = w->cfg.gravity[1];
     float dl = 1.0f / (1.0f + h * w->cfg.linear_damping), da = 1.0f / (1.0f + h * w->cfg.angular_damping);
-    for (uint32_t i = 0; i < w->n; ++i) {
+    for (uint32_t i = 0; i < w->nb; ++i) {
         w->prev_pos[2 * i] = w->pos[2 * i]; w->prev_pos[2 * i + 1] = w->pos[2 * i + 1];
         w->prev_rot[2 * i] = w->rot[2 * i]; w->prev_rot[2 * i + 1] = w->rot[2 * i + 1];
         if (w->inv_mass[i] > 0.0f) {
@@ -1303,7 +1369,7 @@ static void integrate(sfo_world* w, float h) {
 
 /* [XPBD-RB] Alg. 2 lines 12-16; omega is the exact inverse of rotate_by: tan(dtheta)/h */
 static void derive_velocities(sfo_world* w, float inv_h) {
-    for (uint32_t i = 0; i < w->n; ++i) {
+    for (uint32_t i = 0; i < w->nb; ++i) {
         if (!is_dynamic(w, i)) continue;
         w->vel[2 * i] = (w->pos[2 * i] - w->prev_pos[2 * i]) * inv_h;
         w->vel[2 * i + 1] = (w->pos[2 * i + 1] - w->prev_pos[2 * i + 1]) * inv_h;
@@ -1750,8 +1816,11 @@ int sfo_tick_substep(sfo_world* w) {
      * first, at the poses the substep's integration (and the joints) left -- Mueller et al. 2020
      * Alg. 2 "collect collision pairs" per substep -- then the solves run in the chosen order */
     uint32_t n_ord = nbatch ? w->batch_end[nbatch - 1] : 0;
+    /* the manifolds are taken between COLLIDERS (entries, which mirror their bodies), the solves act on the BODIES */
+    mirror_entries(w);
     for (uint32_t k = 0; k < n_ord; ++k) prepare_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]]);
-    for (uint32_t k = 0; k < n_ord; ++k) solve_pos_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]], max_corr);
+    for (uint32_t k = 0; k < n_ord; ++k)
+        solve_pos_pair(w, w->cbody[w->pa[w->order[k]]], w->cbody[w->pb[w->order[k]]], &w->rec[w->order[k]], max_corr);
     derive_velocities(w, inv_h);
     for (uint32_t k = 0; k < w->m; ++k) { /* joint damping, in the joints' solve order */
         uint32_t jk = order == SFO_ORDER_SEQUENTIAL ? k : w->joint_perm[k];
@@ -1763,10 +1832,11 @@ int sfo_tick_substep(sfo_world* w) {
         uint32_t k1 = w->batch_end[bt];
         for (uint32_t k = k0; k < k1; ++k) {
             uint32_t e = w->order[k];
-            if (w->rec[e].count) solve_vel_pair(w, w->pa[e], w->pb[e], &w->rec[e], h, inv_h);
+            if (w->rec[e].count) solve_vel_pair(w, w->cbody[w->pa[e]], w->cbody[w->pb[e]], &w->rec[e], h, inv_h);
         }
         k0 = k1;
     }
+    mirror_entries(w);
     /* stats of the last substep, measured on the records */
     uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
     w->n_contacts = 0; w->max_depth = 0.0f; w->n_manifolds = 0; w->n_manifolds2 = 0;
@@ -1790,7 +1860,7 @@ int sfo_step(sfo_world* w, float frame_dt, int order) {
 int sfo_halo_get(const sfo_world* w, const uint32_t* idx, uint32_t n, float* out) {
     for (uint32_t k = 0; k < n; ++k) {
         uint32_t i = idx[k];
-        if (i >= w->n) return SFX_ERR_INVALID;
+        if (i >= w->nb) return SFX_ERR_INVALID;
         out[8 * k] = w->pos[2 * i]; out[8 * k + 1] = w->pos[2 * i + 1];
         out[8 * k + 2] = w->rot[2 * i]; out[8 * k + 3] = w->rot[2 * i + 1];
         out[8 * k + 4] = w->vel[2 * i]; out[8 * k + 5] = w->vel[2 * i + 1];
@@ -1802,30 +1872,31 @@ int sfo_halo_get(const sfo_world* w, const uint32_t* idx, uint32_t n, float* out
 int sfo_halo_put(sfo_world* w, const uint32_t* idx, uint32_t n, const float* in) {
     for (uint32_t k = 0; k < n; ++k) {
         uint32_t i = idx[k];
-        if (i >= w->n) return SFX_ERR_INVALID;
+        if (i >= w->nb) return SFX_ERR_INVALID;
         w->pos[2 * i] = in[8 * k]; w->pos[2 * i + 1] = in[8 * k + 1];
         w->rot[2 * i] = in[8 * k + 2]; w->rot[2 * i + 1] = in[8 * k + 3];
         w->vel[2 * i] = in[8 * k + 4]; w->vel[2 * i + 1] = in[8 * k + 5];
         w->angvel[i] = in[8 * k + 6];
     }
+    mirror_entries(w);
     return SFX_OK;
 }
 
 int sfo_download_poses(const sfo_world* w, float* pos, float* rot) {
-    if (pos) memcpy(pos, w->pos, 2u * w->n * sizeof(float));
-    if (rot) memcpy(rot, w->rot, 2u * w->n * sizeof(float));
+    if (pos) memcpy(pos, w->pos, 2u * w->nb * sizeof(float));
+    if (rot) memcpy(rot, w->rot, 2u * w->nb * sizeof(float));
     return SFX_OK;
 }
 
 int sfo_download_velocities(const sfo_world* w, float* vel, float* angvel) {
-    if (vel) memcpy(vel, w->vel, 2u * w->n * sizeof(float));
-    if (angvel) memcpy(angvel, w->angvel, w->n * sizeof(float));
+    if (vel) memcpy(vel, w->vel, 2u * w->nb * sizeof(float));
+    if (angvel) memcpy(angvel, w->angvel, w->nb * sizeof(float));
     return SFX_OK;
 }
 
 int sfo_stats(const sfo_world* w, sfx_frame_stats* out) {
     memset(out, 0, sizeof(*out));
-    out->n_bodies = w->n; out->n_small = w->n_small; out->n_large = w->n_large;
+    out->n_bodies = w->nb; out->n_small = w->n_small; out->n_large = w->n_large;
     out->n_pairs = w->n_pairs; out->n_colors = w->n_colors; out->n_leftover = w->n_leftover;
     out->n_contacts = w->n_contacts; out->n_manifolds = w->n_manifolds; out->n_manifolds2 = w->n_manifolds2;
     out->n_joint_colors = w->n_joint_colors;
@@ -1844,7 +1915,7 @@ int sfo_stats(const sfo_world* w, sfx_frame_stats* out) {
     }
     out->max_depth = md;
     double ke = 0.0;
-    for (uint32_t i = 0; i < w->n; ++i) {
+    for (uint32_t i = 0; i < w->nb; ++i) {
         if (w->inv_mass[i] > 0.0f)
             ke += 0.5 * (1.0 / w->inv_mass[i]) * ((double)w->vel[2 * i] * w->vel[2 * i] + (double)w->vel[2 * i + 1] * w->vel[2 * i + 1]);
         if (w->inv_inertia[i] > 0.0f)
@@ -2019,7 +2090,7 @@ static void ray_try(const sfo_world* w, const qindex* q, uint32_t i, uint32_t ma
         if (!(t <= max_t)) return;
     }
     if (best->body == SFX_NO_BODY || t < best->t || (t == best->t && i < best->body)) {
-        best->body = i; best->t = t; best->nx = nx; best->ny = ny;
+        best->body = i; best->t = t; best->nx = nx; best->ny = ny; /* the collider; its body is reported */
     }
 }
 
@@ -2066,7 +2137,7 @@ int sfo_query_points(const sfo_world* w, uint32_t n, const float* points, uint32
                 }
             for (uint32_t l = 0; l < q.nl; ++l) point_try(w, &q, q.large[l], mask, px, py, &lowest, &cnt);
         }
-        body[k] = lowest;
+        body[k] = lowest == SFX_NO_BODY ? lowest : w->cbody[lowest]; /* the body of the lowest collider id */
         if (count) count[k] = cnt;
     }
     qindex_free(&q);
@@ -2083,7 +2154,7 @@ size_t sfo_query_aabbs(const sfo_world* w, uint32_t n, const float* boxes, uint3
 #define BOX_TRY(i)                                                                              \
     do {                                                                                        \
         if ((w->col[(i)].category & mask) && aabb_overlap(B, &q.box[4 * (i)])) {                \
-            if (nh < cap) hits[nh] = ((uint64_t)k << 32) | (i);                                 \
+            if (nh < cap) hits[nh] = ((uint64_t)k << 32) | w->cbody[(i)];                       \
             ++nh;                                                                               \
         }                                                                                       \
     } while (0)
@@ -2116,6 +2187,12 @@ size_t sfo_query_aabbs(const sfo_world* w, uint32_t n, const float* boxes, uint3
 #undef BOX_TRY
     qsort(hits, nh < cap ? nh : cap, sizeof(uint64_t), cmp_u64);
     qindex_free(&q);
+    if (nh <= cap && w->n > w->nb) { /* a body is named once per query, however many of its colliders the box meets */
+        size_t m = 0;
+        for (size_t h = 0; h < nh; ++h)
+            if (m == 0 || hits[h] != hits[m - 1]) hits[m++] = hits[h];
+        nh = m;
+    }
     return nh;
 }
 
@@ -2171,7 +2248,7 @@ int sfo_query_rays(const sfo_world* w, uint32_t n, const float* rays, const floa
                 }
             }
         }
-        out[k].body = best.body; out[k].t = best.t; out[k].normal[0] = best.nx; out[k].normal[1] = best.ny;
+        out[k].body = best.body == SFX_NO_BODY ? best.body : w->cbody[best.body]; out[k].t = best.t; out[k].normal[0] = best.nx; out[k].normal[1] = best.ny;
     }
     qindex_free(&q);
     return SFX_OK;

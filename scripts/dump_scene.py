@@ -9,7 +9,8 @@ def dump(s, path):
     f32 = lambda a: np.ascontiguousarray(a, np.float32)
     pv = f32(s.poly_verts).reshape(-1, 2)
     with open(path, "wb") as f:
-        np.array([0x32584653, s.n, len(s.materials), pv.shape[0], len(s.constraints), s.substeps], np.uint32).tofile(f)
+        assert len(s.colliders) == s.n, "scene files hold one collider per body"
+        np.array([0x33584653, s.n, len(s.materials), pv.shape[0], len(s.constraints), s.substeps], np.uint32).tofile(f)
         for a in (s.pos, s.rot, s.vel, s.angvel, s.inv_mass, s.inv_inertia):
             f32(a).tofile(f)
         np.ascontiguousarray(s.colliders).tofile(f)

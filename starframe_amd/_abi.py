@@ -98,6 +98,7 @@ collider_dtype = np.dtype(
         ("poly_count", "<u4"),
         ("local_pos", "<f4", (2,)),
         ("local_angle", "<f4"),
+        ("body", "<u4"),
     ]
 )
 material_dtype = np.dtype([("restitution", "<f4"), ("static_friction", "<f4"), ("dynamic_friction", "<f4")])
@@ -134,7 +135,7 @@ contact_dtype = np.dtype(
         ("point_b", "<f4", (2, 2)),
     ]
 )
-assert collider_dtype.itemsize == 52
+assert collider_dtype.itemsize == 56
 assert material_dtype.itemsize == 12
 assert constraint_dtype.itemsize == 40
 assert angle_constraint_dtype.itemsize == 24

@@ -155,6 +155,25 @@ public:
         dirty_ = true;
         return k;
     }
+    // A further collider on a body that has one (a compound body; include/sfx.h sfx_collider.body).  density > 0
+    // (dynamic bodies): the shape's mass and inertia -- parallel axis about the body origin, which is taken to stay
+    // the centre of mass -- are added to the body's.
+    void add_collider(BodyKey body, const Collider& collider, float density = 0.0f) {
+        sfx_collider c = collider.raw_;
+        c.material = material_index(collider.material_);
+        c.body = body;
+        if (c.type == SFX_SHAPE_POLY) {
+            c.poly_offset = (uint32_t)(poly_.size() / 2); c.poly_count = (uint32_t)collider.verts_.size();
+            for (const Vec2& v : collider.verts_) { poly_.push_back(v.x); poly_.push_back(v.y); }
+        }
+        further_.push_back(c);
+        if (density > 0.0f && inv_mass_[body] > 0.0f) {
+            const float m = density * collider.area(), i = m * (collider.unit_inertia() + collider.offset2());
+            inv_mass_[body] = 1.0f / (1.0f / inv_mass_[body] + m);
+            if (inv_inertia_[body] > 0.0f) inv_inertia_[body] = 1.0f / (1.0f / inv_inertia_[body] + i);
+        }
+        dirty_ = true;
+    }
     BodyKey add_particle(const Body& body, const Pose& pose) { Collider none; none.raw_.type = SFX_SHAPE_NONE; return add(body, none, pose); }
 
     // distance constraint between body-local anchors (world position for WORLD)
@@ -281,7 +300,9 @@ private:
         if (mats_.empty()) material_index(PhysicsMaterial());
         check(sfx_upload_bodies(world_, n, pos_.data(), rot_.data(), vel_.data(), angvel_.data(), inv_mass_.data(), inv_inertia_.data()), "sfx_upload_bodies");
         check(sfx_upload_materials(world_, (uint32_t)mats_.size(), mats_.data()), "sfx_upload_materials");
-        check(sfx_upload_colliders(world_, n, colliders_.data(), poly_.data(), (uint32_t)(poly_.size() / 2)), "sfx_upload_colliders");
+        std::vector<sfx_collider> all(colliders_);   // the bodies' own colliders, then the further ones
+        all.insert(all.end(), further_.begin(), further_.end());
+        check(sfx_upload_colliders(world_, (uint32_t)all.size(), all.data(), poly_.data(), (uint32_t)(poly_.size() / 2)), "sfx_upload_colliders");
         check(sfx_upload_constraints(world_, (uint32_t)joints_.size(), joints_.data()), "sfx_upload_constraints");
         check(sfx_upload_angle_constraints(world_, (uint32_t)angles_.size(), angles_.data()), "sfx_upload_angle_constraints");
         old_count_ = n; dirty_ = false; ticked_ = true;
@@ -292,7 +313,7 @@ private:
     bool dirty_ = true, ticked_ = false;
     size_t old_count_ = 0;
     std::vector<float> pos_, rot_, vel_, angvel_, inv_mass_, inv_inertia_, poly_;
-    std::vector<sfx_collider> colliders_;
+    std::vector<sfx_collider> colliders_, further_;
     std::vector<sfx_material> mats_;
     std::vector<sfx_distance_constraint> joints_;
     std::vector<sfx_angle_constraint> angles_;

@@ -39,7 +39,19 @@ struct BodyArrays {
     const uint4* filt;
     const float4* poly;  // (vx, vy, nx, ny) per pool vertex
     const float4* mats;  // (restitution, mu_s, mu_d, 0)
+    // Several colliders per body (DESIGN.md "Contract / several colliders per body"): every array above has one element
+    // per ENTRY -- the nb bodies first (entry k < nb = body k with its own collider), then one entry per further
+    // collider, which MIRRORS the pose and velocity of its body (k_mirror) and has no mass.
+    const uint32_t* cbody;  // [entries - nb] body of entry nb + k
+    uint32_t nb;
 };
+
+// the body an entry belongs to (solves write bodies, never mirrors)
+__device__ __forceinline__ uint32_t body_of(const BodyArrays& B, uint32_t e) { return e < B.nb ? e : B.cbody[e - B.nb]; }
+
+// filt.w: bit 0 the entry's body is dynamic; bit 1 a further collider of a dynamic body (its pairs go to the fallback
+// list: they are solved on the body, through body_of); bits 8.. the body id (colliders of one body never pair)
+constexpr uint32_t kFiltDynamic = 1u, kFiltFurther = 2u;
 
 // shape.x bits: type (8) | material (23) << 8 | has a local pose << 31
 __device__ __forceinline__ uint32_t shape_type(const float4& s) { return __float_as_uint(s.x) & 0xFFu; }
@@ -179,7 +191,8 @@ __device__ __forceinline__ bool pair_in_reach(const float4& pa, const float4& sa
 }
 
 __device__ __forceinline__ bool pair_filter(const uint4& a, const uint4& b) {
-    if (!(a.w | b.w)) return false;
+    if (!((a.w | b.w) & kFiltDynamic)) return false;
+    if ((a.w >> 8) == (b.w >> 8)) return false;   // two colliders of one body
     if (!(a.x & b.y) || !(b.x & a.y)) return false;
     if (a.z != 0 && a.z == b.z) return false;
     return true;

@@ -77,9 +77,13 @@ struct sfx_world {
     float cell = 1.0f, inv_cell = 1.0f;
     uint32_t gxl = 2, gyl = 2, ncell = 16, max_pairs = 0;
     // scene
-    uint32_t n = 0, m = 0, n_mats = 0, n_poly = 0;
+    // n counts ENTRIES: the nb bodies (entry k < nb = body k with its own collider), then one entry per further collider
+    // (include/sfx.h sfx_collider.body); every per-entry device array has n elements, the host vectors below nb
+    uint32_t n = 0, nb = 0, m = 0, n_mats = 0, n_poly = 0;
     bool have_bodies = false, have_colliders = false, have_mats = false;
     std::vector<float> h_inv_mass, h_inv_inertia, h_pos_x, h_pos_y;
+    std::vector<uint32_t> h_cbody;     // body of entry nb + k
+    DevBuf<uint32_t> cbody;
     std::vector<sfx_collider> h_col;
     std::vector<float> h_poly;
     DevBuf<float4> pose, prev, vel, shape, lpose, poly, mats, aabb, sorted_aabb;
@@ -257,7 +261,9 @@ float shape_diameter(const sfx_world* w, const sfx_collider& c) {
     }
 }
 
-bool is_dynamic(const sfx_world* w, uint32_t i) { return w->h_inv_mass[i] > 0.0f || w->h_inv_inertia[i] > 0.0f; }
+// the body an entry belongs to; is that body dynamic (an entry beyond the bodies has no mass of its own)
+uint32_t owner(const sfx_world* w, uint32_t e) { return e < w->nb ? e : w->h_cbody[e - w->nb]; }
+bool is_dynamic(const sfx_world* w, uint32_t e) { const uint32_t i = owner(w, e); return w->h_inv_mass[i] > 0.0f || w->h_inv_inertia[i] > 0.0f; }
 
 // DESIGN.md "Contract / grid": identical rule in oracle/sfx_oracle.c
 void resolve_grid(sfx_world* w) {
@@ -285,7 +291,7 @@ void resolve_grid(sfx_world* w) {
         float xmin = INFINITY, xmax = -INFINITY, ymin = INFINITY, ymax = -INFINITY;
         for (uint32_t i = 0; i < w->n; ++i) {
             if (!is_dynamic(w, i) || w->h_col[i].type == SFX_SHAPE_NONE) continue;
-            const float x = w->h_pos_x[i], y = w->h_pos_y[i];
+            const float x = w->h_pos_x[owner(w, i)], y = w->h_pos_y[owner(w, i)];
             if (x < xmin) xmin = x;
             if (x > xmax) xmax = x;
             if (y < ymin) ymin = y;
@@ -319,7 +325,7 @@ void resolve_grid(sfx_world* w) {
         std::vector<uint32_t> cnt(ncol, 0u);
         for (uint32_t i = 0; i < w->n; ++i) {
             if (w->h_col[i].type == SFX_SHAPE_NONE) continue;
-            float f = floorf(w->h_pos_x[i] * w->inv_cell);
+            float f = floorf(w->h_pos_x[owner(w, i)] * w->inv_cell);
             if (!(f > -1073741824.0f)) f = -1073741824.0f;
             if (f > 1073741824.0f) f = 1073741824.0f;
             const int32_t cx = (int32_t)f;
@@ -391,6 +397,7 @@ BodyArrays body_arrays(sfx_world* w) {
     BodyArrays B;
     B.pose = w->pose.p; B.prev = w->prev.p; B.vel = w->vel.p; B.mass = w->mass.p;
     B.shape = w->shape.p; B.lpose = w->lpose.p; B.filt = w->filt.p; B.poly = w->poly.p; B.mats = w->mats.p;
+    B.cbody = w->cbody.p; B.nb = w->nb;
     return B;
 }
 
@@ -448,6 +455,7 @@ void color_global(sfx_world* w, const uint2* edges, const uint32_t* n_edges, uin
                   uint2* sorted, uint32_t* start, uint32_t* n_colors_out, Counters* ctr, int tick_totals) {
     GlobalColor A;
     A.edges = edges; A.n_edges = n_edges; A.cap = cap; A.key_by_index = key_by_index;
+    A.ends_are_colliders = key_by_index ? 0 : 1;   // joints name bodies, the fallback list colliders
     A.filt = w->filt.p; A.used = w->used.p; A.claim = w->claim.p;
     A.color = w->pcolor.p; A.prop = w->prop.p; A.left_list = w->left_list.p;
     A.sorted = sorted; A.start = start; A.n_colors_out = n_colors_out;
@@ -569,6 +577,48 @@ int ready(sfx_world* w) {
     if (!w->have_bodies || !w->have_colliders || !w->have_mats)
         return fail(w, SFX_ERR_INVALID, "bodies, colliders and materials must be uploaded before this call");
     return SFX_OK;
+}
+
+// every per-entry device array at n_entries elements (contents undefined afterwards)
+int alloc_entries(sfx_world* w, uint32_t n_entries) {
+    const uint32_t n = n_entries;
+    w->n = n;
+    w->n_halo_send = w->n_halo_recv = 0;   // the halo lists and the guard's snapshot index the old entries
+    w->halo_guard = 0.0f;
+    const size_t c = std::max(n, 1u);
+    ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
+    ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->lpose, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
+    ALLOC(w, w->bucket, c); ALLOC(w, w->tmp_id, c); ALLOC(w, w->sorted_id, c); ALLOC(w, w->large_tmp, c);
+    ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->slot_off, 2 * ((size_t)n + 1)); ALLOC(w, w->hit_tmp, kHitTmp * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
+    ALLOC(w, w->used, c); ALLOC(w, w->claim, c * kClaim);
+    ALLOC(w, w->cbody, std::max<size_t>(n - w->nb, 1));
+    w->large_cap = n;
+    return SFX_OK;
+}
+
+// the bodies' state (nb elements each) to the device; the entries beyond the bodies mirror their bodies, without mass
+int write_state(sfx_world* w, std::vector<float4>& hp, std::vector<float4>& hv, std::vector<float2>& hm) {
+    const uint32_t n = w->n;
+    hp.resize(std::max(n, 1u)); hv.resize(std::max(n, 1u)); hm.resize(std::max(n, 1u));
+    for (uint32_t e = w->nb; e < n; ++e) {
+        const uint32_t b = w->h_cbody[e - w->nb];
+        hp[e] = hp[b]; hv[e] = hv[b]; hm[e] = make_float2(0.0f, 0.0f);
+    }
+    HIPCHK(w, hipMemcpyAsync(w->pose.p, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipMemcpyAsync(w->prev.p, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipMemcpyAsync(w->vel.p, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipMemcpyAsync(w->mass.p, hm.data(), sizeof(float2) * n, hipMemcpyHostToDevice, w->stream));
+    if (n > w->nb) HIPCHK(w, hipMemcpyAsync(w->cbody.p, w->h_cbody.data(), sizeof(uint32_t) * (n - w->nb), hipMemcpyHostToDevice, w->stream));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    return SFX_OK;
+}
+
+// further colliders take the pose and velocity of their bodies (k_mirror)
+void mirror_entries(sfx_world* w) {
+    if (w->n <= w->nb) return;
+    const uint32_t nsec = w->n - w->nb;
+    Prof p(w, SFX_K_INTEGRATE, nsec);
+    hipLaunchKernelGGL(k_mirror, dim3(cdiv(nsec, kBlock)), dim3(kBlock), 0, w->stream, nsec, w->nb, w->cbody.p, w->pose.p, w->vel.p);
 }
 
 int sync_counters(sfx_world* w, Counters* out, const Counters* dev) {
@@ -726,7 +776,8 @@ static int rebuild_filt(sfx_world* w) {
     if (!w->have_bodies) return SFX_OK;
     std::vector<uint4> f(std::max(w->n, 1u));
     for (uint32_t i = 0; i < w->n; ++i) {
-        uint4 v = make_uint4(0, 0, 0, is_dynamic(w, i) ? 1u : 0u);
+        const bool dyn = is_dynamic(w, i);
+        uint4 v = make_uint4(0, 0, 0, (dyn ? kFiltDynamic : 0u) | ((dyn && i >= w->nb) ? kFiltFurther : 0u) | (owner(w, i) << 8));
         if (w->have_colliders) { v.x = w->h_col[i].category; v.y = w->h_col[i].mask; v.z = w->h_col[i].group; }
         f[i] = v;
     }
@@ -742,22 +793,16 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
     if (n > (1u << 24)) return fail(w, SFX_ERR_UNSUPPORTED, "more than 16M bodies per world");
     HIPCHK(w, hipSetDevice(w->device));
     HIPCHK(w, hipStreamSynchronize(w->stream));
-    const bool resize = !w->have_bodies || n != w->n;
-    if (resize) {
-        w->n = n;
+    const bool resize = !w->have_bodies || n != w->nb;
+    if (resize) {   // another body count: colliders (and the further colliders' entries), joints and halo lists go
+        w->nb = n;
+        w->h_cbody.clear();
         w->have_colliders = false;
         w->m = 0;
         w->h_dist.clear(); w->h_angle.clear(); w->joint_damped = false;
         w->joint_perm.clear(); w->joint_color_sorted.clear(); w->joint_color_start.assign(1, 0);
-        w->n_halo_send = w->n_halo_recv = 0;   // the halo lists index the old bodies
-        w->halo_guard = 0.0f;
-        const size_t c = std::max(n, 1u);
-        ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
-        ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->lpose, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
-        ALLOC(w, w->bucket, c); ALLOC(w, w->tmp_id, c); ALLOC(w, w->sorted_id, c); ALLOC(w, w->large_tmp, c);
-        ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->slot_off, 2 * ((size_t)n + 1)); ALLOC(w, w->hit_tmp, kHitTmp * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
-        ALLOC(w, w->used, c); ALLOC(w, w->claim, c * kClaim);
-        w->large_cap = n;
+        int rc = alloc_entries(w, n);
+        if (rc) return rc;
     }
     std::vector<float4> hp(std::max(n, 1u)), hv(std::max(n, 1u));
     std::vector<float2> hm(std::max(n, 1u));
@@ -770,11 +815,8 @@ int sfx_upload_bodies(sfx_world* w, uint32_t n, const float* pos, const float* r
         hv[i] = make_float4(vel[2 * i], vel[2 * i + 1], angvel[i], 0.0f);
         hm[i] = make_float2(inv_mass[i], inv_inertia[i]);
     }
-    HIPCHK(w, hipMemcpyAsync(w->pose.p, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
-    HIPCHK(w, hipMemcpyAsync(w->prev.p, hp.data(), sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
-    HIPCHK(w, hipMemcpyAsync(w->vel.p, hv.data(), sizeof(float4) * n, hipMemcpyHostToDevice, w->stream));
-    HIPCHK(w, hipMemcpyAsync(w->mass.p, hm.data(), sizeof(float2) * n, hipMemcpyHostToDevice, w->stream));
-    HIPCHK(w, hipStreamSynchronize(w->stream));
+    int rc = write_state(w, hp, hv, hm);
+    if (rc) return rc;
     w->have_bodies = true;
     w->ticked = false;
     w->q_valid = false;
@@ -800,10 +842,25 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
                          uint32_t n_poly_verts) {
     if (!w || (n && !col)) return fail(w, SFX_ERR_INVALID, "null argument");
     if (!w->have_bodies) return fail(w, SFX_ERR_INVALID, "upload bodies before colliders");
-    if (n != w->n) return fail(w, SFX_ERR_UNSUPPORTED, "collider count %u != body count %u (one collider per body)", n, w->n);
+    if (n < w->nb) return fail(w, SFX_ERR_INVALID, "collider count %u < body count %u (collider k < bodies is body k's own: SFX_SHAPE_NONE for none)", n, w->nb);
+    if (n > (1u << 24)) return fail(w, SFX_ERR_UNSUPPORTED, "more than 16M bodies + further colliders per world");
+    for (uint32_t k = w->nb; k < n; ++k)
+        if (col[k].body >= w->nb) return fail(w, SFX_ERR_INVALID, "collider %u: body %u out of range", k, col[k].body);
     if (n_poly_verts && !poly_verts) return fail(w, SFX_ERR_INVALID, "null vertex pool");
     HIPCHK(w, hipSetDevice(w->device));
     HIPCHK(w, hipStreamSynchronize(w->stream));
+    {   // entries: the bodies, then the further colliders; the bodies' state is carried over when their number changes
+        std::vector<float4> hp(std::max(w->nb, 1u)), hv(std::max(w->nb, 1u));
+        std::vector<float2> hm(std::max(w->nb, 1u));
+        HIPCHK(w, hipMemcpy(hp.data(), w->pose.p, sizeof(float4) * w->nb, hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(hv.data(), w->vel.p, sizeof(float4) * w->nb, hipMemcpyDeviceToHost));
+        HIPCHK(w, hipMemcpy(hm.data(), w->mass.p, sizeof(float2) * w->nb, hipMemcpyDeviceToHost));
+        w->h_cbody.resize(n - w->nb);
+        for (uint32_t k = w->nb; k < n; ++k) w->h_cbody[k - w->nb] = col[k].body;
+        if (n != w->n) { int rc = alloc_entries(w, n); if (rc) return rc; }
+        int rc = write_state(w, hp, hv, hm);
+        if (rc) return rc;
+    }
     w->h_col.assign(col, col + n);
     w->h_poly.assign(poly_verts, poly_verts + 2 * (size_t)n_poly_verts);
     w->n_poly = n_poly_verts;
@@ -965,7 +1022,7 @@ int constraints_ready(sfx_world* w, uint32_t m, const void* c) {
     return SFX_OK;
 }
 
-bool body_ok(const sfx_world* w, uint32_t b) { return b == SFX_WORLD_BODY || b < w->n; }
+bool body_ok(const sfx_world* w, uint32_t b) { return b == SFX_WORLD_BODY || b < w->nb; }
 
 }  // namespace
 
@@ -1045,7 +1102,7 @@ int sfx_tick_substep(sfx_world* w) {
     if (!w) return SFX_ERR_INVALID;
     if (!w->tick_open) return fail(w, SFX_ERR_INVALID, "sfx_tick_substep without sfx_tick_begin");
     HIPCHK(w, hipSetDevice(w->device));
-    const uint32_t n = w->n;
+
     const StepParams sp = w->sp;
     w->q_valid = false;
     const BodyArrays B = body_arrays(w);
@@ -1056,10 +1113,10 @@ int sfx_tick_substep(sfx_world* w) {
     // asynchronously); the kernels loop over the batch tables, so any grid size is correct
     const TileArrays T = tile_arrays(w);
     const GridParams g = grid_params(w);
-    const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
+    const uint32_t gb = cdiv(std::max(w->nb, 1u), kBlock);   // integration and derive walk the bodies
     const uint32_t njc = (uint32_t)w->joint_color_start.size() - 1;
-    { Prof p(w, SFX_K_INTEGRATE, n);
-      hipLaunchKernelGGL(k_integrate, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
+    { Prof p(w, SFX_K_INTEGRATE, w->nb);
+      hipLaunchKernelGGL(k_integrate, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
     for (uint32_t jc = 0; jc < njc; ++jc) {
         const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
         if (!cnt) continue;
@@ -1097,6 +1154,7 @@ int sfx_tick_substep(sfx_world* w) {
         else if (tvv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
         else hipLaunchKernelGGL(k_tile_vel<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
     };
+    mirror_entries(w);   // the narrowphase reads colliders (entries), the solves write bodies
     {   // manifolds of all solver pairs at the poses integration and joints left (one pair per lane)
         const uint32_t est = w->ctr_valid ? w->stale.n_pairs : w->max_pairs;
         Prof p(w, SFX_K_NARROW, w->ctr_valid ? w->stale.n_kept : 0);
@@ -1114,8 +1172,8 @@ int sfx_tick_substep(sfx_world* w) {
             launch_pos(w->tile_grid[ph], ph, 1u, 0u, (ph + 1 == nph ? kTileFallback : 0) | kTileStaticFirst);
         }
     }
-    { Prof p(w, SFX_K_DERIVE_VEL, n);
-      hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, n, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
+    { Prof p(w, SFX_K_DERIVE_VEL, w->nb);
+      hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
     for (uint32_t jc = 0; w->joint_damped && jc < njc; ++jc) {
         const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
         if (!cnt) continue;
@@ -1133,6 +1191,7 @@ int sfx_tick_substep(sfx_world* w) {
     }
     HIPCHK(w, hipGetLastError());
     if (++w->substeps_done >= w->cfg.substeps) {
+        mirror_entries(w);   // between ticks the entries are where their bodies are (queries, AABBs, debug hooks)
         // end of the tick: start the asynchronous read-back of its counters
         w->tick_open = false;
         static const uint32_t every = [] { const char* e = getenv("SFX_CTR_EVERY"); return e ? (uint32_t)std::max(1, atoi(e)) : 8u; }();
@@ -1180,9 +1239,9 @@ int sfx_halo_set(sfx_world* w, const uint32_t* send_idx, uint32_t n_send, const 
     if (!w || (n_send && !send_idx) || (n_recv && !recv_idx)) return fail(w, SFX_ERR_INVALID, "null argument");
     if (!w->have_bodies) return fail(w, SFX_ERR_INVALID, "upload bodies before the halo lists");
     for (uint32_t k = 0; k < n_send; ++k)
-        if (send_idx[k] >= w->n) return fail(w, SFX_ERR_INVALID, "halo send index %u out of range", send_idx[k]);
+        if (send_idx[k] >= w->nb) return fail(w, SFX_ERR_INVALID, "halo send index %u out of range", send_idx[k]);
     for (uint32_t k = 0; k < n_recv; ++k)
-        if (recv_idx[k] >= w->n) return fail(w, SFX_ERR_INVALID, "halo receive index %u out of range", recv_idx[k]);
+        if (recv_idx[k] >= w->nb) return fail(w, SFX_ERR_INVALID, "halo receive index %u out of range", recv_idx[k]);
     HIPCHK(w, hipSetDevice(w->device));
     HIPCHK(w, hipStreamSynchronize(w->stream));
     ALLOC(w, w->halo_send_idx, n_send); ALLOC(w, w->halo_recv_idx, n_recv);
@@ -1427,8 +1486,15 @@ int sfx_query_aabbs(sfx_world* w, uint32_t n, const float* boxes, uint32_t mask,
     const size_t got = std::min<size_t>(total, dcap);
     if (e == hipSuccess && got) e = hipMemcpy(hits, d_hits, sizeof(uint64_t) * got, hipMemcpyDeviceToHost);
     if (e != hipSuccess) return fail(w, SFX_ERR_DEVICE, "box query failed: %s", hipGetErrorString(e));
-    std::sort(hits, hits + got);
-    *n_hits = total;
+    size_t kept = got;
+    if (w->n > w->nb && total <= dcap) {   // the kernel names colliders: their bodies, each once per query
+        for (size_t h = 0; h < got; ++h) hits[h] = (hits[h] & 0xFFFFFFFF00000000ull) | owner(w, (uint32_t)hits[h]);
+        std::sort(hits, hits + got);
+        kept = (size_t)(std::unique(hits, hits + got) - hits);
+    } else {
+        std::sort(hits, hits + got);
+    }
+    *n_hits = total > dcap ? total : kept;
     if (w->profiling) { rc = collect_profile(w); if (rc) return rc; }
     if (total > dcap) return fail(w, SFX_ERR_CAPACITY, "box query found %u hits, room for %zu", total, cap);
     return SFX_OK;
@@ -1529,10 +1595,10 @@ int sfx_sync(sfx_world* w) {
 int sfx_download_poses(sfx_world* w, float* pos, float* rot) {
     if (!w || !w->have_bodies) return fail(w, SFX_ERR_INVALID, "no bodies");
     HIPCHK(w, hipSetDevice(w->device));
-    std::vector<float4> hp(std::max(w->n, 1u));
-    HIPCHK(w, hipMemcpyAsync(hp.data(), w->pose.p, sizeof(float4) * w->n, hipMemcpyDeviceToHost, w->stream));
+    std::vector<float4> hp(std::max(w->nb, 1u));
+    HIPCHK(w, hipMemcpyAsync(hp.data(), w->pose.p, sizeof(float4) * w->nb, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(w, hipStreamSynchronize(w->stream));
-    for (uint32_t i = 0; i < w->n; ++i) {
+    for (uint32_t i = 0; i < w->nb; ++i) {
         if (pos) { pos[2 * i] = hp[i].x; pos[2 * i + 1] = hp[i].y; }
         if (rot) { rot[2 * i] = hp[i].z; rot[2 * i + 1] = hp[i].w; }
     }
@@ -1552,24 +1618,24 @@ int sfx_readback_begin(sfx_world* w) {
             HIPCHK(w, hipEventCreateWithFlags(&w->rb_done[k], hipEventDisableTiming));
         }
     }
-    if (w->rb_cap < w->n) {   // first use, or more bodies than before: nothing is in flight in a slot that is free
+    if (w->rb_cap < w->nb) {   // first use, or more bodies than before: nothing is in flight in a slot that is free
         if (w->rb_head != w->rb_tail) return fail(w, SFX_ERR_INVALID, "the body count grew while a read-back is in flight");
         for (int k = 0; k < 2; ++k) {
             if (w->rb_host[k]) { HIPCHK(w, hipHostFree(w->rb_host[k])); w->rb_host[k] = nullptr; }
-            ALLOC(w, w->rb_dev[k], w->n);
-            HIPCHK(w, hipHostMalloc((void**)&w->rb_host[k], sizeof(float4) * w->n, hipHostMallocDefault));
+            ALLOC(w, w->rb_dev[k], w->nb);
+            HIPCHK(w, hipHostMalloc((void**)&w->rb_host[k], sizeof(float4) * w->nb, hipHostMallocDefault));
         }
-        w->rb_cap = w->n;
+        w->rb_cap = w->nb;
     }
     const int k = (int)(w->rb_head & 1u);
-    const size_t bytes = sizeof(float4) * w->n;
+    const size_t bytes = sizeof(float4) * w->nb;
     // snapshot in stream order (the next tick may overwrite the poses), then the transfer on its own stream
     HIPCHK(w, hipMemcpyAsync(w->rb_dev[k].p, w->pose.p, bytes, hipMemcpyDeviceToDevice, w->stream));
     HIPCHK(w, hipEventRecord(w->rb_snap[k], w->stream));
     HIPCHK(w, hipStreamWaitEvent(w->rb_stream, w->rb_snap[k], 0));
     HIPCHK(w, hipMemcpyAsync(w->rb_host[k], w->rb_dev[k].p, bytes, hipMemcpyDeviceToHost, w->rb_stream));
     HIPCHK(w, hipEventRecord(w->rb_done[k], w->rb_stream));
-    w->rb_count[k] = w->n;
+    w->rb_count[k] = w->nb;
     w->rb_head++;
     return SFX_OK;
 }
@@ -1589,10 +1655,10 @@ int sfx_readback_wait(sfx_world* w, const float** poses, uint32_t* n) {
 int sfx_download_velocities(sfx_world* w, float* vel, float* angvel) {
     if (!w || !w->have_bodies) return fail(w, SFX_ERR_INVALID, "no bodies");
     HIPCHK(w, hipSetDevice(w->device));
-    std::vector<float4> hv(std::max(w->n, 1u));
-    HIPCHK(w, hipMemcpyAsync(hv.data(), w->vel.p, sizeof(float4) * w->n, hipMemcpyDeviceToHost, w->stream));
+    std::vector<float4> hv(std::max(w->nb, 1u));
+    HIPCHK(w, hipMemcpyAsync(hv.data(), w->vel.p, sizeof(float4) * w->nb, hipMemcpyDeviceToHost, w->stream));
     HIPCHK(w, hipStreamSynchronize(w->stream));
-    for (uint32_t i = 0; i < w->n; ++i) {
+    for (uint32_t i = 0; i < w->nb; ++i) {
         if (vel) { vel[2 * i] = hv[i].x; vel[2 * i + 1] = hv[i].y; }
         if (angvel) angvel[i] = hv[i].z;
     }
@@ -1716,7 +1782,7 @@ int sfx_debug_joint_order(sfx_world* w, uint32_t* perm, uint8_t* colors, size_t 
 int sfx_stats(sfx_world* w, sfx_frame_stats* out) {
     if (!w || !out) return SFX_ERR_INVALID;
     memset(out, 0, sizeof(*out));
-    out->n_bodies = w->n;
+    out->n_bodies = w->nb;
     out->n_joint_colors = (uint32_t)w->joint_color_start.size() - 1;
     out->launches = w->launches;
     if (!w->have_bodies || !w->have_colliders || !w->ticked) return SFX_OK;

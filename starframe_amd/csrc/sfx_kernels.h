@@ -167,6 +167,17 @@ __global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, const float4* __r
     vel[i] = v;
 }
 
+// Further colliders (entries nb .. n) take the pose and velocity of their bodies: before every narrowphase and at the
+// end of a tick (AABBs, queries and debug read entries; only the solves go through body_of)
+__global__ __launch_bounds__(kBlock) void k_mirror(uint32_t nsec, uint32_t nb, const uint32_t* __restrict__ cbody,
+                                                    float4* __restrict__ pose, float4* __restrict__ vel) {
+    const uint32_t k = blockIdx.x * kBlock + threadIdx.x;
+    if (k >= nsec) return;
+    const uint32_t b = cbody[k];
+    pose[nb + k] = pose[b];
+    vel[nb + k] = vel[b];
+}
+
 // ---------------------------------------------------------------- K2 AABB + histogram
 __global__ __launch_bounds__(kBlock) void k_aabb_count(uint32_t n, const float4* __restrict__ pose,
                                                         const float4* __restrict__ vel, const float4* __restrict__ shape,
@@ -561,7 +572,8 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                     j = sorted_id[q];
                     const uint4 fj = filt[j];
                     hit = pair_filter(fi, fj);
-                    if (r == 5 && small_slot && fj.w != 0u) st = 2;  // small against a large dynamic collider
+                    if (r == 5 && small_slot && (fj.w & kFiltDynamic)) st = 2;  // small against a large dynamic collider
+                    if ((fi.w | fj.w) & kFiltFurther) st = 2;  // a further collider of a dynamic body: solved on the body
                 }
             }
 #pragma unroll
@@ -951,7 +963,7 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
             const uint32_t nb = min(S.off[4u * c], MB), np_all = min(s_poff[c], MP);
             for (uint32_t l = tid; l < nb; l += kBlock) {
                 const uint32_t gid = sorted_id[batch_slot(S, 4u * c, l)];
-                s_dyn[l] = (uint8_t)(filt[gid].w != 0u);
+                s_dyn[l] = (uint8_t)(filt[gid].w & kFiltDynamic);
                 s_mark[l] = 0u;
                 s_used[l] = 0ull;
 #pragma unroll
@@ -1198,7 +1210,8 @@ struct GlobalColor {
     const uint32_t* n_edges;       // device-side count
     uint32_t cap;                  // list capacity (count is clamped to it)
     int key_by_index;              // joints: keyed by edge index, pairs: by (a, b)
-    const uint4* filt;             // .w = dynamic
+    const uint4* filt;             // .w = kFiltDynamic | ... | body << 8
+    int ends_are_colliders;        // the fallback list: an edge's ends are colliders, the conflicts are between their bodies
     unsigned long long* used;      // [n_bodies]
     unsigned long long* claim;     // [n_bodies][kClaim]
     uint8_t* color;                // [cap] out
@@ -1241,9 +1254,15 @@ __global__ __launch_bounds__(kGlobalColorBlock) void k_color_global(GlobalColor 
         if (tid == 0 && A.n_colors_out) *A.n_colors_out = 0u;
         return;
     }
-#define GDYN(x) ((x) != SFX_WORLD_BODY && A.filt[(x)].w != 0u)
+#define GDYN(x) ((x) != SFX_WORLD_BODY && (A.filt[(x)].w & kFiltDynamic))
+    // the ends of an edge as bodies: what the colours must keep apart (the keys stay the list's own ids)
+    auto ends = [&](uint32_t e) {
+        uint2 ab = A.edges[e];
+        if (A.ends_are_colliders) { ab.x = A.filt[ab.x].w >> 8; ab.y = A.filt[ab.y].w >> 8; }
+        return ab;
+    };
     for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {
-        const uint2 ab = A.edges[e];
+        const uint2 ab = ends(e);
         A.color[e] = SFX_NO_COLOR;
         if (GDYN(ab.x)) { A.used[ab.x] = 0ull; for (int k = 0; k < kClaim; ++k) A.claim[(size_t)ab.x * kClaim + k] = ~0ull; }
         if (GDYN(ab.y)) { A.used[ab.y] = 0ull; for (int k = 0; k < kClaim; ++k) A.claim[(size_t)ab.y * kClaim + k] = ~0ull; }
@@ -1252,11 +1271,11 @@ __global__ __launch_bounds__(kGlobalColorBlock) void k_color_global(GlobalColor 
     for (uint32_t r = 0; r < A.rounds; ++r) {
         for (uint32_t e = tid; e < ne; e += kGlobalColorBlock) {  // propose
             if (A.color[e] != SFX_NO_COLOR) continue;
-            const uint2 ab = A.edges[e];
+            const uint2 ab = ends(e), kk = A.edges[e];
             const bool da = GDYN(ab.x), db = GDYN(ab.y);
             const unsigned long long freem = ~((da ? A.used[ab.x] : 0ull) | (db ? A.used[ab.y] : 0ull));
             if (freem == 0ull) { A.prop[e] = SFX_NO_COLOR; atomicOr(&A.ctr->overflow, kOvfColors); continue; }
-            const uint32_t ku = A.key_by_index ? (e >> 24) : ab.x, kv = A.key_by_index ? (e & 0xFFFFFFu) : ab.y;
+            const uint32_t ku = A.key_by_index ? (e >> 24) : kk.x, kv = A.key_by_index ? (e & 0xFFFFFFu) : kk.y;
             const uint32_t c = (uint32_t)__builtin_ctzll(freem);  // first fit
             const uint32_t h = edge_hash(ku, kv, r);
             A.prop[e] = (uint8_t)c;
@@ -1269,9 +1288,9 @@ __global__ __launch_bounds__(kGlobalColorBlock) void k_color_global(GlobalColor 
             if (A.color[e] != SFX_NO_COLOR) continue;
             const uint32_t c = A.prop[e];
             if (c == SFX_NO_COLOR) continue;
-            const uint2 ab = A.edges[e];
+            const uint2 ab = ends(e), kk = A.edges[e];
             const bool da = GDYN(ab.x), db = GDYN(ab.y);
-            const uint32_t ku = A.key_by_index ? (e >> 24) : ab.x, kv = A.key_by_index ? (e & 0xFFFFFFu) : ab.y;
+            const uint32_t ku = A.key_by_index ? (e >> 24) : kk.x, kv = A.key_by_index ? (e & 0xFFFFFFu) : kk.y;
             const uint32_t h = edge_hash(ku, kv, r);
             const unsigned long long p = edge_prio(ku, kv, r, h);
             const bool win = (!da || A.claim[(size_t)ab.x * kClaim + (c & (kClaim - 1u))] == p) &&
@@ -1314,7 +1333,7 @@ __global__ __launch_bounds__(kGlobalColorBlock) void k_color_global(GlobalColor 
         if (tid == 0) {
             for (uint32_t q = 0; q < nleft; ++q) {
                 const uint32_t e = s_srt[q];
-                const uint2 ab = A.edges[e];
+                const uint2 ab = ends(e);
                 const bool da = GDYN(ab.x), db = GDYN(ab.y);
                 const unsigned long long freem = ~((da ? A.used[ab.x] : 0ull) | (db ? A.used[ab.y] : 0ull));
                 if (freem == 0ull) { atomicOr(&A.ctr->overflow, kOvfColors); continue; }
@@ -1446,10 +1465,11 @@ __device__ __forceinline__ void fallback_pos(const TileArrays& T, const Counters
     for (uint32_t c = 0; c < nc; ++c) {
         const uint32_t s = ctr->fb_start[c], e = ctr->fb_start[c + 1];
         for (uint32_t k = s + threadIdx.x; k < e; k += blockDim.x) {
-            const uint2 ab = T.fsorted[k];
+            uint2 ab = T.fsorted[k];
             PairRec r;
             load_record(C, T.max_pairs + k, r);
             if (r.count == 0) continue;
+            ab.x = body_of(B, ab.x); ab.y = body_of(B, ab.y);   // the list names colliders, the solve moves their bodies
             float4 pa = B.pose[ab.x], pb = B.pose[ab.y];
             const float2 wa = B.mass[ab.x], wb = B.mass[ab.y];
             const bool moved = solve_pos_rec(r, pa, wa, pb, wb, max_corr);
@@ -1471,10 +1491,11 @@ __device__ __forceinline__ void fallback_vel(const TileArrays& T, const Counters
     for (uint32_t c = 0; c < nc; ++c) {
         const uint32_t s = ctr->fb_start[c], e = ctr->fb_start[c + 1];
         for (uint32_t k = s + threadIdx.x; k < e; k += blockDim.x) {
-            const uint2 ab = T.fsorted[k];
+            uint2 ab = T.fsorted[k];
             PairRec r;
             load_record(C, T.max_pairs + k, r);
             if (r.count == 0) continue;
+            ab.x = body_of(B, ab.x); ab.y = body_of(B, ab.y);
             float4 pa = B.pose[ab.x], pb = B.pose[ab.y];
             float4 va = B.vel[ab.x], vb = B.vel[ab.y];
             const float2 wa = B.mass[ab.x], wb = B.mass[ab.y];
@@ -2152,7 +2173,7 @@ __global__ __launch_bounds__(kBlock) void k_query_points(uint32_t nq, const floa
             }
     }
     for (uint32_t l = 0; l < nl; ++l) try_slot(ns + l);
-    body[k] = lowest;
+    body[k] = lowest == SFX_NO_BODY ? lowest : body_of(B, lowest);   // the body of the lowest collider id
     if (count) count[k] = cnt;
 }
 
@@ -2253,7 +2274,7 @@ __global__ __launch_bounds__(kBlock) void k_query_rays(uint32_t nq, const float4
         }
     }
     sfx_ray_hit h;
-    h.body = bbody; h.t = bt; h.normal[0] = bnx; h.normal[1] = bny;
+    h.body = bbody == SFX_NO_BODY ? bbody : body_of(B, bbody); h.t = bt; h.normal[0] = bnx; h.normal[1] = bny;
     out[k] = h;
 }
 

@@ -111,6 +111,18 @@ class Physics:
             return self._b.poly(position, collider.verts, rounding=collider.r, **dyn, **kw)
         raise ValueError(collider.kind)
 
+    def add_collider(self, body_id, collider, density=None):
+        """A further collider on a body that has one (a compound body; include/sfx.h sfx_collider.body).  With a
+        density (dynamic bodies) the shape's mass and inertia are added to the body's; the body origin is taken to
+        stay the centre of mass.  Polygons are not offered here (use one polygon per body)."""
+        if self._world is not None:
+            raise RuntimeError("add colliders before the first tick")
+        kw = dict(material=self._mat(collider.material), category=collider.category, mask=collider.mask, group=collider.group)
+        dims = {"circle": (collider.r,), "rect": (collider.a, collider.b, collider.r), "capsule": (collider.a, collider.r)}
+        if collider.kind not in dims:
+            raise ValueError(collider.kind)
+        self._b.add_collider(body_id, collider.kind, dims[collider.kind], collider.offset, collider.local_angle, density=density, **kw)
+
     def add_distance_constraint(self, a, b, anchor_a=(0.0, 0.0), anchor_b=(0.0, 0.0), rest_length=None, compliance=0.0,
                                 limit=0, damping=0.0):
         """limit: 0 holds the length both ways, 1 (rope) only pulls, 2 (strut) only pushes.

@@ -27,6 +27,17 @@ def splitmix64_uniform(seed, count):
     return ((z >> np.uint64(40)).astype(np.float64) / float(1 << 24)).astype(np.float32)
 
 
+def as_colliders(arr):
+    """A collider array of an older layout (fields missing from the end of the struct: local pose, body) in today's."""
+    arr = np.asarray(arr)
+    if arr.dtype == collider_dtype:
+        return arr
+    out = np.zeros(len(arr), collider_dtype)
+    for f in arr.dtype.names:
+        out[f] = arr[f]
+    return out
+
+
 @dataclass
 class Scene:
     name: str
@@ -50,6 +61,11 @@ class Scene:
     def n(self):
         return self.pos.shape[0]
 
+    @property
+    def n_colliders(self):
+        """Bodies + further colliders (colliders[n:] name their body in the `body` field)."""
+        return len(self.colliders)
+
     def n_dynamic(self):
         return int(np.count_nonzero((self.inv_mass > 0) | (self.inv_inertia > 0)))
 
@@ -68,6 +84,8 @@ class Scene:
     def subset(self, idx, name=None):
         """Scene restricted to bodies idx (constraints are dropped)."""
         idx = np.asarray(idx)
+        if self.n_colliders != self.n:
+            raise ValueError("subset of a scene with several colliders per body is not supported")
         return Scene(
             name or self.name, self.pos[idx].copy(), self.rot[idx].copy(), self.vel[idx].copy(),
             self.angvel[idx].copy(), self.inv_mass[idx].copy(), self.inv_inertia[idx].copy(),
@@ -84,6 +102,7 @@ class SceneBuilder:
         self.substeps = substeps
         self.pos, self.rot, self.vel, self.angvel = [], [], [], []
         self.inv_mass, self.inv_inertia, self.col = [], [], []
+        self.extra = []     # further colliders of bodies that already have one: (collider tuple with its body id last)
         self.poly_pool = []
         self.constraints = []
         self.angle_constraints = []
@@ -105,7 +124,77 @@ class SceneBuilder:
     @staticmethod
     def _col(type_, p, material=0, category=1, mask=0xFFFFFFFF, group=0, poly_offset=0, poly_count=0, local_pos=(0.0, 0.0),
              local_angle=0.0):
-        return (type_, material, category, mask, group, tuple(p), poly_offset, poly_count, tuple(local_pos), local_angle)
+        return (type_, material, category, mask, group, tuple(p), poly_offset, poly_count, tuple(local_pos), local_angle, 0)
+
+    # ---- several colliders per body (include/sfx.h, sfx_collider.body)
+    @staticmethod
+    def _shape_mass(kind, dims, density):
+        """(mass, inertia about the shape's own centre) of kind in ("circle", "rect", "capsule") with dims as the
+        builder methods take them: (r,), (hw, hh[, rounding]), (hl, r)."""
+        if kind == "circle":
+            (r,) = dims
+            m = density * np.pi * r * r
+            return m, 0.5 * m * r * r
+        if kind == "rect":
+            hw, hh, rounding = (tuple(dims) + (0.0,))[:3]
+            w, h = 2 * (hw + rounding), 2 * (hh + rounding)
+            m = density * w * h
+            return m, m * (w * w + h * h) / 12.0
+        if kind == "capsule":
+            hl, r = dims
+            mr, mc = density * (2 * hl) * (2 * r), density * np.pi * r * r
+            return mr + mc, mr * ((2 * hl) ** 2 + (2 * r) ** 2) / 12.0 + mc * (0.5 * r * r + hl * hl)
+        raise ValueError(kind)
+
+    def _shape_col(self, kind, dims, **kw):
+        if kind == "circle":
+            return self._col(SHAPE_CIRCLE, (0, 0, dims[0]), **kw)
+        if kind == "rect":
+            hw, hh, rounding = (tuple(dims) + (0.0,))[:3]
+            return self._col(SHAPE_RECT, (hw, hh, rounding), **kw)
+        if kind == "capsule":
+            return self._col(SHAPE_CAPSULE, (dims[0], 0, dims[1]), **kw)
+        raise ValueError(kind)
+
+    def add_collider(self, body, kind, dims, local_pos=(0.0, 0.0), local_angle=0.0, density=None, **kw):
+        """A further collider on an existing body.  density (dynamic bodies): the shape's mass and inertia (parallel
+        axis about the body origin) are added to the body's; the body origin is taken to stay the centre of mass --
+        lay the shapes out accordingly, or use compound(), which recentres."""
+        col = self._shape_col(kind, dims, local_pos=local_pos, local_angle=local_angle, **kw)
+        self.extra.append(col[:-1] + (int(body),))
+        if density and self.inv_mass[body] > 0:
+            m, i = self._shape_mass(kind, dims, density)
+            i += m * (local_pos[0] ** 2 + local_pos[1] ** 2)
+            self.inv_mass[body] = 1.0 / (1.0 / self.inv_mass[body] + m)
+            self.inv_inertia[body] = 1.0 / (1.0 / self.inv_inertia[body] + i)
+        return len(self.extra) - 1
+
+    def compound(self, pos, parts, density=1.0, angle=0.0, vel=(0, 0), angvel=0.0, **kw):
+        """One body of several shapes.  parts: [(kind, dims, local_pos, local_angle), ...] in any frame of the
+        compound; `pos`, `angle` place that frame.  The body origin is moved to the centre of mass (every local_pos
+        shifts by -com, the body sits at pos + R(angle) com); density 0 = a static compound (level geometry).
+        Returns the body id."""
+        ms = [self._shape_mass(k, d, density if density > 0 else 1.0) for k, d, _, _ in parts]
+        mt = sum(m for m, _ in ms)
+        com = np.sum([m * np.asarray(lp, float) for (m, _), (_, _, lp, _) in zip(ms, parts)], axis=0) / mt
+        if density <= 0:
+            com = np.zeros(2)
+        inertia = sum(i + m * float(np.sum((np.asarray(lp, float) - com) ** 2)) for (m, i), (_, _, lp, _) in zip(ms, parts))
+        c, s = np.cos(angle), np.sin(angle)
+        origin = (pos[0] + c * com[0] - s * com[1], pos[1] + s * com[0] + c * com[1])
+        k0, d0, lp0, la0 = parts[0]
+        first = self._shape_col(k0, d0, local_pos=tuple(np.asarray(lp0, float) - com), local_angle=la0, **kw)
+        self.pos.append(origin)
+        self.rot.append((c, s))
+        self.vel.append(vel)
+        self.angvel.append(angvel)
+        self.inv_mass.append(0.0 if density <= 0 else 1.0 / mt)
+        self.inv_inertia.append(0.0 if density <= 0 else 1.0 / inertia)
+        self.col.append(first)
+        body = len(self.pos) - 1
+        for k, d, lp, la in parts[1:]:
+            self.add_collider(body, k, d, local_pos=tuple(np.asarray(lp, float) - com), local_angle=la, **kw)
+        return body
 
     def circle(self, pos, r, density=1.0, angle=0.0, vel=(0, 0), angvel=0.0, **kw):
         m = density * np.pi * r * r
@@ -189,7 +278,7 @@ class SceneBuilder:
         return Scene(
             self.name, f(self.pos, (n, 2)), f(self.rot, (n, 2)), f(self.vel, (n, 2)), f(self.angvel, (n,)),
             f(self.inv_mass, (n,)), f(self.inv_inertia, (n,)),
-            np.array(self.col, dtype=collider_dtype), np.array(self.materials, dtype=material_dtype),
+            np.array(self.col + self.extra, dtype=collider_dtype), np.array(self.materials, dtype=material_dtype),
             f(self.poly_pool, (len(self.poly_pool), 2)), np.array(self.constraints, dtype=constraint_dtype),
             substeps=self.substeps,
             angle_constraints=np.array(self.angle_constraints, dtype=angle_constraint_dtype),
@@ -340,9 +429,10 @@ def granular_slab(n=4_000_000, seed=0x5EED0005, width=40000, pitch=0.22, wall_hh
 
 # ------------------------------------------------------------------ small test scenes
 
-def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, speed=1.0, offsets=0.0):
+def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, speed=1.0, offsets=0.0, compounds=0.0):
     """Overlapping random shapes of every type with random velocities: a broadphase and
-    narrowphase stress scene for parity tests."""
+    narrowphase stress scene for parity tests.  offsets: fraction of bodies whose shape has a local pose;
+    compounds: fraction of bodies that get one or two further colliders (and one more on every static)."""
     rng = np.random.default_rng(seed)
     b = SceneBuilder(f"soup{n}_{seed}", materials=[(0.1, 0.5, 0.4), (0.6, 0.8, 0.6), (0.0, 0.2, 0.1)])
     for i in range(n):
@@ -375,4 +465,23 @@ def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, sp
         b.static_rect((0.0, -extent - 0.5), extent + 2.0, 0.5)
         b.static_rect((-extent - 1.0, 0.0), 0.5, extent + 1.0)
         b.static_rect((extent + 1.0, 0.0), 0.5, extent + 1.0, angle=0.1)
+    if compounds:
+        crng = np.random.default_rng(seed + 7919)
+        for i in range(n):
+            if b.col[i][0] == SHAPE_NONE or crng.random() >= compounds:
+                continue
+            for _ in range(int(crng.integers(1, 3))):
+                lp = tuple(crng.uniform(-0.25, 0.25, 2))
+                la = float(crng.uniform(-np.pi, np.pi))
+                kw = dict(material=int(crng.integers(0, 3)), group=b.col[i][4], category=b.col[i][2], mask=b.col[i][3])
+                if crng.random() < 0.5:
+                    b.add_collider(i, "circle", (crng.uniform(0.04, 0.15),), lp, 0.0, density=1.0, **kw)
+                elif crng.random() < 0.5:
+                    b.add_collider(i, "rect", (crng.uniform(0.04, 0.15), crng.uniform(0.04, 0.15)), lp, la, density=1.0, **kw)
+                else:
+                    b.add_collider(i, "capsule", (crng.uniform(0.05, 0.15), crng.uniform(0.03, 0.06)), lp, la, density=1.0, **kw)
+        if with_statics:   # level geometry as compounds: a ledge on the floor body, a step on a wall body
+            b.add_collider(n, "rect", (0.8, 0.15), (1.0, 0.65), 0.0)
+            b.add_collider(n + 1, "rect", (0.3, 0.3), (0.8, -1.0), 0.3)
+            b.add_collider(n, "circle", (1.2,), (-2.0, 0.2), 0.0)    # a large further collider
     return b.build()

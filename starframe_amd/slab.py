@@ -18,6 +18,8 @@ MI355X; the CPU oracle's OracleWorld in the CPU tests).
 """
 from dataclasses import dataclass, field
 
+import os
+
 import numpy as np
 
 from ._abi import SHAPE_CAPSULE, SHAPE_CIRCLE, SHAPE_POLY, SHAPE_RECT
@@ -300,7 +302,8 @@ class DistSlab:
                  transport="auto", **cfg_kw):
         """transport (device path only): "native" = libsfx_rccl.so, plain rccl.h ncclSend / ncclRecv on the world's own
         stream through a communicator of its own (the path a host without torch uses; include/sfx_rccl.h);
-        "torch" = torch.distributed batch_isend_irecv on tensors that alias the library's buffers; "auto" = native."""
+        "torch" = torch.distributed batch_isend_irecv on tensors that alias the library's buffers; "auto" = native when it comes up on every rank, else torch (all ranks together, with a warning).
+        The environment variable SFX_SLAB_TRANSPORT overrides the argument."""
         import torch
 
         self.torch, self.dist = torch, dist
@@ -332,9 +335,9 @@ class DistSlab:
         self.n_sl, self.n_sr, self.n_rl, self.n_rr = len(p.send_left), len(p.send_right), len(p.recv_left), len(p.recv_right)
         self.send = self.recv = None
         self.native = False
-        if self.on_device and self.transport in ("auto", "native"):
-            self._native_comm()
-            self.native = True
+        transport = os.environ.get("SFX_SLAB_TRANSPORT", self.transport)
+        if self.on_device and transport in ("auto", "native"):
+            self.native = self._native_comm(required=transport == "native")
         if self.on_device and not self.native:
             try:
                 dev = torch.device("cuda", device_index if device_index is not None else torch.cuda.current_device())
@@ -354,19 +357,44 @@ class DistSlab:
                 self.on_device = False
                 self.world.set_stream(0)
 
-    def _native_comm(self):
+    def _agree(self, ok):
+        """True when every rank says so (one all-reduce): the ranks switch transport together or not at all."""
+        t = self.torch
+        flag = t.tensor([1 if ok else 0], dtype=t.int32, device=t.device("cuda", t.cuda.current_device()))
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    def _native_comm(self, required):
         """A RCCL communicator of the library's own (once per driver; it outlives re-cuts): rank 0 makes the id, the
-        existing process group carries its 128 bytes to the others."""
+        existing process group carries its 128 bytes to the others.  Returns whether the native transport is up on
+        every rank; when it is not and it was not `required`, all ranks use torch.distributed instead (with a warning):
+        the ranks agree after each step that can fail on one of them alone, before the next collective one."""
         import ctypes as C
+        import warnings
 
         from . import _abi
 
         if self.comm is not None:
-            return
-        self.rccl = _abi.load_libsfx_rccl()
+            return True
+
+        def settle(ok, what):
+            if self._agree(ok):
+                return True
+            if required:
+                raise RuntimeError(f"native slab transport: {what} failed on a rank: " + (err[0] or "see the other ranks"))
+            warnings.warn(f"native slab transport unavailable ({what}: {err[0] or 'failed on another rank'}); using torch.distributed")
+            return False
+
+        err = [""]
         buf = (C.c_ubyte * _abi.RCCL_ID_BYTES)()
-        if self.rank == 0 and self.rccl.sfx_rccl_unique_id(buf) != 0:
-            raise RuntimeError("sfx_rccl_unique_id: " + self.rccl.sfx_rccl_last_error().decode())
+        try:
+            self.rccl = _abi.load_libsfx_rccl()
+            if self.rank == 0 and self.rccl.sfx_rccl_unique_id(buf) != 0:
+                err[0] = "sfx_rccl_unique_id: " + self.rccl.sfx_rccl_last_error().decode()
+        except OSError as e:
+            err[0] = repr(e)
+        if not settle(not err[0], "loading libsfx_rccl.so"):
+            return False
         box = [bytes(buf)]
         self.dist.broadcast_object_list(box, src=0)
         comm = C.c_void_p()
@@ -374,8 +402,13 @@ class DistSlab:
         rc = self.rccl.sfx_rccl_comm_create((C.c_ubyte * _abi.RCCL_ID_BYTES).from_buffer_copy(box[0]), self.rank, self.nranks, dev,
                                             C.byref(comm))
         if rc != 0:
-            raise RuntimeError("sfx_rccl_comm_create: " + self.rccl.sfx_rccl_last_error().decode())
+            err[0] = "sfx_rccl_comm_create: " + self.rccl.sfx_rccl_last_error().decode()
+        if not settle(rc == 0, "creating the communicator"):
+            if rc == 0:
+                self.rccl.sfx_rccl_comm_destroy(comm)
+            return False
         self.comm = comm
+        return True
 
     def drift(self):
         """The per-frame count exchange: every rank bins its owned bodies' current x into the

@@ -26,7 +26,8 @@ class WorldBase:
     lib = None
     prefix = ""
     handle = None
-    n = 0
+    n = 0      # bodies
+    nc = 0     # colliders (>= n: the further colliders of compound bodies follow the bodies' own)
     m = 0
     n_halo_send = 0
     n_halo_recv = 0
@@ -51,6 +52,7 @@ class WorldBase:
         self._check(self._f("upload_bodies")(self.handle, self.n, fptr(pos), fptr(rot), fptr(vel),
                                               fptr(angvel), fptr(im), fptr(ii)))
         col = np.ascontiguousarray(scene.colliders)
+        self.nc = len(col)
         pv = f32(scene.poly_verts).reshape(-1, 2)
         self._check(self._f("upload_materials")(self.handle, len(scene.materials),
                                                  vptr(np.ascontiguousarray(scene.materials))))
@@ -220,7 +222,7 @@ class World(WorldBase):
         self._check(self.lib.sfx_debug_broadphase(self.handle, dt))
 
     def aabbs(self):
-        out = np.empty((self.n, 4), np.float32)
+        out = np.empty((self.nc, 4), np.float32)   # one box per collider
         self._check(self.lib.sfx_debug_aabbs(self.handle, fptr(out)))
         return out
 

@@ -66,6 +66,7 @@ if __name__ == "__main__":
     make("pile3000_settled", settled_pile())
     make("soup200", scenes.random_soup(200, seed=21, extent=3.0))
     make("soup300_offsets", scenes.random_soup(300, seed=23, extent=3.5, offsets=0.5))   # half the shapes off their body's origin
+    make("soup300_compounds", scenes.random_soup(300, seed=29, extent=3.5, offsets=0.3, compounds=0.4))   # several colliders per body
     make("pyramid6", scenes.pyramid(base=6))
     make("chains4x20", scenes.chains(n_chains=4, links=20))
     make("circles500", scenes.circles_container(n=500, width=25, floor_hw=4.0, wall_hh=6.0))

@@ -9,6 +9,7 @@ import os
 import numpy as np
 import pytest
 
+from starframe_amd import scenes
 from starframe_amd.scenes import Scene
 from tests.helpers import colors_by_key, rel_err
 
@@ -20,7 +21,7 @@ DT = 1.0 / 60.0
 def load(path):
     z = np.load(path, allow_pickle=False)
     s = Scene(os.path.basename(path), z["pos"], z["rot"], z["vel"], z["angvel"], z["inv_mass"], z["inv_inertia"],
-              z["colliders"], z["materials"], z["poly_verts"], z["constraints"], substeps=int(z["substeps"]))
+              scenes.as_colliders(z["colliders"]), z["materials"], z["poly_verts"], z["constraints"], substeps=int(z["substeps"]))
     return s, z
 
 

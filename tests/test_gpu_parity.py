@@ -519,3 +519,85 @@ def test_colliders_with_a_local_pose_match_oracle():
     assert rel_err(g.velocities()[0], o.velocities()[0], floor=1.0) <= 1e-4
     assert rel_err(g.velocities()[1], o.velocities()[1], floor=10.0) <= 1e-4
     assert g.stats().overflow == 0
+
+
+def test_several_colliders_per_body_match_oracle():
+    """sfx_collider.body: a third of a soup's bodies carry one or two further colliders, the
+    static floor and wall carry level geometry.  AABBs per collider, pair set, owner units (further colliders of dynamic
+    bodies on the fallback list, those of static bodies in the tiles), colours bit-exact; contacts, queries (which name
+    the body of the collider hit, each body once per box) and twenty ticks of poses within tolerance."""
+    from oracle.oracle import ORDER_COLORED
+    from tests.test_oracle_queries import query_inputs
+
+    s = scenes.random_soup(2000, seed=37, extent=9.0, offsets=0.3, compounds=0.35)
+    assert s.n_colliders > s.n + 700
+    g, o = make_pair(s)
+    g.broadphase(DT)
+    o.broadphase(DT)
+    assert g.aabbs().shape == (s.n_colliders, 4)
+    assert np.array_equal(g.aabbs().view(np.uint32), o.aabbs().view(np.uint32)), "AABBs differ bitwise"
+    assert np.array_equal(g.pairs(), o.pairs())
+    gk, gc, gt = colors_by_key(*g.pair_colors())
+    ok, oc, ot = colors_by_key(*o.pair_colors())
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot) and np.array_equal(gc, oc)
+    gs, os_ = g.stats(), o.stats()
+    assert gs.n_fallback == os_.n_fallback > 300 and gs.n_bodies == os_.n_bodies == s.n
+    gcon, ocon = g.contacts(), o.contacts()
+    assert np.array_equal(gcon["count"], ocon["count"]) and (gcon["count"] > 0).sum() > 300
+    assert rel_err(gcon["normal"], ocon["normal"], floor=1.0) <= TOL
+    assert rel_err(gcon["depth"], ocon["depth"], floor=1e-2) <= TOL
+    pts, boxes, rays, max_t = query_inputs(37, 9.0, n=500, near=s.pos)
+    gb, gn = g.query_points(pts)
+    ob, on = o.query_points(pts)
+    assert np.array_equal(gb, ob) and np.array_equal(gn, on) and (on > 0).sum() > 50 and gb[gb != 0xFFFFFFFF].max() < s.n
+    assert np.array_equal(g.query_aabbs(boxes), o.query_aabbs(boxes))
+    gh, oh = g.query_rays(rays, max_t), o.query_rays(rays, max_t)
+    assert np.array_equal(gh["body"], oh["body"])
+    for _ in range(20):
+        g.step(DT)
+        o.step(DT, ORDER_COLORED)
+    assert g.poses()[0].shape == (s.n, 2)
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= 1e-4
+    assert rel_err(g.poses()[1], o.poses()[1], floor=1.0) <= 1e-4
+    assert rel_err(g.velocities()[0], o.velocities()[0], floor=1.0) <= 1e-3
+    assert g.stats().overflow == 0
+    # the same bodies, new state: the further colliders stay and follow
+    pos, rot = o.poses()
+    vel, ang = o.velocities()
+    for w in (g, o):
+        w.set_state(pos + np.float32(0.25), rot, vel, ang, s.inv_mass, s.inv_inertia)
+        w.broadphase(DT)
+    assert np.array_equal(g.aabbs().view(np.uint32), o.aabbs().view(np.uint32))
+    assert np.array_equal(g.pairs(), o.pairs())
+
+
+def test_dumbbell_and_static_level_geometry_on_the_gpu():
+    """The oracle's known answers for compound bodies (tests/test_oracle_compound.py) on the GPU: a dumbbell (two discs
+    and a bar, one body) comes to rest on both discs; a disc rolls down a ramp into the corner of a static body made of
+    three colliders, whose pairs stay in the tiles; 300 ticks equal the oracle's within tolerance."""
+    from oracle.oracle import ORDER_COLORED
+    from tests.test_oracle_compound import dumbbell_scene
+    from starframe_amd.scenes import SceneBuilder
+
+    s, floor, k = dumbbell_scene()
+    g, o = make_pair(s)
+    for _ in range(240):
+        g.step(DT)
+        o.step(DT, ORDER_COLORED)
+    gp, gr = g.poses()
+    assert abs(gp[k, 1] - 0.2) < 3e-3 and abs(gr[k, 1]) < 2e-3
+    assert rel_err(gp, o.poses()[0], floor=1.0) <= 1e-4 and rel_err(gr, o.poses()[1], floor=1.0) <= 1e-4
+    assert g.stats().n_fallback == 1          # floor x second disc (the bar hovers above the floor)
+    b = SceneBuilder("level", materials=[(0.0, 0.5, 0.4)])
+    level = b.compound((0.0, 0.0), [("rect", (3.0, 0.5), (0.0, -0.5), 0.0), ("rect", (0.5, 2.0), (-3.5, 1.0), 0.0)], density=0.0)
+    b.add_collider(level, "rect", (1.5, 0.05), (1.0, 0.6), 0.35)
+    d = b.circle((1.5, 1.6), 0.15)
+    g2, o2 = make_pair(b.build())
+    for _ in range(600):
+        g2.step(DT)
+        o2.step(DT, ORDER_COLORED)
+    p = g2.poses()[0]
+    assert abs(p[d, 0] - (-3.0 + 0.15)) < 5e-3 and abs(p[d, 1] - 0.15) < 5e-3
+    assert rel_err(p, o2.poses()[0], floor=1.0) <= 1e-4
+    st = g2.stats()
+    assert st.n_fallback == 0 and st.n_tiles >= 1 and st.overflow == 0

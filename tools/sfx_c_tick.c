@@ -9,7 +9,7 @@
 #include "sfx.h"
 
 /* every struct any binding mirrors: their sizes are part of the ABI (include/sfx.h has the same asserts) */
-_Static_assert(sizeof(sfx_collider) == 52, "sfx_collider");
+_Static_assert(sizeof(sfx_collider) == 56, "sfx_collider");
 _Static_assert(sizeof(sfx_material) == 12, "sfx_material");
 _Static_assert(sizeof(sfx_distance_constraint) == 40, "sfx_distance_constraint");
 

@@ -43,7 +43,7 @@ static bool load(const char* path, Scene& s) {
     FILE* f = fopen(path, "rb");
     if (!f) return false;
     uint32_t hdr[6];
-    bool ok = fread(hdr, 4, 6, f) == 6 && hdr[0] == 0x32584653u && hdr[3] == 0 && hdr[4] == 0;  // no polygons, no joints
+    bool ok = fread(hdr, 4, 6, f) == 6 && hdr[0] == 0x33584653u && hdr[3] == 0 && hdr[4] == 0;  // no polygons, no joints
     if (ok) {
         s.n = hdr[1]; s.n_mat = hdr[2]; s.substeps = hdr[5];
         ok = rd(f, s.pos, 2 * (size_t)s.n) && rd(f, s.rot, 2 * (size_t)s.n) && rd(f, s.vel, 2 * (size_t)s.n) &&
