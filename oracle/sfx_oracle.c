@@ -1487,11 +1487,13 @@ static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec, 
     }
     float l0 = 0.0f, l1 = 0.0f;
     float ims = ima + imb;
-    float K00 = (ims + iia * (cna[0] * cna[0])) + iib * (cnb[0] * cnb[0]);
+    /* [DESIGN] effective masses: the sum of the inverse masses plus the SUM of the two bodies' angular terms (the sum of
+     * two terms does not depend on which body comes first: the device computes it on either side of the pair) */
+    float K00 = ims + (iia * (cna[0] * cna[0]) + iib * (cnb[0] * cnb[0]));
     if (!(K00 > 0.0f)) return;
     if (count == 2) {
-        float K11 = (ims + iia * (cna[1] * cna[1])) + iib * (cnb[1] * cnb[1]);
-        float K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
+        float K11 = ims + (iia * (cna[1] * cna[1]) + iib * (cnb[1] * cnb[1]));
+        float K01 = ims + (iia * (cna[0] * cna[1]) + iib * (cnb[0] * cnb[1]));
         solve_lcp2(K00, K01, K11, d[0], d[1], &l0, &l1);
     } else {
         l0 = fmaxf(d[0], 0.0f) / K00;
@@ -1569,11 +1571,11 @@ static void solve_vel_pair(sfo_world* w, uint32_t a, uint32_t b, const pair_rec*
         dv[k] = fmaxf(-e * rec->vn_pre[k], 0.0f) - vn;
         cna[k] = rax[k] * ny - ray[k] * nx;
         cnb[k] = rbx[k] * ny - rby[k] * nx;
-        K[k] = (ims + iia * (cna[k] * cna[k])) + iib * (cnb[k] * cnb[k]);
+        K[k] = ims + (iia * (cna[k] * cna[k]) + iib * (cnb[k] * cnb[k]));
         act[k] = rec->lam[k] > 0.0f && K[k] > 0.0f;
     }
     float K01 = 0.0f;
-    if (count == 2) K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
+    if (count == 2) K01 = ims + (iia * (cna[0] * cna[1]) + iib * (cnb[0] * cnb[1]));
     float p0, p1;
     kinv_apply(K, K01, act, count, dv[0], dv[1], &p0, &p1);
     {
@@ -1599,7 +1601,7 @@ static void solve_vel_pair(sfo_world* w, uint32_t a, uint32_t b, const pair_rec*
     if (!(vt > EPS_LEN)) return;
     float tx = vtx / vt, ty = vty / vt;
     float cta = max_ * ty - may_ * tx, ctb = mbx_ * ty - mby_ * tx;
-    float Att = (ims + iia * (cta * cta)) + iib * (ctb * ctb);
+    float Att = ims + (iia * (cta * cta) + iib * (ctb * ctb));
     float At0 = iia * (cta * cna[0]) + iib * (ctb * cnb[0]);
     float At1 = iia * (cta * cna[1]) + iib * (ctb * cnb[1]);
     float y0, y1;

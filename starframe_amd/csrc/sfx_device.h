@@ -670,11 +670,13 @@ __device__ __forceinline__ bool solve_pos_rec(PairRec& r, float4& pa, const floa
     }
     float l0 = 0.0f, l1 = 0.0f;
     const float ims = ima + imb;
-    const float K00 = (ims + iia * (cna[0] * cna[0])) + iib * (cnb[0] * cnb[0]);
+    // effective masses: the sum of the two inverse masses plus the SUM of the two bodies' angular terms (a sum of two is the
+    // same whichever body comes first: solve_pos_side computes it on either side of the pair)
+    const float K00 = ims + (iia * (cna[0] * cna[0]) + iib * (cnb[0] * cnb[0]));
     if (!(K00 > 0.0f)) return false;
     if (r.count == 2) {
-        float K11 = (ims + iia * (cna[1] * cna[1])) + iib * (cnb[1] * cnb[1]);
-        float K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
+        float K11 = ims + (iia * (cna[1] * cna[1]) + iib * (cnb[1] * cnb[1]));
+        float K01 = ims + (iia * (cna[0] * cna[1]) + iib * (cnb[0] * cnb[1]));
         solve_lcp2(K00, K01, K11, d[0], d[1], l0, l1);
     } else {
         l0 = fmaxf(d[0], 0.0f) / K00;
@@ -754,12 +756,12 @@ __device__ __forceinline__ int solve_vel_rec(const PairRec& r, float4& pa, float
             dv[k] = fmaxf(-e * vpre, 0.0f) - vn;
             cna[k] = rax[k] * ny - ray[k] * nx;
             cnb[k] = rbx[k] * ny - rby[k] * nx;
-            K[k] = (ims + iia * (cna[k] * cna[k])) + iib * (cnb[k] * cnb[k]);
+            K[k] = ims + (iia * (cna[k] * cna[k]) + iib * (cnb[k] * cnb[k]));
             act[k] = lam > 0.0f && K[k] > 0.0f;
         }
     }
     float K01 = 0.0f;
-    if (count == 2) K01 = (ims + iia * (cna[0] * cna[1])) + iib * (cnb[0] * cnb[1]);
+    if (count == 2) K01 = ims + (iia * (cna[0] * cna[1]) + iib * (cnb[0] * cnb[1]));
     float p0, p1;
     kinv_apply(K[0], K[1], K01, act[0], act[1], count, dv[0], dv[1], p0, p1);
     {
@@ -788,7 +790,7 @@ __device__ __forceinline__ int solve_vel_rec(const PairRec& r, float4& pa, float
         if (vt > SFX_EPS_LEN) {
             float tx = vtx / vt, ty = vty / vt;
             float cta = max_ * ty - may_ * tx, ctb = mbx_ * ty - mby_ * tx;
-            float Att = (ims + iia * (cta * cta)) + iib * (ctb * ctb);
+            float Att = ims + (iia * (cta * cta) + iib * (ctb * ctb));
             float At0 = iia * (cta * cna[0]) + iib * (ctb * cnb[0]);
             float At1 = iia * (cta * cna[1]) + iib * (ctb * cnb[1]);
             float y0, y1;
@@ -820,6 +822,151 @@ __device__ __forceinline__ int solve_vel_rec(const PairRec& r, float4& pa, float
                         pb.y = pb.y + (jy * sp.h) * imb;
                     }
                     if (iib > 0.0f) rotate_by(pb.z, pb.w, iib * (jb * sp.h));
+                }
+            }
+        }
+    }
+    return shift ? 3 : 1;
+}
+
+// ---- the same two solves with TWO LANES PER PAIR (the tile kernels): lane 2k holds body a of a pair, lane 2k + 1 body b.
+// A lane computes what belongs to its own body (anchors, lever arms, angular terms, the update of its pose and velocity)
+// and takes the other body's few numbers from its neighbour lane (one DPP move each); what belongs to the pair (depths,
+// the 2x2 solve, friction) both lanes compute, on identical inputs, to identical bits.  With the normal SIGNED per lane
+// (n for a, -n for b) the code is the same on both sides and equals solve_pos_rec / solve_vel_rec bit for bit: negations
+// are exact, sums of two are commutative, and rounding is symmetric in the sign.
+__device__ __forceinline__ float other_side(float x) {   // the neighbour lane's value (lanes 2k <-> 2k + 1: quad_perm [1,0,3,2])
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
+}
+
+// One side of a prepared pair, in registers.
+struct SideRec {
+    int count;             // 0, 1 or 2 points
+    float nx, ny;          // the normal as this side sees it: from this body to the other
+    float mu_s, mu_d, rest;
+    float l[2][2];         // this body's local anchors
+    float vpre[2];
+    float l0, l1;
+};
+
+// returns true when the pose changed; r.l0 / r.l1 = the multipliers (the same on both lanes)
+__device__ __forceinline__ bool solve_pos_side(SideRec& r, float4& p, const float2& w, float max_corr) {
+    const float nx = r.nx, ny = r.ny, im = w.x, ii = w.y;
+    float d[2], cn[2];
+    d[1] = 0.0f; cn[1] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k < r.count) {
+            float rx, ry;
+            anchor_world(p, r.l[k][0], r.l[k][1], rx, ry);
+            const float qx = p.x + rx, qy = p.y + ry;
+            const float ox = other_side(qx), oy = other_side(qy);
+            d[k] = (qx - ox) * nx + (qy - oy) * ny;
+            d[k] = fminf(d[k], max_corr);
+            cn[k] = rx * ny - ry * nx;
+        }
+    }
+    float l0 = 0.0f, l1 = 0.0f;
+    const float ims = im + other_side(im);
+    const float t00 = ii * (cn[0] * cn[0]);
+    const float K00 = ims + (t00 + other_side(t00));
+    if (!(K00 > 0.0f)) return false;
+    if (r.count == 2) {
+        const float t11 = ii * (cn[1] * cn[1]), t01 = ii * (cn[0] * cn[1]);
+        const float K11 = ims + (t11 + other_side(t11));
+        const float K01 = ims + (t01 + other_side(t01));
+        solve_lcp2(K00, K01, K11, d[0], d[1], l0, l1);
+    } else {
+        l0 = fmaxf(d[0], 0.0f) / K00;
+    }
+    r.l0 = l0; r.l1 = l1;
+    const float lt = l0 + l1;
+    if (!(lt > 0.0f)) return false;
+    if (im > 0.0f) {
+        p.x = p.x - (nx * lt) * im;
+        p.y = p.y - (ny * lt) * im;
+    }
+    if (ii > 0.0f) rotate_by(p.z, p.w, -(ii * (cn[0] * l0 + cn[1] * l1)));
+    return true;
+}
+
+// bit 0: the velocity changed, bit 1: the pose changed (static friction)
+__device__ __forceinline__ int solve_vel_side(const SideRec& r, float4& p, float4& v, const float2& w, const StepParams& sp) {
+    const int count = r.count;
+    const float l0 = r.l0, l1 = count == 2 ? r.l1 : 0.0f;
+    const float lt = l0 + l1;
+    const float nx = r.nx, ny = r.ny, mu_s = r.mu_s, mu_d = r.mu_d, rest = r.rest;
+    const float im = w.x, ii = w.y;
+    const float ims = im + other_side(im);
+    float rx[2], ry[2], dv[2], cn[2], K[2];
+    bool act[2];
+    act[1] = false; dv[1] = 0.0f; cn[1] = 0.0f; K[1] = 1.0f;
+    rx[1] = ry[1] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k < count) {
+            const float lam = k == 0 ? r.l0 : r.l1;
+            const float vpre = r.vpre[k];
+            anchor_world(p, r.l[k][0], r.l[k][1], rx[k], ry[k]);
+            const float ux = v.x - v.z * ry[k], uy = v.y + v.z * rx[k];
+            const float ox = other_side(ux), oy = other_side(uy);
+            const float vn = (ox - ux) * nx + (oy - uy) * ny;
+            const float e = fabsf(vpre) <= sp.vthr ? 0.0f : rest;
+            dv[k] = fmaxf(-e * vpre, 0.0f) - vn;
+            cn[k] = rx[k] * ny - ry[k] * nx;
+            const float tkk = ii * (cn[k] * cn[k]);
+            K[k] = ims + (tkk + other_side(tkk));
+            act[k] = lam > 0.0f && K[k] > 0.0f;
+        }
+    }
+    float K01 = 0.0f;
+    if (count == 2) { const float t01 = ii * (cn[0] * cn[1]); K01 = ims + (t01 + other_side(t01)); }
+    float p0, p1;
+    kinv_apply(K[0], K[1], K01, act[0], act[1], count, dv[0], dv[1], p0, p1);
+    {
+        const float pt = p0 + p1;
+        const float cr = cn[0] * p0 + cn[1] * p1;
+        v.x = v.x - (nx * pt) * im;
+        v.y = v.y - (ny * pt) * im;
+        v.z = v.z - ii * cr;
+    }
+    bool shift = false;
+    if (!(sp.flags & SFX_CFG_NO_FRICTION)) {
+        float mx, my;
+        if (count == 2) { mx = 0.5f * (rx[0] + rx[1]); my = 0.5f * (ry[0] + ry[1]); }
+        else { mx = rx[0]; my = ry[0]; }
+        const float ux = v.x - v.z * my, uy = v.y + v.z * mx;
+        const float vx = other_side(ux) - ux, vy = other_side(uy) - uy;
+        const float vn = vx * nx + vy * ny;
+        const float vtx = vx - nx * vn, vty = vy - ny * vn;
+        const float vt = sqrtf(vtx * vtx + vty * vty);
+        if (vt > SFX_EPS_LEN) {
+            const float tx = vtx / vt, ty = vty / vt;
+            const float ct = mx * ty - my * tx;
+            const float att = ii * (ct * ct), a0 = ii * (ct * cn[0]), a1 = ii * (ct * cn[1]);
+            const float Att = ims + (att + other_side(att));
+            const float At0 = a0 + other_side(a0);
+            const float At1 = a1 + other_side(a1);
+            float y0, y1;
+            kinv_apply(K[0], K[1], K01, act[0], act[1], count, At0, At1, y0, y1);
+            const float S = Att - (At0 * y0 + At1 * y1);
+            if (S > 0.0f) {
+                const float need = vt / S;
+                const bool is_static = need * sp.h < mu_s * lt;
+                const float pt = is_static ? -need : -fminf(mu_d * lt * sp.inv_h, need);
+                const float q0 = -(y0 * pt), q1 = -(y1 * pt);
+                const float jx = tx * pt + nx * (q0 + q1), jy = ty * pt + ny * (q0 + q1);
+                const float jr = (ct * pt + cn[0] * q0) + cn[1] * q1;
+                v.x = v.x - jx * im;
+                v.y = v.y - jy * im;
+                v.z = v.z - ii * jr;
+                if (is_static) {
+                    shift = true;
+                    if (im > 0.0f) {
+                        p.x = p.x - (jx * sp.h) * im;
+                        p.y = p.y - (jy * sp.h) * im;
+                    }
+                    if (ii > 0.0f) rotate_by(p.z, p.w, -(ii * (jr * sp.h)));
                 }
             }
         }

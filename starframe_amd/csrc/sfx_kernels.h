@@ -126,10 +126,12 @@ __global__ __launch_bounds__(kBlock) void k_integrate(uint32_t n, float4* __rest
     float4 v = vel[i];
     const float2 w = mass[i];
     prev[i] = p;
+#ifndef SFX_PROBE_NOSOLVE   // (the timing probe keeps the scene where it is)
     if (w.x > 0.0f) {
         v.x = v.x + sp.gx * sp.h;
         v.y = v.y + sp.gy * sp.h;
     }
+#endif
     if (w.x > 0.0f || w.y > 0.0f) {
         v.x = v.x * sp.damp_lin;
         v.y = v.y * sp.damp_lin;
@@ -1541,68 +1543,72 @@ __device__ __forceinline__ PairEnds pair_ends(const uint4& pr) {
     return e;
 }
 
-// One pair of a batch as the colour loops see it: ends + record, fetched from the pair list and
-// the contact arrays one colour ahead of its use.
-struct PairSlot {
-    PairEnds e;
-    PairRec r;
+// Two lanes per pair (sfx_device.h solve_pos_side / solve_vel_side): lane 2k takes body a of the run's k-th pair, lane
+// 2k + 1 body b.  One side of a pair as the colour loops see it: this body's LDS index + its side of the record, fetched
+// from the pair list and the contact arrays one colour ahead of its use.
+struct SideSlot {
+    uint32_t li;     // this body's local index
+    SideRec r;
     bool valid;
 };
 
-// The raw fields of one pair as loaded: every field unconditionally and at once (one round trip,
-// no load waits for another, nothing branches on loaded data), decoded only when the pair's colour
-// comes up -- so the loads of colour c + 1 are in flight while colour c is solved.
-struct RawSlot {
+// The raw fields of one side as loaded: every field unconditionally and at once (one round trip, no load waits for
+// another, nothing branches on loaded data), decoded only when the pair's colour comes up -- so the loads of colour
+// c + 1 are in flight while colour c is solved.  The two lanes of a pair load the same lines (one request).
+struct RawSide {
     float4 m;        // (restitution, count as bits, vn_pre0, vn_pre1)
     float2 lam;
     uint4 pr;
-    float4 hdr, a0, a1;
+    float4 hdr;
+    float2 a0, a1;   // this side's local anchors
     bool in_range;
 };
 
 template <bool VEL>
-__device__ __forceinline__ void fetch_raw(const TileArrays& T, const ContactArrays& C, uint32_t slot, bool in_range,
-                                          RawSlot& q) {
+__device__ __forceinline__ void fetch_side(const TileArrays& T, const ContactArrays& C, uint32_t slot, uint32_t side, bool in_range,
+                                           RawSide& q) {
     // lanes past the end of the run load slot 0 (always there) and ignore it: no branch around the loads, so
     // nothing has to wait for them before the pair's colour comes up
     q.in_range = in_range;
     slot = in_range ? slot : 0u;
     q.lam = make_float2(0.0f, 0.0f);
     const float4* line = C.rec + 4u * (size_t)slot;
+    const float2* half = reinterpret_cast<const float2*>(line);
     q.pr = T.tpair[slot];
     q.m = line[3];
     q.hdr = line[0];
-    q.a0 = line[1];
-    q.a1 = line[2];
+    q.a0 = half[2u + side];   // line[1] = (a's anchor 0, b's anchor 0)
+    q.a1 = half[4u + side];   // line[2] = (a's anchor 1, b's anchor 1)
     if (VEL) q.lam = C.lam[slot];
 }
 
 template <bool VEL>
-__device__ __forceinline__ void decode_raw(const RawSlot& q, PairSlot& p, uint32_t nb) {
+__device__ __forceinline__ void decode_side(const RawSide& q, uint32_t side, SideSlot& p, uint32_t nb) {
     p.valid = false;
     p.r.count = 0;
-    p.e = pair_ends(q.pr);
+    const PairEnds e = pair_ends(q.pr);
+    p.li = side ? e.lb : e.la;
     const int count = (int)__float_as_uint(q.m.y);
     if (!q.in_range || count == 0) return;
-    if (p.e.la >= nb || p.e.lb >= nb) return;  // an outside body that found no LDS slot (kOvfExt was reported)
+    if (e.la >= nb || e.lb >= nb) return;  // an outside body that found no LDS slot (kOvfExt was reported)
     if (VEL && !(q.lam.x + q.lam.y > 0.0f)) return;  // nothing was pushed: nothing to do in the velocity pass
-    PairRec& r = p.r;
+    SideRec& r = p.r;
     r.count = count; r.rest = q.m.x;
     r.l0 = q.lam.x; r.l1 = q.lam.y; r.vpre[0] = q.m.z; r.vpre[1] = q.m.w;
-    r.nx = q.hdr.x; r.ny = q.hdr.y; r.mu_s = q.hdr.z; r.mu_d = q.hdr.w;
-    r.la[0][0] = q.a0.x; r.la[0][1] = q.a0.y; r.lb[0][0] = q.a0.z; r.lb[0][1] = q.a0.w;
+    r.nx = side ? -q.hdr.x : q.hdr.x; r.ny = side ? -q.hdr.y : q.hdr.y;   // from this body to the other
+    r.mu_s = q.hdr.z; r.mu_d = q.hdr.w;
+    r.l[0][0] = q.a0.x; r.l[0][1] = q.a0.y;
     const bool two = count == 2;
-    r.la[1][0] = two ? q.a1.x : 0.0f; r.la[1][1] = two ? q.a1.y : 0.0f;
-    r.lb[1][0] = two ? q.a1.z : 0.0f; r.lb[1][1] = two ? q.a1.w : 0.0f;
+    r.l[1][0] = two ? q.a1.x : 0.0f; r.l[1][1] = two ? q.a1.y : 0.0f;
     p.valid = true;
 }
 
 template <bool VEL>
-__device__ __forceinline__ void fetch_pair(const TileArrays& T, const ContactArrays& C, uint32_t slot, bool in_range,
-                                           PairSlot& p, uint32_t nb) {
-    RawSlot q;
-    fetch_raw<VEL>(T, C, slot, in_range, q);
-    decode_raw<VEL>(q, p, nb);
+__device__ __forceinline__ void fetch_side_now(const TileArrays& T, const ContactArrays& C, uint32_t slot, uint32_t side,
+                                               SideSlot& p, uint32_t nb) {
+    RawSide q;
+    fetch_side<VEL>(T, C, slot, side, true, q);
+    decode_side<VEL>(q, side, p, nb);
 }
 
 // Workgroup barrier for steps that hand data over through LDS only: waits for the LDS traffic,
@@ -1772,8 +1778,9 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol, npb = min(d.np, kBatchP);
         // everything that no earlier phase of this launch writes is fetched before waiting for them: the records of
         // the first colour (it starts the batch's list), the body ids, the masses, the colour runs
-        RawSlot nxt;
-        fetch_raw<false>(T, C, start + tid, start + tid < T.max_pairs, nxt);
+        const uint32_t side = tid & 1u, half = tid >> 1;   // two lanes per pair: body a, body b
+        RawSide nxt;
+        fetch_side<false>(T, C, start + half, side, start + half < T.max_pairs, nxt);
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
         for (uint32_t l = tid; l < nb; l += NT) {  // block bodies, then the large colliders outside the block its pairs touch
             const uint32_t gid = T.bbody[d.boff + l];
@@ -1790,34 +1797,37 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         SFX_TT_ADD(6, tt0, ttw);
         for (uint32_t l = tid; l < nb; l += NT) s_pose[l] = B.pose[s_gid[l]];  // (the lane that stored s_gid[l])
         __syncthreads();
-        nxt.in_range = ncol > 0u && tid < s_ce[0];
+        nxt.in_range = ncol > 0u && half < s_ce[0];
         const uint32_t ahead = take_ahead<NT>(ctr, flags);  // the next batch's ticket, in flight during the colour loop
         SFX_TT(tt1);
         SFX_TT(tt2);
-        auto solve = [&](uint32_t k, PairSlot& p) {  // everything from LDS: no memory wait inside a colour step
-            const PairEnds& e = p.e;
-            float4 pa = s_pose[e.la];
-            float4 pb = s_pose[e.lb];
-            const float2 wa = s_mass[e.la];
-            const float2 wb = s_mass[e.lb];
-            if (solve_pos_rec(p.r, pa, wa, pb, wb, max_corr)) {
-                if (wa.x > 0.0f || wa.y > 0.0f) s_pose[e.la] = pa;
-                if (wb.x > 0.0f || wb.y > 0.0f) s_pose[e.lb] = pb;
+        auto solve = [&](uint32_t k, SideSlot& p) {  // everything from LDS: no memory wait inside a colour step
+            float4 ps = s_pose[p.li];
+            const float2 w = s_mass[p.li];
+#ifdef SFX_PROBE_NOSOLVE   // timing probe: the colour loop without its arithmetic (results are wrong)
+            ps.x += p.r.l[0][0] * 1e-30f;
+            if (w.x > 0.0f) s_pose[p.li] = ps;
+            return;
+#endif
+            if (solve_pos_side(p.r, ps, w, max_corr)) {
+                if (w.x > 0.0f || w.y > 0.0f) s_pose[p.li] = ps;
             }
-            s_lam[k] = make_float2(p.r.l0, p.r.l1);
+            if (side == 0u) s_lam[k] = make_float2(p.r.l0, p.r.l1);
         };
+        // (fetching two colours ahead, with two register sets, was measured again in round 2: 2 % slower -- a step does
+        // not wait for its record, it is one wave's dependent instruction chain)
         for (uint32_t c = 0; c < ncol; ++c) {
-            PairSlot cur;
-            decode_raw<false>(nxt, cur, nb);
-            const uint32_t k0 = s_cs[c] + tid, ce = s_ce[c];
+            SideSlot cur;
+            decode_side<false>(nxt, side, cur, nb);
+            const uint32_t k0 = s_cs[c] + half, ce = s_ce[c];
             {   // the next colour's pair, in flight while this one is solved
                 const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
-                fetch_raw<false>(T, C, start + s_cs[c1] + tid, c + 1u < ncol && s_cs[c1] + tid < s_ce[c1], nxt);
+                fetch_side<false>(T, C, start + s_cs[c1] + half, side, c + 1u < ncol && s_cs[c1] + half < s_ce[c1], nxt);
             }
             if (cur.valid) solve(k0, cur);
-            for (uint32_t k = k0 + NT; k < ce; k += NT) {  // colour runs longer than the workgroup (rare)
-                PairSlot more;
-                fetch_pair<false>(T, C, start + k, true, more, nb);
+            for (uint32_t k = k0 + NT / 2; k < ce; k += NT / 2) {  // colour runs longer than half the workgroup
+                SideSlot more;
+                fetch_side_now<false>(T, C, start + k, side, more, nb);
                 if (more.valid) solve(k, more);
             }
             lds_barrier();
@@ -1872,8 +1882,9 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         const uint32_t* tiles = T.active + d.first;   // one tile list for all phases
         SFX_TT(tv0);
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol;
-        RawSlot nxt;  // as in k_tile_pos: what earlier phases do not write is fetched before waiting for them
-        fetch_raw<true>(T, C, start + tid, start + tid < T.max_pairs, nxt);
+        const uint32_t side = tid & 1u, half = tid >> 1;   // two lanes per pair: body a, body b
+        RawSide nxt;  // as in k_tile_pos: what earlier phases do not write is fetched before waiting for them
+        fetch_side<true>(T, C, start + half, side, start + half < T.max_pairs, nxt);
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
         if (tid == 0) s_shift = 0u;
         if (tid < SFX_MAX_COLORS) {
@@ -1893,33 +1904,33 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
             s_vel[l] = B.vel[gid];
         }
         __syncthreads();
-        nxt.in_range = ncol > 0u && tid < s_ce[0];
+        nxt.in_range = ncol > 0u && half < s_ce[0];
         const uint32_t ahead = take_ahead<NT>(ctr, flags);
         SFX_TT(tv1);
-        auto solve = [&](const PairSlot& p) {
-            const PairEnds& e = p.e;
-            float4 pa = s_pose[e.la], va = s_vel[e.la];
-            float4 pb = s_pose[e.lb], vb = s_vel[e.lb];
-            const float2 wa = s_mass[e.la], wb = s_mass[e.lb];
-            const int ch = solve_vel_rec(p.r, pa, va, wa, pb, vb, wb, sp);
-            if (ch) {
-                if (wa.x > 0.0f || wa.y > 0.0f) { s_vel[e.la] = va; if (ch & 2) s_pose[e.la] = pa; }
-                if (wb.x > 0.0f || wb.y > 0.0f) { s_vel[e.lb] = vb; if (ch & 2) s_pose[e.lb] = pb; }
-                if (ch & 2) s_shift = 1u;
-            }
+        auto solve = [&](const SideSlot& p) {
+            float4 ps = s_pose[p.li], vs = s_vel[p.li];
+            const float2 w = s_mass[p.li];
+#ifdef SFX_PROBE_NOSOLVE
+            vs.x += p.r.l[0][0] * 1e-30f;
+            if (w.x > 0.0f) s_vel[p.li] = vs;
+            return;
+#endif
+            const int ch = solve_vel_side(p.r, ps, vs, w, sp);
+            if (w.x > 0.0f || w.y > 0.0f) { s_vel[p.li] = vs; if (ch & 2) s_pose[p.li] = ps; }
+            if ((ch & 2) && side == 0u) s_shift = 1u;
         };
         for (uint32_t c = 0; c < ncol; ++c) {
-            PairSlot cur;
-            decode_raw<true>(nxt, cur, nb);
-            const uint32_t k0 = s_cs[c] + tid, ce = s_ce[c];
+            SideSlot cur;
+            decode_side<true>(nxt, side, cur, nb);
+            const uint32_t k0 = s_cs[c] + half, ce = s_ce[c];
             {
                 const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
-                fetch_raw<true>(T, C, start + s_cs[c1] + tid, c + 1u < ncol && s_cs[c1] + tid < s_ce[c1], nxt);
+                fetch_side<true>(T, C, start + s_cs[c1] + half, side, c + 1u < ncol && s_cs[c1] + half < s_ce[c1], nxt);
             }
             if (cur.valid) solve(cur);
-            for (uint32_t k = k0 + NT; k < ce; k += NT) {
-                PairSlot more;
-                fetch_pair<true>(T, C, start + k, true, more, nb);
+            for (uint32_t k = k0 + NT / 2; k < ce; k += NT / 2) {
+                SideSlot more;
+                fetch_side_now<true>(T, C, start + k, side, more, nb);
                 if (more.valid) solve(more);
             }
             lds_barrier();
