@@ -163,6 +163,9 @@ def main():
                          "3.4 us: every tick would take 3.4 %% off the value, every 8th takes 0.4 %%)")
     ap.add_argument("--force-slab", action="store_true",
                     help="rehearse the N > 1 code path (slab driver over torch.distributed nccl) with one rank")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks that SHARE GPU 0, process group over gloo, halos through host memory: everything of the "
+                         "N > 1 path except RCCL (cuts, ghosts, guard, re-cuts, gather, timing); the line says so and is no result")
     args = ap.parse_args()
     rank, local_rank, world = dist_env()
     # stdout carries the one JSON line and nothing else: what libraries print to file descriptor 1 (RCCL's version
@@ -186,8 +189,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(device)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
+        if args.rehearse_on_one_gpu:
+            device = 0
+            os.environ["SFX_SHARED_DEVICE"] = "1"   # several processes' fused launches on one GPU: batches by ticket
+            torch.cuda.set_device(device)
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", device))
 
         from starframe_amd.slab import DistSlab
 
@@ -276,7 +285,7 @@ def main():
     if dist is not None:
         import torch
 
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.rehearse_on_one_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.barrier()
@@ -359,14 +368,14 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": load_traffic(dom),
+            "traffic": load_traffic(dom) if slab is None else None,   # the PMC passes were taken on the N = 1 pile
             "bytes_per_launch": sp["bytes_per_launch"],
             "launch_us": sp["launch_us"],
             "launches_per_step": kt[dom]["launches"] / prof_frames,
             "launch_us_second_leg": per_kernel[dom]["launch_us"],
             "other_kernels": {KERNEL_NAMES[c].split(" ")[0]: {"achieved": round(v["achieved"], 1), "frac": round(v["achieved"] / HBM_PEAK_GBS, 4),
                                                                 "launch_us": round(v["launch_us"], 2), "bytes_per_launch": v["bytes_per_launch"],
-                                                                "traffic": load_traffic(c)}
+                                                                "traffic": load_traffic(c) if slab is None else None}
                               for c, v in per_kernel.items() if c != dom},
             "tick_bytes_per_body_substep": bpbs,
             "tick_frac": (value / world) * bpbs / (HBM_PEAK_GBS * 1e9),
@@ -379,6 +388,8 @@ def main():
     }
     if slab is not None and single is not None:
         out["scaling_reference"] = single
+    if args.rehearse_on_one_gpu:
+        out["rehearsal"] = f"{world} ranks sharing ONE GPU over gloo with host-staged halos: a test of the N > 1 code path, not a measurement"
     if dist is not None:
         dist.barrier()
     w.close()
