@@ -411,7 +411,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize_slots(uint32_t n, GridParam
 // k_tile_list + a scan of those counts the fill pass reserves room per slot and stream with
 // one atomic each and writes (id a, id b, slot a, slot b).  Pairs of tiles flagged as over
 // capacity are re-routed to the fallback list.
-constexpr int kGroup = 8;                 // lanes per slot
+#ifndef SFX_PAIR_GROUP
+#define SFX_PAIR_GROUP 8
+#endif
+constexpr int kGroup = SFX_PAIR_GROUP;    // lanes per slot (a power of two, 2 .. 16)
+constexpr int kGroupLog = kGroup == 16 ? 4 : kGroup == 8 ? 3 : kGroup == 4 ? 2 : 1;
 constexpr int kSlotsPerWave = 64 / kGroup;
 
 struct PairArrays {
@@ -436,12 +440,12 @@ constexpr uint32_t kHitTmp = 16;  // a slot with more tile pairs (or any fallbac
 // the group's (uniform inside the group); returns the group's base (FILL) or nothing useful.
 template <bool WANT_BASE>
 __device__ __forceinline__ uint32_t wave_group_add(uint32_t* __restrict__ arr, uint32_t idx, uint32_t c, int lane) {
-    const int grp = lane >> 3;
+    const int grp = lane >> kGroupLog;
     uint32_t tot = 0, pre = 0;
     int leader = grp;
 #pragma unroll
-    for (int gq = 0; gq < 8; ++gq) {
-        const uint32_t t = __shfl(idx, gq << 3, 64), cc = __shfl(c, gq << 3, 64);
+    for (int gq = 0; gq < kSlotsPerWave; ++gq) {
+        const uint32_t t = __shfl(idx, gq << kGroupLog, 64), cc = __shfl(c, gq << kGroupLog, 64);
         if (t == idx) {
             tot += cc;
             if (gq < grp) pre += cc;
@@ -449,12 +453,12 @@ __device__ __forceinline__ uint32_t wave_group_add(uint32_t* __restrict__ arr, u
         }
     }
     uint32_t rb = 0;
-    if ((lane & 7) == 0 && leader == grp && tot) {
+    if ((lane & (kGroup - 1)) == 0 && leader == grp && tot) {
         if (WANT_BASE) rb = atomicAdd(&arr[idx], tot);
         else atomicAdd(&arr[idx], tot);
     }
     if (!WANT_BASE) return 0u;
-    rb = __shfl(rb, leader << 3, 64);
+    rb = __shfl(rb, leader << kGroupLog, 64);
     return rb + pre;
 }
 
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
             const bool f0 = c0 && P.tile_flag[T0], f1 = c1 && P.tile_flag[T1];
             const uint32_t fb_total = c2 + (f0 ? c0 : 0u) + (f1 ? c1 : 0u);
             // groups that are not live or have nothing for a stream get an index of their own
-            const uint32_t none = 0xFFFFFF00u + (uint32_t)(lane >> 3);
+            const uint32_t none = 0xFFFFFF00u + (uint32_t)(lane >> kGroupLog);
             // places inside the tiles' ranges come from the prefix sums of k_tile_count: no cursor, no atomic, and the
             // pairs of a tile are in slot order whatever the waves' timing
             const uint32_t r0 = (live && c0 && !f0) ? P.slot_off[2 * p] : 0u;

@@ -215,3 +215,44 @@ def test_mixed_pile_20k_600_frames_statistics():
     assert g.stats().overflow == 0
     compare_statistics(stats[0], stats[1], 0.25, "pile20k")
     assert stats[0]["p99"] < 0.04 and stats[0]["p50"] < 0.006
+
+
+def test_granular_slab_one_gpus_share_500k_one_tick():
+    """configs[4] (4 M circles over 8 GPUs) at ONE GPU's share, 500 k circles, settled on the GPU: broadphase objects
+    bit-exact against the oracle, one tick within tolerance (the contacts' hook is skipped: 1.4 M manifolds on the host)."""
+    s = settle_on_gpu(scenes.granular_slab(n=500_000, width=5000), 300)
+    check_one_tick(s, min_pairs=1_200_000, min_manifolds=900_000, contacts=False)
+
+
+def test_granular_slab_in_eight_logical_slabs_equals_the_oracles_slabs():
+    """configs[4]'s decomposition in small: a 160 k-circle slab cut into EIGHT slabs on x (eight worlds on the one GPU,
+    halos copied device to device per substep, the halo guard armed), against the same eight slabs on the oracle: one tick
+    bit-comparable, then 60 ticks stay a pile at rest."""
+    from oracle.oracle import OracleWorld
+    from starframe_amd.slab import LocalSlabs
+    from starframe_amd.world import World
+
+    s = settle_on_gpu(scenes.granular_slab(n=160_000, width=1600), 400)
+    G = LocalSlabs(s, 8, World, halo=2.0)
+    O = LocalSlabs(s, 8, OracleWorld, halo=2.0)
+    assert sum(len(p.recv_idx) for p in G.plans) > 8000          # 14 cut faces, some hundred ghosts each
+    G.step(DT)
+    O.step(DT)
+    gp, gr, gv, ga = G.gather()
+    op, orr, ov, oa = O.gather()
+    assert rel_err(gp, op, floor=1.0) <= TOL and rel_err(gr, orr, floor=1.0) <= TOL
+    assert rel_err(gv, ov, floor=1.0) <= 1e-4
+    O.close()
+    W = World.from_scene(s)          # the same pile undecomposed: released from the damped settling, both sag alike
+    W.step(DT)
+    for _ in range(60):
+        G.step(DT)
+        W.step(DT)
+    pos, ref = G.gather()[0], W.poses()[0]
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    assert np.isfinite(pos).all() and pos[dyn, 1].min() > -0.05
+    assert abs(pos[dyn, 1].mean() - ref[dyn, 1].mean()) < 0.003
+    assert abs(np.percentile(pos[dyn, 1], 99.5) - np.percentile(ref[dyn, 1], 99.5)) < 0.02
+    W.close()
+    assert all(w.stats().overflow == 0 for w in G.worlds)
+    G.close()
