@@ -96,6 +96,8 @@ typedef struct sfx_config {
 
 #define SFX_CFG_RESERVED 1u      /* not used: the tick is not launch-bound (host enqueue 0.08 ms of a 1 ms tick) */
 #define SFX_CFG_NO_FRICTION 2u   /* skip static + dynamic friction (debug)          */
+#define SFX_CFG_ONE_LEVEL 4u     /* broadphase grid without its second level: every collider too large for a base
+                                    cell goes on the flat list (tested against everything)                     */
 
 /* collider component (BASELINE.json:5 "body/collider/material components"; SURVEY.md section 8a row a4: shape,
  * local offset, layer mask).  The shape sits at a LOCAL POSE in the body's frame: local_pos (metres) and

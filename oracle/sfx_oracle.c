@@ -742,15 +742,26 @@ static void emit_pair(sfo_world* w, uint32_t i, uint32_t j) {
     w->n_pairs++;
 }
 
+/* [DESIGN] DESIGN.md "Contract / grid", two levels (upstream's broadphase is a hierarchical grid: SURVEY.md 8a row a7).
+ * Level 0: cells of the base size, for the SMALL colliders (extent <= 0.9 cell on both axes).  Level 1: cells eight
+ * times as wide on the same torus, for the MEDIUM ones (not small, extent <= 0.9 of such a cell); what is larger still
+ * stays on the flat list.  Every collider is sorted into one bucket: the home cell of its AABB's low corner at its own
+ * level.  Emission per small slot: its own cell (later slots), the forward neighbours (1,0) (-1,1) (0,1) (1,1), the
+ * medium colliders homed in the level-1 cells [c1(lo) - 1, c1(hi)] on both axes (an overlapping medium's home cell lies
+ * there: its box is less than 1.9 cells wide), then the flat list; per medium slot the same forward scheme on level 1,
+ * then the flat list; per listed collider every later one.  SFX_CFG_ONE_LEVEL puts the medium ones on the flat list. */
 static void grid_pairs(sfo_world* w) {
     uint32_t n = w->n, GX = 1u << w->gxl, GY = 1u << w->gyl, ncell = GX * GY;
-    uint32_t* start = (uint32_t*)calloc((size_t)ncell + 1, sizeof(uint32_t));
+    const int two = !(w->cfg.flags & SFX_CFG_ONE_LEVEL);
+    uint32_t gxl1 = w->gxl - 3u, gyl1 = w->gyl - 3u, GX1 = 1u << gxl1, GY1 = 1u << gyl1, ncell1 = two ? GX1 * GY1 : 0u;
+    float inv1 = w->inv_cell * 0.125f;
+    uint32_t* start = (uint32_t*)calloc((size_t)ncell + ncell1 + 1, sizeof(uint32_t));
     uint32_t* bucket = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
     int32_t *ccx = w->ccx, *ccy = w->ccy;
     uint32_t* slot_id = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
     uint32_t* large = (uint32_t*)malloc((n ? n : 1) * sizeof(uint32_t));
-    uint32_t ns = 0, nl = 0;
-    float lim = 0.9f * w->cell;
+    uint32_t ns = 0, nm = 0, nl = 0;
+    float lim = 0.9f * w->cell, lim1 = 0.9f * (8.0f * w->cell);
     for (uint32_t i = 0; i < n; ++i) {
         bucket[i] = 0xFFFFFFFFu;
         w->is_small[i] = 0;
@@ -763,29 +774,50 @@ static void grid_pairs(sfo_world* w) {
             start[bucket[i] + 1]++;
             w->is_small[i] = 1;
             ++ns;
+        } else if (two && (A[2] - A[0]) <= lim1 && (A[3] - A[1]) <= lim1) {
+            ccx[i] = cell_coord(A[0], inv1);      /* home cell at level 1 */
+            ccy[i] = cell_coord(A[1], inv1);
+            bucket[i] = ncell + ((((uint32_t)ccy[i] & (GY1 - 1)) << gxl1) | ((uint32_t)ccx[i] & (GX1 - 1)));
+            start[bucket[i] + 1]++;
+            ++nm;
         } else {
             large[nl++] = i;
         }
     }
-    for (uint32_t c = 0; c < ncell; ++c) start[c + 1] += start[c];
-    uint32_t* fill = (uint32_t*)malloc((size_t)ncell * sizeof(uint32_t));
-    memcpy(fill, start, (size_t)ncell * sizeof(uint32_t));
+    for (uint32_t c = 0; c < ncell + ncell1; ++c) start[c + 1] += start[c];
+    uint32_t* fill = (uint32_t*)malloc(((size_t)ncell + ncell1 + 1) * sizeof(uint32_t));
+    memcpy(fill, start, ((size_t)ncell + ncell1) * sizeof(uint32_t));
     for (uint32_t i = 0; i < n; ++i)
-        if (bucket[i] != 0xFFFFFFFFu) slot_id[fill[bucket[i]]++] = i;
-    w->n_small = ns; w->n_large = nl;
+        if (bucket[i] != 0xFFFFFFFFu) slot_id[fill[bucket[i]]++] = i;   /* small slots [0, ns), medium slots [ns, ns + nm) */
+    w->n_small = ns; w->n_large = nm + nl;
     w->n_pairs = 0; w->overflow = 0;
     static const int off[5][2] = {{0, 0}, {1, 0}, {-1, 1}, {0, 1}, {1, 1}};
-    for (uint32_t p = 0; p < ns; ++p) {
+    for (uint32_t p = 0; p < ns + nm; ++p) {
         uint32_t i = slot_id[p];
+        const int lvl = p >= ns;
         for (int o = 0; o < 5; ++o) {
             int32_t nx = ccx[i] + off[o][0], ny = ccy[i] + off[o][1];
-            uint32_t nb = (((uint32_t)ny & (GY - 1)) << w->gxl) | ((uint32_t)nx & (GX - 1));
+            uint32_t nb = lvl ? ncell + ((((uint32_t)ny & (GY1 - 1)) << gxl1) | ((uint32_t)nx & (GX1 - 1)))
+                              : (((uint32_t)ny & (GY - 1)) << w->gxl) | ((uint32_t)nx & (GX - 1));
             for (uint32_t q = start[nb]; q < start[nb + 1]; ++q) {
                 uint32_t j = slot_id[q];
                 if (ccx[j] != nx || ccy[j] != ny) continue;
                 if (o == 0 && q <= p) continue;
                 emit_pair(w, i, j);
             }
+        }
+        if (!lvl && nm) { /* a small collider against the medium ones around it */
+            const float* A = &w->aabb[4 * i];
+            int32_t x0 = cell_coord(A[0], inv1) - 1, x1 = cell_coord(A[2], inv1);
+            int32_t y0 = cell_coord(A[1], inv1) - 1, y1 = cell_coord(A[3], inv1);
+            for (int32_t Y = y0; Y <= y1; ++Y)
+                for (int32_t X = x0; X <= x1; ++X) {
+                    uint32_t nb = ncell + ((((uint32_t)Y & (GY1 - 1)) << gxl1) | ((uint32_t)X & (GX1 - 1)));
+                    for (uint32_t q = start[nb]; q < start[nb + 1]; ++q) {
+                        uint32_t j = slot_id[q];
+                        if (ccx[j] == X && ccy[j] == Y) emit_pair(w, i, j);
+                    }
+                }
         }
         for (uint32_t l = 0; l < nl; ++l) emit_pair(w, i, large[l]);
     }

@@ -75,7 +75,7 @@ struct sfx_world {
     int device = 0;
     // resolved
     float cell = 1.0f, inv_cell = 1.0f;
-    uint32_t gxl = 2, gyl = 2, ncell = 16, max_pairs = 0;
+    uint32_t gxl = 2, gyl = 2, ncell = 16, ncell1 = 0, max_pairs = 0;   // ncell1: cells of the grid's second level (0: one level)
     // scene
     // n counts ENTRIES: the nb bodies (entry k < nb = body k with its own collider), then one entry per further collider
     // (include/sfx.h sfx_collider.body); every per-entry device array has n elements, the host vectors below nb
@@ -170,6 +170,7 @@ struct sfx_world {
     uint32_t launches = 0;
     uint32_t color_grid = 1024, tile_grid[4] = {1024, 1024, 1024, 1024}, tile_grid_max = 8192;
     uint32_t group = 4;  // tiles a colouring workgroup cuts into batches (from the pair density of an earlier tick)
+    uint32_t group_cap = kMaxGroup;  // halved whenever a batch ran out of LDS slots for colliders outside its cells (kOvfExt)
     bool ticked = false;
     // profiling
     bool profiling = false;
@@ -339,6 +340,8 @@ void resolve_grid(sfx_world* w) {
     if (w->tly < gy && gy < w->tly + 2u) w->tly = gy;   // fewer than four tile rows: one row (strips)
     w->gxl = gx; w->gyl = gy;
     w->ncell = (1u << gx) * (1u << gy);
+    // second level: cells eight times as wide on the same torus (gx >= tile width + 2 >= 3 and gy >= 3 above)
+    w->ncell1 = (w->cfg.flags & SFX_CFG_ONE_LEVEL) ? 0u : (1u << (gx - 3u)) * (1u << (gy - 3u));
     w->ntiles = w->ncell >> (w->tlx + w->tly);
 }
 
@@ -347,6 +350,10 @@ GridParams grid_params(const sfx_world* w) {
     g.inv_cell = w->inv_cell;
     g.small_lim = 0.9f * w->cell;
     g.gxl = w->gxl; g.gyl = w->gyl; g.ncell = w->ncell;
+    g.ncell_all = w->ncell + w->ncell1;
+    g.gxl1 = w->gxl - 3u; g.gyl1 = w->gyl - 3u;
+    g.inv_cell1 = w->inv_cell * 0.125f;
+    g.medium_lim = w->ncell1 ? 0.9f * (8.0f * w->cell) : 0.0f;
     g.tlx = w->tlx; g.tly = w->tly; g.ntiles = w->ntiles;
     g.pstride = w->ntiles;   // every phase (class of pairs) may have a batch per tile
     return g;
@@ -414,7 +421,7 @@ void point_zero_block(sfx_world* w) {
     uint32_t* base = w->zero.p + (size_t)w->zero_half * (w->zero_bytes / 4);
     w->ctr = reinterpret_cast<Counters*>(base);
     w->cell_start = base + sizeof(Counters) / 4;
-    w->tile_cnt = w->cell_start + ((size_t)w->ncell + 1 + pad);
+    w->tile_cnt = w->cell_start + ((size_t)w->ncell + w->ncell1 + 1 + pad);
     w->tile_fill = w->tile_cnt + ((size_t)w->ntiles + 1 + pad);
     w->tile_flag = w->tile_fill + w->ntiles;
     w->tile_batch = w->tile_flag + w->ntiles;   // [4 phases][ntiles]
@@ -485,7 +492,7 @@ int broadphase(sfx_world* w, float dt) {
                          w->lpose.p, w->poly.p, w->cfg.aabb_margin, w->cfg.vel_pad_max, dt, g, w->aabb.p, w->bucket.p, w->cellxy.p, w->cell_start,
                          w->large_tmp.p, w->large_cap, w->ctr, stale_half, n16, w->sticky.p,
                          (w->halo_guard > 0.0f && w->halo_x0.n == n) ? w->halo_x0.p : (const float*)nullptr, w->halo_guard); }
-    int rc = scan_u32(w, w->cell_start, w->ncell + 1, w->cell_fill.p);
+    int rc = scan_u32(w, w->cell_start, w->ncell + w->ncell1 + 1, w->cell_fill.p);
     if (rc) return rc;
     { Prof p(w, SFX_K_SCATTER, n);
       hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(kBlock), 0, w->stream, n, w->bucket.p, w->cell_fill.p, w->tmp_id.p); }
@@ -562,6 +569,10 @@ void adopt_counters(sfx_world* w) {
             const uint32_t fit = std::max((2u * kBatchP / 3u) / per_tile, 1u);
             w->group = std::min(std::min(std::max(want, 1u), fit), (uint32_t)kMaxGroup);
         }
+        // a batch's pairs touched more than kMaxExt colliders outside its cells (many mid-size or large colliders over one
+        // batch of tiles): that tick dropped those pairs and says so; from now on batches hold half as many tiles
+        if ((w->stale.overflow & kOvfExt) && w->group_cap > 1u) w->group_cap = std::max(1u, std::min(w->group, w->group_cap) / 2u);
+        if (!w->group_fixed) w->group = std::min(w->group, w->group_cap);
         uint32_t groups = 0;
         for (int ph = 0; ph < 4; ++ph) {
             const uint32_t b = w->stale.n_batches[ph];
@@ -906,14 +917,14 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     // fallback list: pairs with a large dynamic collider and pairs of tiles over capacity
     w->fb_cap = std::max(65536u, w->max_pairs / 8u);
     const size_t pad = kScanItems;
-    const size_t words = sizeof(Counters) / 4 + ((size_t)w->ncell + 1 + pad) + ((size_t)w->ntiles + 1 + pad) +
+    const size_t words = sizeof(Counters) / 4 + ((size_t)w->ncell + w->ncell1 + 1 + pad) + ((size_t)w->ntiles + 1 + pad) +
                          6 * (size_t)w->ntiles;   // tile_fill, tile_flag, tile_batch per phase
     const size_t words16 = (words + 3) & ~(size_t)3;  // cleared by k_zero in 16-byte units
     ALLOC(w, w->zero, 2 * words16);
     w->zero_bytes = words16 * 4;
     w->zero_half = 0;
     point_zero_block(w);
-    ALLOC(w, w->cell_fill, (size_t)w->ncell + 1 + pad);
+    ALLOC(w, w->cell_fill, (size_t)w->ncell + w->ncell1 + 1 + pad);
     const size_t max_batches = 4 * (size_t)w->ntiles;   // per phase at most one per tile
     ALLOC(w, w->active, 2 * (size_t)w->ntiles); ALLOC(w, w->batches, max_batches);
     ALLOC(w, w->rawp, w->max_pairs); ALLOC(w, w->tpair, w->max_pairs); ALLOC(w, w->torder, w->max_pairs);
@@ -1364,6 +1375,7 @@ int build_query_index(sfx_world* w, const QueryBuffers& Q) {
     uint32_t* qcs = Q.zero + sizeof(Counters) / 4;
     GridParams g = grid_params(w);
     g.tlx = 0; g.tly = 0; g.ntiles = w->ncell; g.pstride = 0;  // plain row-major buckets
+    g.ncell_all = w->ncell; g.medium_lim = 0.0f;                 // the query index has one level
     const uint32_t gb = cdiv(std::max(n, 1u), kBlock);
     { Prof p(w, SFX_K_QUERY, 0);
       const uint32_t n16 = (uint32_t)(Q.zero_bytes / 16);
@@ -1801,7 +1813,7 @@ int sfx_stats(sfx_world* w, sfx_frame_stats* out) {
     rc = sync_counters(w, &c, w->ctr);
     if (rc) return rc;
     w->launches = saved;
-    out->n_small = c.n_small; out->n_large = c.n_large; out->n_pairs = c.n_pairs; out->n_colors = c.n_colors;
+    out->n_small = c.n_small; out->n_large = c.n_large + c.n_medium;   /* everything not in a base cell */ out->n_pairs = c.n_pairs; out->n_colors = c.n_colors;
     uint32_t dev_sticky = 0;
     HIPCHK(w, hipMemcpy(&dev_sticky, w->sticky.p, sizeof(uint32_t), hipMemcpyDeviceToHost));
     out->n_leftover = c.n_leftover; out->overflow = c.overflow | dev_sticky | w->ovf_host;   // this tick's and every unreported earlier one's

@@ -79,7 +79,8 @@ struct Counters {
     uint32_t run_cursor;    // batches that have written their colour run table
     uint32_t item_ticket[2];  // next batch of a tile-solve launch, handed out in item order; launches alternate between
                               // the two counters and every launch clears the one its successor will use
-    uint32_t pad3[3];
+    uint32_t n_medium;      // colliders sorted into the grid's second level (written by k_finalize_slots)
+    uint32_t pad3[2];
 };
 static_assert(sizeof(Counters) % 16 == 0, "the per-tick block is cleared in 16-byte units");
 static_assert(offsetof(Counters, overflow) == 12, "k_zero / k_aabb_count fold word 3 of the block into the sticky overflow word");
@@ -92,7 +93,17 @@ struct GridParams {
     uint32_t tlx, tly; // log2 tile width / height (cells); tly == gyl: full-height strips
     uint32_t ntiles;
     uint32_t pstride;  // entries per phase in the tile lists and batch tables
+    // second level (DESIGN.md "Contract / grid"): cells eight times as wide on the same torus for the MEDIUM colliders
+    // (too large for a base cell, extent <= medium_lim); their buckets follow the base cells' in cell_start, so the
+    // sorted order is small slots, medium slots, then the flat list.  medium_lim == 0: one level (ncell_all == ncell).
+    uint32_t ncell_all;
+    uint32_t gxl1, gyl1;
+    float inv_cell1, medium_lim;
 };
+
+__device__ __forceinline__ uint32_t bucket1_of(int32_t cx, int32_t cy, const GridParams& g) {
+    return g.ncell + ((((uint32_t)cy & ((1u << g.gyl1) - 1u)) << g.gxl1) | ((uint32_t)cx & ((1u << g.gxl1) - 1u)));
+}
 
 // wrapped tile index of true tile coordinates
 __device__ __forceinline__ uint32_t tile_of(int32_t tx, int32_t ty, const GridParams& g) {
@@ -211,6 +222,11 @@ __global__ __launch_bounds__(kBlock) void k_aabb_count(uint32_t n, const float4*
         if ((A.z - A.x) <= g.small_lim && (A.w - A.y) <= g.small_lim) {
             const int32_t cx = cell_coord(A.x, g.inv_cell), cy = cell_coord(A.y, g.inv_cell);
             bk = bucket_of(cx, cy, g);
+            cellxy[i] = make_int2(cx, cy);
+            atomicAdd(&cell_count[bk], 1u);
+        } else if ((A.z - A.x) <= g.medium_lim && (A.w - A.y) <= g.medium_lim) {   // (never with one level: medium_lim == 0)
+            const int32_t cx = cell_coord(A.x, g.inv_cell1), cy = cell_coord(A.y, g.inv_cell1);
+            bk = bucket1_of(cx, cy, g);
             cellxy[i] = make_int2(cx, cy);
             atomicAdd(&cell_count[bk], 1u);
         } else {
@@ -373,9 +389,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize_slots(uint32_t n, GridParam
                                                             uint32_t* __restrict__ sorted_id, float4* __restrict__ sorted_aabb,
                                                             int2* __restrict__ sorted_cell, Counters* __restrict__ ctr) {
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    const uint32_t ns = cell_start[g.ncell];
+    const uint32_t ns = cell_start[g.ncell_all];   // grid-sorted slots: the small colliders, then the medium ones
     const uint32_t nl = min(ctr->n_large, large_cap);
-    if (p == 0) ctr->n_small = ns;
+    if (p == 0) { ctr->n_small = cell_start[g.ncell]; ctr->n_medium = ns - cell_start[g.ncell]; }
     if (p < ns) {
         const uint32_t i = tmp_id[p];
         const uint32_t bk = bucket[i];
@@ -473,9 +489,10 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
     const int gshift = lane & ~(kGroup - 1);     // first lane of the group
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     const uint32_t nwaves = (gridDim.x * kBlock) >> 6;
-    const uint32_t ns = cell_start[g.ncell];
+    const uint32_t ns = cell_start[g.ncell];       // small slots [0, ns)
+    const uint32_t nsm = cell_start[g.ncell_all];  // medium slots [ns, nsm): sorted by level-1 cell; then the flat list
     const uint32_t nl = min(ctr->n_large, large_cap);
-    const uint32_t nact = ns + nl;
+    const uint32_t nact = nsm + nl;
     const uint64_t below = (1ull << gl) - 1ull;  // group-local lanes before this one
     for (uint32_t p0 = wave * kSlotsPerWave; p0 < nact; p0 += nwaves * kSlotsPerWave) {
         const uint32_t p = p0 + (uint32_t)(lane / kGroup);
@@ -529,18 +546,19 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
         for (int r = 0; r < 6; ++r) {
             uint32_t qs = 0, qe = 0;
             int32_t ncx = 0, ncy = 0;
-            if (test && p < ns) {
+            if (test && p < nsm) {   // a grid-sorted slot: the same forward scheme at its own level (a medium slot: level 1)
+                const bool lvl1 = p >= ns;
                 if (r == 0) {
                     ncx = c.x; ncy = c.y;
-                    qs = p + 1; qe = cell_start[bucket_of(ncx, ncy, g) + 1];
+                    qs = p + 1; qe = cell_start[(lvl1 ? bucket1_of(ncx, ncy, g) : bucket_of(ncx, ncy, g)) + 1];
                 } else if (r < 5) {
                     const int dx = (r == 1) ? 1 : (r == 2) ? -1 : (r == 3) ? 0 : 1;
                     const int dy = (r == 1) ? 0 : 1;
                     ncx = c.x + dx; ncy = c.y + dy;
-                    const uint32_t bk = bucket_of(ncx, ncy, g);
+                    const uint32_t bk = lvl1 ? bucket1_of(ncx, ncy, g) : bucket_of(ncx, ncy, g);
                     qs = cell_start[bk]; qe = cell_start[bk + 1];
                 } else {
-                    qs = ns; qe = nact;
+                    qs = nsm; qe = nact;
                 }
             } else if (test && r == 5) {
                 qs = p + 1; qe = nact;  // large slot: later larges only
@@ -550,6 +568,28 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
         }
         const bool small_slot = p < ns;
         const uint32_t L = off_[6];
+        // a tested candidate joins its stream: count pass -> hit_tmp + stream sizes, fill pass -> the pair lists
+        auto emit = [&](bool hit, uint32_t j, uint32_t q, int st, uint32_t cls) {
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const bool mine = hit && st == s3;
+                const uint64_t bal = (__ballot(mine) >> gshift) & ((1ull << kGroup) - 1ull);
+                if (!FILL && mine && s3 < 2) {
+                    const uint32_t idx = cnt[s3] + (uint32_t)__popcll(bal & below);
+                    if (idx < kHitTmp) P.hit_tmp[(size_t)p * kHitTmp + (s3 == 0 ? idx : kHitTmp - 1u - idx)] = make_uint2(j, q | (cls << kClassShift));
+                }
+                if (FILL && mine) {
+                    const uint32_t dst = base[s3] + cnt[s3] + (uint32_t)__popcll(bal & below);
+                    const bool swap = j < i;
+                    if (to_fb[s3]) {
+                        if (dst < P.fb_cap) P.fpairs[dst] = make_uint2(swap ? j : i, swap ? i : j);
+                    } else if (dst < P.max_pairs) {
+                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, (swap ? p : q) | (cls << kClassShift));
+                    }
+                }
+                cnt[s3] += (uint32_t)__popcll(bal);
+            }
+        };
         for (uint32_t x0 = 0; __any(x0 < L); x0 += kGroup) {
             const uint32_t x = x0 + (uint32_t)gl;
             int r = 0;
@@ -560,8 +600,8 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                 if (x >= off_[k]) { r = k; q = qs_[k] + (x - off_[k]); ncx = ncx_[k]; ncy = ncy_[k]; }
             bool hit = false;
             uint32_t j = 0;
-            // stream: a neighbour cell in the tile to the left -> that tile's stream; a large slot's pairs and a small
-            // slot's pair with a large dynamic collider -> the fallback list
+            // stream: a neighbour cell in the tile to the left -> that tile's stream; a slot that is not small (all its
+            // pairs) and a small slot's pair with a large dynamic collider -> the fallback list
             int st = (!small_slot) ? 2 : (r >= 1 && r < 5 && (ncx >> g.tlx) < txp) ? 1 : 0;
             // class of a tile pair (DESIGN.md "Contract / tiles"): 0 interior, 1 x seam, 2 y seam, 3 corner -- where the two
             // home tiles lie; it rides in the two top bits of the pair's second slot word
@@ -582,24 +622,52 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                     if ((fi.w | fj.w) & kFiltFurther) st = 2;  // a further collider of a dynamic body: solved on the body
                 }
             }
+            emit(hit, j, q, st, cls);
+        }
+        // Second level: a small slot against the medium colliders homed in the level-1 cells [c1(lo) - 1, c1(hi)] on both
+        // axes (an overlapping medium collider's home cell lies there: its box is under 1.9 such cells wide).  Up to nine
+        // cells, joined end to end like the ranges above; nothing of this runs in a scene without medium colliders.
+        if (nsm > ns) {
+            uint32_t qs1[9], off1[10];
+            int32_t X0 = 0, Y0 = 0;
+            uint32_t nx1 = 0, ny1 = 0;
+            if (test && small_slot) {
+                X0 = cell_coord(Ai.x, g.inv_cell1) - 1; Y0 = cell_coord(Ai.y, g.inv_cell1) - 1;
+                nx1 = (uint32_t)(cell_coord(Ai.z, g.inv_cell1) - X0) + 1u; ny1 = (uint32_t)(cell_coord(Ai.w, g.inv_cell1) - Y0) + 1u;
+                nx1 = min(nx1, 3u); ny1 = min(ny1, 3u);   // (a small box spans at most two level-1 cells per axis)
+            }
+            off1[0] = 0u;
 #pragma unroll
-            for (int s3 = 0; s3 < 3; ++s3) {
-                const bool mine = hit && st == s3;
-                const uint64_t bal = (__ballot(mine) >> gshift) & ((1ull << kGroup) - 1ull);
-                if (!FILL && mine && s3 < 2) {
-                    const uint32_t idx = cnt[s3] + (uint32_t)__popcll(bal & below);
-                    if (idx < kHitTmp) P.hit_tmp[(size_t)p * kHitTmp + (s3 == 0 ? idx : kHitTmp - 1u - idx)] = make_uint2(j, q | (cls << kClassShift));
+            for (int k = 0; k < 9; ++k) {
+                uint32_t qs = 0, qe = 0;
+                if ((uint32_t)k < nx1 * ny1) {
+                    const uint32_t bk = bucket1_of(X0 + (int32_t)((uint32_t)k % nx1), Y0 + (int32_t)((uint32_t)k / nx1), g);
+                    qs = cell_start[bk]; qe = cell_start[bk + 1];
                 }
-                if (FILL && mine) {
-                    const uint32_t dst = base[s3] + cnt[s3] + (uint32_t)__popcll(bal & below);
-                    const bool swap = j < i;
-                    if (to_fb[s3]) {
-                        if (dst < P.fb_cap) P.fpairs[dst] = make_uint2(swap ? j : i, swap ? i : j);
-                    } else if (dst < P.max_pairs) {
-                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, (swap ? p : q) | (cls << kClassShift));
+                qs1[k] = qs;
+                off1[k + 1] = off1[k] + (qe - qs);
+            }
+            const uint32_t L1 = off1[9];
+            for (uint32_t x0 = 0; __any(x0 < L1); x0 += kGroup) {
+                const uint32_t x = x0 + (uint32_t)gl;
+                uint32_t k1 = 0, q = qs1[0] + x;
+#pragma unroll
+                for (int k = 1; k < 9; ++k)
+                    if (x >= off1[k]) { k1 = (uint32_t)k; q = qs1[k] + (x - off1[k]); }
+                bool hit = false;
+                uint32_t j = 0;
+                int st = 0;   // small + medium: the small collider's tile, unless the medium one is dynamic
+                if (x < L1) {
+                    const int2 cq = sorted_cell[q];
+                    if (cq.x == X0 + (int32_t)(k1 % nx1) && cq.y == Y0 + (int32_t)(k1 / nx1) && aabb_overlap(Ai, sorted_aabb[q])) {
+                        j = sorted_id[q];
+                        const uint4 fj = filt[j];
+                        hit = pair_filter(fi, fj);
+                        if (fj.w & kFiltDynamic) st = 2;
+                        if ((fi.w | fj.w) & kFiltFurther) st = 2;
                     }
                 }
-                cnt[s3] += (uint32_t)__popcll(bal);
+                emit(hit, j, q, st, 0u);
             }
         }
         if (FILL && copy) {

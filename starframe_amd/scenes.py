@@ -429,10 +429,12 @@ def granular_slab(n=4_000_000, seed=0x5EED0005, width=40000, pitch=0.22, wall_hh
 
 # ------------------------------------------------------------------ small test scenes
 
-def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, speed=1.0, offsets=0.0, compounds=0.0):
+def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, speed=1.0, offsets=0.0, compounds=0.0, platforms=0):
     """Overlapping random shapes of every type with random velocities: a broadphase and
     narrowphase stress scene for parity tests.  offsets: fraction of bodies whose shape has a local pose;
-    compounds: fraction of bodies that get one or two further colliders (and one more on every static)."""
+    compounds: fraction of bodies that get one or two further colliders (and one more on every static);
+    platforms: that many mid-size static rects (0.4 .. 1.6 m half extents) strewn over the scene and a tenth as many
+    mid-size DYNAMIC boxes -- the colliders the second level of the broadphase grid is for."""
     rng = np.random.default_rng(seed)
     b = SceneBuilder(f"soup{n}_{seed}", materials=[(0.1, 0.5, 0.4), (0.6, 0.8, 0.6), (0.0, 0.2, 0.1)])
     for i in range(n):
@@ -465,6 +467,14 @@ def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, sp
         b.static_rect((0.0, -extent - 0.5), extent + 2.0, 0.5)
         b.static_rect((-extent - 1.0, 0.0), 0.5, extent + 1.0)
         b.static_rect((extent + 1.0, 0.0), 0.5, extent + 1.0, angle=0.1)
+    if platforms:
+        prng = np.random.default_rng(seed + 104729)
+        for _ in range(platforms):
+            b.static_rect(tuple(prng.uniform(-extent, extent, 2)), prng.uniform(0.4, 1.6), prng.uniform(0.1, 0.5),
+                          angle=float(prng.uniform(-0.5, 0.5)))
+        for _ in range(max(platforms // 10, 1)):
+            b.rect(tuple(prng.uniform(-extent, extent, 2)), prng.uniform(0.5, 0.9), prng.uniform(0.4, 0.8),
+                   vel=tuple(prng.normal(0, speed, 2)), angvel=float(prng.normal(0, 1.0)))
     if compounds:
         crng = np.random.default_rng(seed + 7919)
         for i in range(n):

@@ -601,3 +601,65 @@ def test_dumbbell_and_static_level_geometry_on_the_gpu():
     assert rel_err(p, o2.poses()[0], floor=1.0) <= 1e-4
     st = g2.stats()
     assert st.n_fallback == 0 and st.n_tiles >= 1 and st.overflow == 0
+
+
+def test_second_grid_level_matches_oracle_and_the_one_level_grid():
+    """The broadphase grid's second level (DESIGN.md "Contract / grid"; SURVEY.md 8a row a7: upstream's HGrid): a soup with
+    400 mid-size static platforms and 40 mid-size dynamic boxes.  AABBs, pairs, owner units, colours bit-exact against the
+    oracle; the same world with SFX_CFG_ONE_LEVEL (every collider too large for a base cell on the flat list) has the
+    same pairs, owners and colours and, after ten ticks, the same poses bit for bit."""
+    from oracle.oracle import ORDER_COLORED
+
+    s = scenes.random_soup(4000, seed=41, extent=16.0, platforms=400)
+    # square tiles: with strips a batch of sixteen 1.2 m columns spans the whole soup and its pairs would touch more than
+    # the 64 outside colliders a batch has LDS slots for (the next test is about that)
+    g, o = make_pair(s, cell_size=0.6, tile_cells_y=2)
+    from starframe_amd.world import World
+    g1 = World.from_scene(s, cell_size=0.6, tile_cells_y=2, flags=4)
+    for w in (g, o, g1):
+        w.broadphase(DT)
+    assert np.array_equal(g.aabbs().view(np.uint32), o.aabbs().view(np.uint32))
+    gp = g.pairs()
+    assert len(gp) > 8_000 and np.array_equal(gp, o.pairs()) and np.array_equal(gp, g1.pairs())
+    gk, gc, gt = colors_by_key(*g.pair_colors())
+    ok, oc, ot = colors_by_key(*o.pair_colors())
+    k1, c1, t1 = colors_by_key(*g1.pair_colors())
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot) and np.array_equal(gc, oc)
+    assert np.array_equal(gk, k1) and np.array_equal(gt, t1) and np.array_equal(gc, c1)
+    gs, os_ = g.stats(), o.stats()
+    assert (gs.n_small, gs.n_large, gs.n_pairs, gs.n_fallback, gs.n_tiles) == (os_.n_small, os_.n_large, os_.n_pairs, os_.n_fallback, os_.n_tiles)
+    assert gs.n_large >= 430 and gs.overflow == 0
+    for _ in range(10):
+        g.step(DT)
+        g1.step(DT)
+        o.step(DT, ORDER_COLORED)
+    assert np.array_equal(g.poses()[0].view(np.uint32), g1.poses()[0].view(np.uint32))
+    assert np.array_equal(g.velocities()[0].view(np.uint32), g1.velocities()[0].view(np.uint32))
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= 1e-4
+    assert g.stats().overflow == 0 and g1.stats().overflow == 0
+
+
+def test_batches_shrink_when_their_pairs_touch_too_many_outside_colliders():
+    """A batch of tiles keeps the colliders outside its cells that its pairs touch (container walls, platforms) in 64 LDS
+    slots.  The soup of 400 platforms under full-height strips overruns that: the ticks that did drop those pairs and say
+    so (overflow bit 64 -> SFX_ERR_CAPACITY at the next sync, once); the library then halves the tiles per batch until the
+    batches fit, and the run goes on without errors."""
+    from starframe_amd.world import SfxError, World
+
+    s = scenes.random_soup(4000, seed=41, extent=16.0, platforms=400)
+    w = World.from_scene(s, cell_size=0.6)
+    reported = clean = 0
+    for _ in range(12):
+        try:
+            for _ in range(9):       # the counters come back every eighth tick
+                w.step(DT)
+            w.sync()
+            clean += 1
+        except SfxError as e:
+            assert e.code == -4 and "64" in str(e)
+            reported += 1
+            clean = 0
+            w.sync()                 # reported once: the next sync is clean
+    assert reported >= 1 and clean >= 4, (reported, clean)
+    assert w.stats().overflow == 0
+    w.close()

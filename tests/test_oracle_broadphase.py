@@ -231,3 +231,41 @@ def test_reach_test_only_drops_pairs_that_cannot_touch(speed):
         con = w2.contacts()
         keys = (con["body_a"].astype(np.uint64) << np.uint64(32)) | con["body_b"].astype(np.uint64)
         assert not (set(int(x) for x in keys[con["count"] > 0]) & dropped)
+
+
+@pytest.mark.parametrize("seed", [5, 6])
+def test_second_grid_level_changes_nothing_but_the_cost(seed):
+    """Two-level grid (DESIGN.md "Contract / grid"; upstream's broadphase is a hierarchical grid): a soup with 120 mid-size
+    static platforms and a dozen mid-size dynamic boxes.  The medium colliders are sorted into level-1 cells instead of the
+    flat list: grid = sweep = brute force; SFX_CFG_ONE_LEVEL gives the same pairs, owners and colours; a small collider
+    with a static medium one stays in its tile, a dynamic medium one goes to the fallback list; ten ticks agree bit for bit."""
+    s = scenes.random_soup(1200, seed=seed, extent=10.0, platforms=120)
+    # (the cell size is set: derived from the largest dynamic body it would be 3 m here and the platforms small)
+    two, one = OracleWorld.from_scene(s, cell_size=0.6), OracleWorld.from_scene(s, cell_size=0.6, flags=4)
+    for w in (two, one):
+        w.broadphase(DT)
+    g, sw, br = two.pairs(), two.pairs_sweep(), two.pairs_brute()
+    assert len(g) > 2000 and np.array_equal(g, sw) and np.array_equal(g, br)
+    assert np.array_equal(g, one.pairs())
+    k2, c2, t2 = colors_by_key(*two.pair_colors())
+    k1, c1, t1 = colors_by_key(*one.pair_colors())
+    assert np.array_equal(k2, k1) and np.array_equal(c2, c1) and np.array_equal(t2, t1)
+    st2, st1 = two.stats(), one.stats()
+    assert st2.n_small == st1.n_small and st2.n_large == st1.n_large >= 120     # medium + listed colliders
+    # which colliders are medium: bounding boxes too large for a base cell, small enough for a level-1 cell
+    rc = two.resolved_config()
+    A = two.aabbs()
+    ext = np.maximum(A[:, 2] - A[:, 0], A[:, 3] - A[:, 1])
+    medium = (ext > np.float32(0.9) * np.float32(rc.cell_size)) & (ext <= np.float32(0.9) * (np.float32(8.0) * np.float32(rc.cell_size)))
+    assert medium.sum() >= 110
+    dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
+    a, b = (k2 >> np.uint64(32)).astype(np.int64), (k2 & np.uint64(0xFFFFFFFF)).astype(np.int64)
+    with_static_medium = (medium[b] & ~dyn[b] & ~medium[a]) | (medium[a] & ~dyn[a] & ~medium[b])
+    with_dynamic_medium = (medium[a] & dyn[a]) | (medium[b] & dyn[b])
+    assert with_static_medium.sum() > 300 and np.all(t2[with_static_medium & ~with_dynamic_medium] != 0xFFFFFFFF)
+    assert with_dynamic_medium.sum() > 20 and np.all(t2[with_dynamic_medium] == 0xFFFFFFFF)
+    for _ in range(10):
+        two.step(DT)
+        one.step(DT)
+    assert np.array_equal(two.poses()[0].view(np.uint32), one.poses()[0].view(np.uint32))
+    assert np.array_equal(two.velocities()[0].view(np.uint32), one.velocities()[0].view(np.uint32))
