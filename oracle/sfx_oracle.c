@@ -427,6 +427,7 @@ static int color_scratch_init(color_scratch* cs, uint32_t n_bodies) {
 
 static void color_scratch_free(color_scratch* cs) { free(cs->used); free(cs->claim); }
 
+#define SFO_LEFT_CAP 4096u /* = kLeftCap of the device code */
 typedef struct { uint64_t key; uint32_t idx; } key_idx;
 static int cmp_key_idx(const void* a, const void* b) {
     const key_idx *x = (const key_idx*)a, *y = (const key_idx*)b;
@@ -488,6 +489,8 @@ static uint32_t color_edges(color_scratch* cs, uint32_t ne, const uint32_t* idx,
         ++nl;
     }
     qsort(left, nl, sizeof(key_idx), cmp_key_idx);
+    if (nl > SFO_LEFT_CAP) *overflow = 1; /* [DESIGN] the serial finish of one list takes at most this many edges (the device's
+                                            * table); more is a reported capacity overflow, like a 65th colour */
     for (uint32_t q = 0; q < nl; ++q) {
         uint32_t e = left[q].idx, a = ea[e], b = eb[e];
         int da = DYN(a), db = DYN(b);
