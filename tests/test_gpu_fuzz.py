@@ -70,3 +70,39 @@ def test_random_scene_random_config(seed):
         assert rel_err(g.velocities()[0], o.velocities()[0], floor=1.0) <= 1e-4, cfg
     g.close()
     o.close()
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_random_slab_decompositions(seed):
+    """Slab decomposition under the same fuzz: a random container of circles, partly fallen, cut into 2..6 slabs on x;
+    the GPU worlds (halos copied device to device every substep) against the same slabs on the oracle: three ticks equal
+    within tolerance, every slab without overflow, and the gathered state equals what the slabs' owners hold."""
+    from oracle.oracle import OracleWorld
+    from starframe_amd.slab import LocalSlabs
+    from starframe_amd.world import World
+
+    rng = np.random.default_rng(5000 + seed)
+    n = int(rng.integers(600, 4000))
+    width = int(rng.integers(40, 160))
+    s = scenes.circles_container(n=n, width=width, floor_hw=width * 0.22 / 2 + 1.0, wall_hh=8.0, seed=0x5EED0000 + seed)
+    nslabs = int(rng.integers(2, 7))
+    w0 = World.from_scene(s)                      # let the lattice fall for a while, undecomposed
+    for _ in range(int(rng.integers(20, 90))):
+        w0.step(DT)
+    pos, rot = w0.poses()
+    vel, ang = w0.velocities()
+    w0.close()
+    s = s.with_state(pos, rot, vel, ang)
+    halo = float(rng.uniform(1.0, 2.5))
+    nslabs = max(2, min(nslabs, int(width * 0.22 / (2.2 * halo))))   # a slab is wider than two halos
+    G, O = LocalSlabs(s, nslabs, World, halo=halo), LocalSlabs(s, nslabs, OracleWorld, halo=halo)
+    for _ in range(3):
+        G.step(DT)
+        O.step(DT)
+    gp, gr, gv, ga = G.gather()
+    op, orr, ov, oa = O.gather()
+    assert rel_err(gp, op, floor=1.0) <= 1e-5 and rel_err(gr, orr, floor=1.0) <= 1e-5, (n, width, nslabs, halo)
+    assert rel_err(gv, ov, floor=1.0) <= 1e-4, (n, width, nslabs, halo)
+    assert all(w.stats().overflow == 0 for w in G.worlds)
+    G.close()
+    O.close()
