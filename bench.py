@@ -129,7 +129,19 @@ def cpu_baseline(scene, budget_s=15.0):
         "sample": f"{frames} ticks of the same settled {scene.name} scene ({n_dyn} bodies, {scene.substeps} substeps), "
                   f"sequential Gauss-Seidel order; this repo's CPU restatement, not starframe's Rust tick (unavailable)",
         "ms_per_step": 1e3 * el / frames,
+        "cpu_model": cpu_model(),
     }
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def load_traffic(cls):
