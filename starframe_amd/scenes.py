@@ -429,12 +429,13 @@ def granular_slab(n=4_000_000, seed=0x5EED0005, width=40000, pitch=0.22, wall_hh
 
 # ------------------------------------------------------------------ small test scenes
 
-def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, speed=1.0, offsets=0.0, compounds=0.0, platforms=0):
+def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, speed=1.0, offsets=0.0, compounds=0.0, platforms=0, joints=0.0):
     """Overlapping random shapes of every type with random velocities: a broadphase and
     narrowphase stress scene for parity tests.  offsets: fraction of bodies whose shape has a local pose;
     compounds: fraction of bodies that get one or two further colliders (and one more on every static);
     platforms: that many mid-size static rects (0.4 .. 1.6 m half extents) strewn over the scene and a tenth as many
-    mid-size DYNAMIC boxes -- the colliders the second level of the broadphase grid is for."""
+    mid-size DYNAMIC boxes -- the colliders the second level of the broadphase grid is for; joints: fraction of bodies that
+    get a random constraint (distance link, spring, rope, world pin, hinge with an angle range, world angle lock)."""
     rng = np.random.default_rng(seed)
     b = SceneBuilder(f"soup{n}_{seed}", materials=[(0.1, 0.5, 0.4), (0.6, 0.8, 0.6), (0.0, 0.2, 0.1)])
     for i in range(n):
@@ -494,4 +495,30 @@ def random_soup(n=300, seed=1, extent=4.0, with_poly=True, with_statics=True, sp
             b.add_collider(n, "rect", (0.8, 0.15), (1.0, 0.65), 0.0)
             b.add_collider(n + 1, "rect", (0.3, 0.3), (0.8, -1.0), 0.3)
             b.add_collider(n, "circle", (1.2,), (-2.0, 0.2), 0.0)    # a large further collider
+    if joints:
+        jrng = np.random.default_rng(seed + 15485863)
+        P = np.asarray(b.pos[:n], float)
+        for i in range(n):
+            if jrng.random() >= joints:
+                continue
+            d = np.linalg.norm(P - P[i], axis=1)
+            d[i] = np.inf
+            j = int(np.argsort(d)[int(jrng.integers(0, 3))])   # one of the three nearest bodies
+            anchors = dict(anchor_a=tuple(jrng.uniform(-0.1, 0.1, 2)), anchor_b=tuple(jrng.uniform(-0.1, 0.1, 2)))
+            kind = int(jrng.integers(0, 6))
+            if kind == 0:      # rigid distance link at the current distance
+                b.distance(i, j)
+            elif kind == 1:    # soft spring with damping, anchors off the origins
+                b.distance(i, j, rest=float(d[j]) * 0.8, compliance=float(jrng.uniform(1e-4, 1e-2)),
+                           damping=float(jrng.uniform(0.0, 2.0)), **anchors)
+            elif kind == 2:    # rope (one-sided), slack or taut
+                b.distance(i, j, rest=float(d[j]) * float(jrng.uniform(0.7, 1.3)), limit=1, **anchors)
+            elif kind == 3:    # pin to the world
+                b.distance(WORLD_BODY, i, anchor_a=tuple(P[i] + jrng.uniform(-0.2, 0.2, 2)), anchor_b=anchors["anchor_b"],
+                           rest=float(jrng.uniform(0.0, 0.3)), compliance=float(jrng.choice([0.0, 1e-3])))
+            elif kind == 4:    # hinge: pin plus an angle range
+                b.attach(i, j, anchor_a=tuple(0.5 * (P[j] - P[i])), anchor_b=tuple(0.5 * (P[i] - P[j])))
+                b.angle(i, j, -0.4, 0.6, compliance=float(jrng.choice([0.0, 1e-3])), damping=float(jrng.choice([0.0, 0.5])))
+            else:              # angle lock against the world
+                b.angle(WORLD_BODY, i, -0.2, 0.2)
     return b.build()

@@ -106,3 +106,38 @@ def test_random_slab_decompositions(seed):
     assert all(w.stats().overflow == 0 for w in G.worlds)
     G.close()
     O.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_joints(seed):
+    """Joints under the same fuzz: a random soup where a third to all of the bodies carry a random constraint (rigid
+    link, damped spring, rope, world pin, hinge with an angle range, world angle lock), with and without colliders in
+    the way.  Joint order and colours bit-exact, five ticks of poses and velocities within tolerance."""
+    from oracle.oracle import ORDER_COLORED, OracleWorld
+    from starframe_amd.world import World
+
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(30, 600))
+    s = scenes.random_soup(n, seed=300 + seed, extent=float(rng.uniform(2.0, 6.0)), speed=float(rng.uniform(0.0, 1.5)),
+                           offsets=float(rng.choice([0.0, 0.3])), compounds=float(rng.choice([0.0, 0.2])),
+                           joints=float(rng.choice([0.3, 0.6, 1.0])))
+    if seed % 4 == 3:      # joints alone: no collider touches another
+        s.colliders["category"], s.colliders["mask"] = 1, 0
+    cfg = dict(substeps=int(rng.integers(1, 9)), color_rounds=int(rng.choice([1, 4, 12])))
+    g, o = World.from_scene(s, **cfg), OracleWorld.from_scene(s, **cfg)
+    assert len(s.constraints) + len(s.angle_constraints) > 0
+    if len(s.constraints):
+        gp, gc = g.joint_order()
+        op, oc = o.joint_order()
+        assert np.array_equal(gp, op) and np.array_equal(gc, oc), cfg
+    for _ in range(5):
+        g.step(DT)
+        o.step(DT, ORDER_COLORED)
+    assert g.stats().overflow == 0 and o.stats().overflow == 0, cfg
+    assert g.stats().n_joint_colors == o.stats().n_joint_colors
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= 1e-5, cfg
+    assert rel_err(g.poses()[1], o.poses()[1], floor=1.0) <= 1e-5, cfg
+    assert rel_err(g.velocities()[0], o.velocities()[0], floor=1.0) <= 1e-4, cfg
+    assert rel_err(g.velocities()[1], o.velocities()[1], floor=1.0) <= 1e-4, cfg
+    g.close()
+    o.close()
