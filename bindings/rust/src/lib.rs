@@ -32,7 +32,10 @@ pub const SFX_MAX_COLORS: usize = 64;
 pub const SFX_MAX_TAN_CORRECTION: f32 = 0.25;
 pub const SFX_TILE_MAX_PAIRS: u32 = 2048;
 pub const SFX_TILE_MAX_BODIES: u32 = 1024;
+pub const SFX_CFG_MULTI_LAUNCH: u32 = 1;
 pub const SFX_CFG_NO_FRICTION: u32 = 2;
+pub const SFX_CFG_ONE_LEVEL: u32 = 4;
+pub const SFX_CFG_ONE_WORKGROUP: u32 = 8;
 pub const SFX_LIMIT_NONE: u32 = 0;
 pub const SFX_LIMIT_ROPE: u32 = 1;
 pub const SFX_LIMIT_STRUT: u32 = 2;

@@ -94,7 +94,13 @@ typedef struct sfx_config {
     uint32_t flags;         /* SFX_CFG_* */
 } sfx_config;
 
-#define SFX_CFG_RESERVED 1u      /* not used: the tick is not launch-bound (host enqueue 0.08 ms of a 1 ms tick) */
+#define SFX_CFG_MULTI_LAUNCH 1u  /* never take the one-workgroup path.  Default: a tiny, sparse world (at most 512 bodies
+                                    and, by the last counters read back, at most 1024 pairs in at most 8 colours) runs
+                                    its substeps in ONE workgroup with the bodies in LDS -- one launch per sfx_step, one
+                                    per sfx_tick_substep -- with bit-identical results (scheduling only)   */
+#define SFX_CFG_ONE_WORKGROUP 8u /* a world of at most 2048 bodies takes the one-workgroup path whatever its pair and
+                                    colour counts, from its first tick on (slower than the default for most worlds
+                                    above a few hundred bodies: measured in DESIGN.md)                              */
 #define SFX_CFG_NO_FRICTION 2u   /* skip static + dynamic friction (debug)          */
 #define SFX_CFG_ONE_LEVEL 4u     /* broadphase grid without its second level: every collider too large for a base
                                     cell goes on the flat list (tested against everything)                     */

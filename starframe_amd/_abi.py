@@ -28,7 +28,10 @@ TILE_MAX_BODIES = 1024
 FALLBACK_TILE = 0xFFFFFFFF
 
 LIMIT_NONE, LIMIT_ROPE, LIMIT_STRUT = 0, 1, 2
+CFG_MULTI_LAUNCH = 1     # small worlds too take the launch-per-stage path
 CFG_NO_FRICTION = 2
+CFG_ONE_LEVEL = 4
+CFG_ONE_WORKGROUP = 8    # worlds of <= 1024 bodies: substeps in one workgroup from the first tick on
 
 
 class SfxConfig(C.Structure):

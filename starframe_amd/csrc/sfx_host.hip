@@ -1109,10 +1109,54 @@ int sfx_tick_begin(sfx_world* w, float frame_dt) {
     return SFX_OK;
 }
 
+static int substeps_done(sfx_world* w, uint32_t count, bool mirror);
+
+// Small worlds (sfx_kernels.h k_small_substeps): whole substeps in one workgroup, the bodies in LDS.  Measured on MI355X
+// (profiles/r02/small_world_paths.log): it saves launches (a dependent launch boundary is ~1.5 us) but gives up the
+// device -- one workgroup steps through the colours of ALL batches of a phase where the launch-per-stage path runs every
+// batch on a CU of its own with its own colour count -- so it wins only for tiny, sparse worlds (pyramid of 496 boxes
+// x1.06, 8 chains of 60 links x1.11) and loses from a few hundred bodies with ten colours on (soup of 300: x0.83,
+// 1000 circles: x0.72).  Taken by itself only there: at most 512 bodies and, by the last counters read back, at most
+// 1024 pairs in at most 8 colours; SFX_CFG_ONE_WORKGROUP takes it for any world of at most kSmallBodies bodies,
+// SFX_CFG_MULTI_LAUNCH (or SFX_SMALL_WORLDS=0 in the environment) never.  Not under profiling (the launch-per-stage
+// path has the per-stage events).  Both paths give the same bits, so a world may change between them from tick to tick.
+constexpr uint32_t kAutoSmallBodies = 512, kAutoSmallPairs = 1024, kAutoSmallColors = 8;
+static const bool g_small_off = [] { const char* e = getenv("SFX_SMALL_WORLDS"); return e && e[0] == '0'; }();
+
+static bool small_world(const sfx_world* w) {
+    if (g_small_off || (w->cfg.flags & SFX_CFG_MULTI_LAUNCH) || w->profiling || w->prof_mask || w->nb > kSmallBodies ||
+        w->joint_color_start.size() > (size_t)SFX_MAX_COLORS + 1)
+        return false;
+    if (w->cfg.flags & SFX_CFG_ONE_WORKGROUP) return true;
+    return w->nb <= kAutoSmallBodies && w->ctr_valid && w->stale.n_pairs <= kAutoSmallPairs && w->stale.n_colors <= kAutoSmallColors;
+}
+
+static int small_substeps(sfx_world* w, uint32_t nsub) {
+    const StepParams sp = w->sp;
+    w->q_valid = false;
+    JointArrays J;
+    J.bodies = w->j_bodies.p; J.anchors = w->j_anchors.p; J.params = w->j_params.p;
+    SmallJoints SJ;
+    SJ.ncolors = (uint32_t)w->joint_color_start.size() - 1;
+    SJ.damped = w->joint_damped ? 1u : 0u;
+    for (uint32_t c = 0; c <= SFX_MAX_COLORS; ++c) SJ.start[c] = w->joint_color_start[std::min<size_t>(c, SJ.ncolors)];
+    const uint32_t nph = (w->tly == w->gyl) ? 2u : 4u;
+    // (test hook: SFX_SMALL_TABLED=0 makes the kernel take its batches one after the other, the path of worlds with
+    // more batches than its LDS tables hold)
+    const char* te = getenv("SFX_SMALL_TABLED");
+    const uint32_t max_tabled = (te && te[0] == '0') ? 0u : kSmallBatches;
+    ++w->launches;
+    hipLaunchKernelGGL(k_small_substeps, dim3(1), dim3(kSmallThreads), 0, w->stream, nsub, nph, w->n, grid_params(w), tile_arrays(w),
+                       w->ctr, body_arrays(w), contact_arrays(w), J, SJ, sp, w->cfg.speculative_margin, max_tabled);
+    HIPCHK(w, hipGetLastError());
+    return substeps_done(w, nsub, false);
+}
+
 int sfx_tick_substep(sfx_world* w) {
     if (!w) return SFX_ERR_INVALID;
     if (!w->tick_open) return fail(w, SFX_ERR_INVALID, "sfx_tick_substep without sfx_tick_begin");
     HIPCHK(w, hipSetDevice(w->device));
+    if (small_world(w)) return small_substeps(w, 1u);
 
     const StepParams sp = w->sp;
     w->q_valid = false;
@@ -1201,8 +1245,14 @@ int sfx_tick_substep(sfx_world* w) {
         }
     }
     HIPCHK(w, hipGetLastError());
-    if (++w->substeps_done >= w->cfg.substeps) {
-        mirror_entries(w);   // between ticks the entries are where their bodies are (queries, AABBs, debug hooks)
+    return substeps_done(w, 1u, true);
+}
+
+// after `count` substeps have been enqueued: at the end of the tick, the mirror entries (unless the kernel that ran the
+// substeps has written them) and the asynchronous read-back of the tick's counters
+static int substeps_done(sfx_world* w, uint32_t count, bool mirror) {
+    if ((w->substeps_done += count) >= w->cfg.substeps) {
+        if (mirror) mirror_entries(w);   // between ticks the entries are where their bodies are (queries, AABBs, debug hooks)
         // end of the tick: start the asynchronous read-back of its counters
         w->tick_open = false;
         static const uint32_t every = [] { const char* e = getenv("SFX_CTR_EVERY"); return e ? (uint32_t)std::max(1, atoi(e)) : 8u; }();
@@ -1221,6 +1271,7 @@ int sfx_tick_substep(sfx_world* w) {
 
 int sfx_step(sfx_world* w, float frame_dt) {
     int rc = sfx_tick_begin(w, frame_dt);
+    if (rc == SFX_OK && small_world(w)) return small_substeps(w, w->cfg.substeps);   // the whole tick in one launch
     for (uint32_t s = 0; rc == SFX_OK && s < w->cfg.substeps; ++s) rc = sfx_tick_substep(w);
     return rc;
 }

@@ -128,15 +128,9 @@ __global__ __launch_bounds__(kBlock) void k_zero(uint4* __restrict__ p, uint32_t
 }
 
 // ---------------------------------------------------------------- K1 / K7 streaming
-__global__ __launch_bounds__(kBlock) void k_integrate(uint32_t n, float4* __restrict__ pose, float4* __restrict__ prev,
-                                                      float4* __restrict__ vel, const float2* __restrict__ mass,
-                                                      StepParams sp) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    float4 p = pose[i];
-    float4 v = vel[i];
-    const float2 w = mass[i];
-    prev[i] = p;
+// one body's integration step (DESIGN.md "Order"): returns the pose at the start of the substep in `q`
+__device__ __forceinline__ void integrate_body(float4& p, float4& q, float4& v, const float2& w, const StepParams& sp) {
+    q = p;
 #ifndef SFX_PROBE_NOSOLVE   // (the timing probe keeps the scene where it is)
     if (w.x > 0.0f) {
         v.x = v.x + sp.gx * sp.h;
@@ -147,23 +141,28 @@ __global__ __launch_bounds__(kBlock) void k_integrate(uint32_t n, float4* __rest
         v.x = v.x * sp.damp_lin;
         v.y = v.y * sp.damp_lin;
         v.z = v.z * sp.damp_ang;
-        vel[i] = v;
     }
     p.x = p.x + v.x * sp.h;
     p.y = p.y + v.y * sp.h;
     rotate_by(p.z, p.w, v.z * sp.h);
+}
+
+__global__ __launch_bounds__(kBlock) void k_integrate(uint32_t n, float4* __restrict__ pose, float4* __restrict__ prev,
+                                                      float4* __restrict__ vel, const float2* __restrict__ mass,
+                                                      StepParams sp) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 p = pose[i], q;
+    float4 v = vel[i];
+    const float2 w = mass[i];
+    integrate_body(p, q, v, w, sp);
+    prev[i] = q;
+    if (w.x > 0.0f || w.y > 0.0f) vel[i] = v;
     pose[i] = p;
 }
 
-__global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, const float4* __restrict__ pose,
-                                                    const float4* __restrict__ prev, float4* __restrict__ vel,
-                                                    const float2* __restrict__ mass, StepParams sp) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const float2 w = mass[i];
-    if (!(w.x > 0.0f || w.y > 0.0f)) return;
-    const float4 p = pose[i], q = prev[i];
-    float4 v = vel[i];
+// velocity of one dynamic body from what the substep did to its pose (p now, q at the start of the substep)
+__device__ __forceinline__ void derive_body(const float4& p, const float4& q, float4& v, const StepParams& sp) {
     v.x = (p.x - q.x) * sp.inv_h;
     v.y = (p.y - q.y) * sp.inv_h;
     float dc = p.z * q.z + p.w * q.w;
@@ -177,6 +176,17 @@ __global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, const float4* __r
         if (dw < -lim) wn = v.z - lim;
         v.z = wn;
     }
+}
+
+__global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, const float4* __restrict__ pose,
+                                                    const float4* __restrict__ prev, float4* __restrict__ vel,
+                                                    const float2* __restrict__ mass, StepParams sp) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float2 w = mass[i];
+    if (!(w.x > 0.0f || w.y > 0.0f)) return;
+    float4 v = vel[i];
+    derive_body(pose[i], prev[i], v, sp);
     vel[i] = v;
 }
 
@@ -2045,6 +2055,299 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
 #ifdef SFX_TILE_TIMING
     if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[49 + 2 * (epoch & 15u)], wall_clock64());    // latest kernel exit
 #endif
+}
+
+// ---------------------------------------------------------------- small worlds: whole substeps in ONE workgroup
+// A world of at most kSmallBodies bodies does not fill one CU, and its multi-launch substep (integrate, joint colours,
+// narrowphase, fused position solve, derive, fused velocity solve) is all dispatch and hand-off: every launch loads
+// the bodies, takes a step and writes them back through global memory.  Here ONE workgroup keeps every body's state
+// in LDS -- indexed by body id, so that tile pairs, the fallback list and joints all address it alike -- and runs
+// `nsub` substeps back to back: the same stages, the same per-pair and per-joint functions, the same batch tables,
+// colour runs and orders as the launches above, with workgroup barriers where those have launch boundaries, flags or
+// phases.  Results are bit-identical to the multi-launch path (tests/test_gpu_parity.py).  The manifold records still
+// go through the contact arrays in global memory (written and read by this one workgroup: visible after a barrier).
+// The joint and fallback functions take a BodyArrays view whose state pointers are the LDS arrays (generic pointers).
+constexpr uint32_t kSmallBodies = 2048;    // LDS: 56 bytes of state per body
+constexpr int kSmallThreads = 512;
+constexpr uint32_t kSmallBatches = 64;     // batches of all phases together whose colour runs are tabulated in LDS
+
+// The batches of one phase do not interact, so the workgroup solves colour c of ALL of them in one step (the launches
+// above give each batch a workgroup of its own).  Per phase and colour the runs of the phase's batches are laid end to
+// end: pre[c][...] holds the running sum of their lengths (one row segment per phase, a leading 0 each), first[c][b]
+// the run's first pair within batch b's list, bstart[b] that list's first record slot.  Built once per launch.
+struct SmallTables {
+    uint16_t pre[SFX_MAX_COLORS][kSmallBatches + 4];
+    uint16_t first[SFX_MAX_COLORS][kSmallBatches];
+    uint32_t bstart[kSmallBatches];
+    uint32_t pb0[5];      // first batch of each phase in the flattened numbering, [nph..4] = all batches
+    uint32_t pncol[4];    // most colours of any batch of the phase
+};
+
+struct SmallJoints {
+    uint32_t ncolors;
+    uint32_t damped;
+    uint32_t start[SFX_MAX_COLORS + 1];   // joint colour c = joints start[c] .. start[c + 1] of the colour-sorted arrays
+};
+
+// one batch of one phase, colour by colour, on the LDS state (the loop of k_tile_pos / k_tile_vel: two lanes per pair,
+// the next colour's record in flight while this one is solved)
+template <bool VEL>
+__device__ __forceinline__ void small_batch(const BatchDesc& d, const TileArrays& T, const ContactArrays& C, const BodyArrays& B,
+                                            float4* s_pose, float4* s_vel, const float2* s_mass, uint32_t* s_cs, uint32_t* s_ce,
+                                            const StepParams& sp) {
+    constexpr uint32_t NT = kSmallThreads;
+    const uint32_t tid = threadIdx.x, side = tid & 1u, half = tid >> 1;
+    const uint32_t start = d.bstart, ncol = d.ncol;
+    RawSide nxt;
+    fetch_side<VEL>(T, C, start + half, side, start + half < T.max_pairs, nxt);
+    __syncthreads();   // the previous batch has read its colour runs
+    if (tid < SFX_MAX_COLORS) {
+        const uint32_t v = T.bruns[64u * d.roff + tid];
+        s_cs[tid] = v & 0xFFFFu; s_ce[tid] = v >> 16;
+    }
+    __syncthreads();
+    nxt.in_range = ncol > 0u && half < s_ce[0];
+    auto solve = [&](uint32_t k, const RawSide& q) {
+        SideSlot p;
+        decode_side<VEL>(q, side, p, 0xFFFFFFFFu);   // no local-index limit: the state is addressed by body id
+        if (!VEL && side == 0u && q.in_range && !p.valid) C.lam[start + k] = make_float2(0.0f, 0.0f);
+        if (!p.valid) return;
+        const uint32_t bi = body_of(B, side ? q.pr.y : q.pr.x);
+        float4 ps = s_pose[bi];
+        const float2 w = s_mass[bi];
+        if constexpr (VEL) {
+            float4 vs = s_vel[bi];
+            const int ch = solve_vel_side(p.r, ps, vs, w, sp);
+            if (w.x > 0.0f || w.y > 0.0f) { s_vel[bi] = vs; if (ch & 2) s_pose[bi] = ps; }
+        } else {
+            if (solve_pos_side(p.r, ps, w, sp.max_corr)) {
+                if (w.x > 0.0f || w.y > 0.0f) s_pose[bi] = ps;
+            }
+            if (side == 0u) C.lam[start + k] = make_float2(p.r.l0, p.r.l1);
+        }
+    };
+    for (uint32_t c = 0; c < ncol; ++c) {
+        const RawSide cur = nxt;
+        const uint32_t k0 = s_cs[c] + half, ce = s_ce[c];
+        {
+            const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
+            fetch_side<VEL>(T, C, start + s_cs[c1] + half, side, c + 1u < ncol && s_cs[c1] + half < s_ce[c1], nxt);
+        }
+        solve(k0, cur);
+        for (uint32_t k = k0 + NT / 2; k < ce; k += NT / 2) {  // colour runs longer than half the workgroup
+            RawSide more;
+            fetch_side<VEL>(T, C, start + k, side, true, more);
+            solve(k, more);
+        }
+        lds_barrier();
+    }
+}
+
+// colour c of every batch of phase ph in one step, on the LDS state (two lanes per pair; the next colour's record is
+// in flight while this one is solved)
+template <bool VEL>
+__device__ __forceinline__ void small_phase(uint32_t ph, const SmallTables& S, const TileArrays& T, const ContactArrays& C,
+                                            const BodyArrays& B, float4* s_pose, float4* s_vel, const float2* s_mass,
+                                            const StepParams& sp) {
+    constexpr uint32_t NT = kSmallThreads;
+    const uint32_t tid = threadIdx.x, side = tid & 1u, half = tid >> 1;
+    const uint32_t b0 = S.pb0[ph], nbat = S.pb0[ph + 1] - b0, base = b0 + ph, ncol = S.pncol[ph];
+    if (nbat == 0u) return;
+    // record slot of the h-th pair of colour c over the phase's batches (false past the end)
+    auto locate = [&](uint32_t c, uint32_t h, uint32_t& slot) -> bool {
+        const uint16_t* row = &S.pre[c][base];
+        slot = 0u;
+        if (h >= row[nbat]) return false;
+        uint32_t lo = 0u, hi = nbat;   // largest j with row[j] <= h
+        while (hi - lo > 1u) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (row[mid] <= h) lo = mid; else hi = mid;
+        }
+        slot = S.bstart[b0 + lo] + S.first[c][b0 + lo] + (h - row[lo]);
+        return true;
+    };
+    auto solve = [&](uint32_t slot, const RawSide& q) {
+        SideSlot p;
+        decode_side<VEL>(q, side, p, 0xFFFFFFFFu);   // no local-index limit: the state is addressed by body id
+        if (!VEL && side == 0u && q.in_range && !p.valid) C.lam[slot] = make_float2(0.0f, 0.0f);
+        if (!p.valid) return;
+        const uint32_t bi = body_of(B, side ? q.pr.y : q.pr.x);
+        float4 ps = s_pose[bi];
+        const float2 w = s_mass[bi];
+        if constexpr (VEL) {
+            float4 vs = s_vel[bi];
+            const int ch = solve_vel_side(p.r, ps, vs, w, sp);
+            if (w.x > 0.0f || w.y > 0.0f) { s_vel[bi] = vs; if (ch & 2) s_pose[bi] = ps; }
+        } else {
+            if (solve_pos_side(p.r, ps, w, sp.max_corr)) {
+                if (w.x > 0.0f || w.y > 0.0f) s_pose[bi] = ps;
+            }
+            if (side == 0u) C.lam[slot] = make_float2(p.r.l0, p.r.l1);
+        }
+    };
+    RawSide nxt;
+    uint32_t nslot = 0u;
+    {
+        const bool in = ncol > 0u && locate(0u, half, nslot);
+        fetch_side<VEL>(T, C, nslot, side, in, nxt);
+    }
+    for (uint32_t c = 0; c < ncol; ++c) {
+        const RawSide cur = nxt;
+        const uint32_t cslot = nslot;
+        const uint32_t total = S.pre[c][base + nbat];
+        {
+            const bool in = c + 1u < ncol && locate(c + 1u, half, nslot);
+            fetch_side<VEL>(T, C, nslot, side, in, nxt);
+        }
+        solve(cslot, cur);
+        for (uint32_t h = half + NT / 2; h < total; h += NT / 2) {  // colours with more pairs than half the workgroup
+            uint32_t slot;
+            RawSide more;
+            locate(c, h, slot);
+            fetch_side<VEL>(T, C, slot, side, true, more);
+            solve(slot, more);
+        }
+        lds_barrier();
+    }
+}
+
+__global__ __launch_bounds__(kSmallThreads) void k_small_substeps(uint32_t nsub, uint32_t nph, uint32_t n_entries, GridParams g,
+                                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B,
+                                                                   ContactArrays C, JointArrays J, SmallJoints SJ, StepParams sp,
+                                                                   float sm, uint32_t max_tabled) {
+    constexpr uint32_t NT = kSmallThreads;
+    __shared__ SmallTables S;
+    __shared__ float4 s_pose[kSmallBodies];
+    __shared__ float4 s_prev[kSmallBodies];
+    __shared__ float4 s_vel[kSmallBodies];
+    __shared__ float2 s_mass[kSmallBodies];
+    __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
+    const uint32_t tid = threadIdx.x;
+    SFX_TT(ts_entry);
+    const uint32_t nb = min(B.nb, kSmallBodies);
+    for (uint32_t i = tid; i < nb; i += NT) {
+        s_pose[i] = B.pose[i]; s_vel[i] = B.vel[i]; s_mass[i] = B.mass[i];
+    }
+    BodyArrays L = B;   // the same world with its state in LDS: what solve_joint, damp_joint and the fallback solves take
+    L.pose = s_pose; L.prev = s_prev; L.vel = s_vel; L.mass = s_mass;
+    const uint32_t ntp = min(ctr->tp_cursor, T.max_pairs);
+    const uint32_t nfb = min(ctr->n_fb, T.fb_cap) ? ctr->fb_start[SFX_MAX_COLORS] : 0u;
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t ph = 0; ph < 4u; ++ph) {
+            S.pb0[ph] = run; S.pncol[ph] = 0u;
+            if (ph < nph) run += min(ctr->n_batches[ph], g.pstride);
+        }
+        S.pb0[4] = run;
+    }
+    __syncthreads();
+    // (more batches than the tables hold, or pair lists past 16-bit offsets: the batches are solved one after the other)
+    const uint32_t nbt = S.pb0[4];
+    const bool tabled = nbt <= min(max_tabled, kSmallBatches) && ntp <= 0xFFFFu;
+    if (tabled) {
+        for (uint32_t t = tid; t < nbt * (uint32_t)SFX_MAX_COLORS; t += NT) {
+            const uint32_t fb = t / (uint32_t)SFX_MAX_COLORS, c = t % (uint32_t)SFX_MAX_COLORS;
+            uint32_t ph = 0;
+            while (ph + 1u < nph && fb >= S.pb0[ph + 1]) ++ph;
+            const BatchDesc d = T.batches[ph * g.pstride + (fb - S.pb0[ph])];
+            const uint32_t v = T.bruns[64u * d.roff + c];
+            const uint32_t cs = v & 0xFFFFu, ce = v >> 16;
+            S.first[c][fb] = (uint16_t)cs;
+            S.pre[c][fb + ph + 1u] = (uint16_t)((c < d.ncol && ce > cs) ? ce - cs : 0u);   // lengths first, running sums below
+            if (c == 0u) { S.bstart[fb] = d.bstart; atomicMax(&S.pncol[ph], min(d.ncol, (uint32_t)SFX_MAX_COLORS)); }
+        }
+        __syncthreads();
+        if (tid < nph * (uint32_t)SFX_MAX_COLORS) {
+            const uint32_t c = tid % (uint32_t)SFX_MAX_COLORS, ph = tid / (uint32_t)SFX_MAX_COLORS;
+            const uint32_t base = S.pb0[ph] + ph, nbat = S.pb0[ph + 1] - S.pb0[ph];
+            uint32_t run = 0;
+            S.pre[c][base] = 0;
+            for (uint32_t j = 1; j <= nbat; ++j) { run += S.pre[c][base + j]; S.pre[c][base + j] = (uint16_t)run; }
+        }
+    }
+    __syncthreads();
+    SFX_TT(ts_setup);
+    SFX_TT_ADD(64, ts_entry, ts_setup);
+    for (uint32_t s = 0; s < nsub; ++s) {
+        SFX_TT(ts0);
+        for (uint32_t i = tid; i < nb; i += NT) {
+            float4 p = s_pose[i], q, v = s_vel[i];
+            integrate_body(p, q, v, s_mass[i], sp);
+            s_pose[i] = p; s_prev[i] = q; s_vel[i] = v;
+        }
+        __syncthreads();
+        for (uint32_t jc = 0; jc < SJ.ncolors; ++jc) {
+            for (uint32_t k = SJ.start[jc] + tid; k < SJ.start[jc + 1]; k += NT) solve_joint(L, J, k, sp.inv_h2);
+            __syncthreads();
+        }
+        SFX_TT(ts1);
+        SFX_TT_ADD(65, ts0, ts1);
+        // manifolds of every solver pair at these poses (k_narrow's loop; a further collider is where its body is)
+        for (uint32_t j = tid; j < ntp + nfb; j += NT) {
+            uint32_t a, b, slot;
+            if (j < ntp) {
+                const uint4 o = T.torder[j];
+                slot = o.z;
+                if (slot == kNoPair) continue;
+                a = o.x; b = o.y;
+            } else {
+                const uint2 ab = T.fsorted[j - ntp];
+                a = ab.x; b = ab.y; slot = T.max_pairs + (j - ntp);
+            }
+            const uint32_t ba = body_of(B, a), bb = body_of(B, b);
+            PairRec r;
+            const float4 pa = s_pose[ba], pb = s_pose[bb], sa = B.shape[a], sb = B.shape[b];
+            prepare_pair(pa, sa, s_vel[ba], pb, sb, s_vel[bb], shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, r);
+            store_record(C, slot, r);
+        }
+        __syncthreads();   // (a workgroup barrier orders this workgroup's global stores and loads as well)
+        SFX_TT(ts2);
+        SFX_TT_ADD(66, ts1, ts2);
+        for (uint32_t ph = 0; ph < nph; ++ph) {
+            if (tabled) { small_phase<false>(ph, S, T, C, B, s_pose, s_vel, s_mass, sp); continue; }
+            const uint32_t nbat = S.pb0[ph + 1] - S.pb0[ph];
+            for (uint32_t it = 0; it < nbat; ++it)
+                small_batch<false>(T.batches[ph * g.pstride + it], T, C, B, s_pose, s_vel, s_mass, s_cs, s_ce, sp);
+        }
+        __syncthreads();
+        SFX_TT(ts3);
+        SFX_TT_ADD(67, ts2, ts3);
+        fallback_pos(T, ctr, L, C, sp.max_corr);
+        for (uint32_t i = tid; i < nb; i += NT) {
+            const float2 w = s_mass[i];
+            if (!(w.x > 0.0f || w.y > 0.0f)) continue;
+            float4 v = s_vel[i];
+            derive_body(s_pose[i], s_prev[i], v, sp);
+            s_vel[i] = v;
+        }
+        __syncthreads();   // also: the multipliers the position pass stored are visible to the velocity pass
+        SFX_TT(ts4);
+        SFX_TT_ADD(68, ts3, ts4);
+        for (uint32_t jc = 0; SJ.damped && jc < SJ.ncolors; ++jc) {
+            for (uint32_t k = SJ.start[jc] + tid; k < SJ.start[jc + 1]; k += NT) damp_joint(L, J, k, sp.h);
+            __syncthreads();
+        }
+        for (uint32_t ph = 0; ph < nph; ++ph) {
+            if (tabled) { small_phase<true>(ph, S, T, C, B, s_pose, s_vel, s_mass, sp); continue; }
+            const uint32_t nbat = S.pb0[ph + 1] - S.pb0[ph];
+            for (uint32_t it = 0; it < nbat; ++it)
+                small_batch<true>(T.batches[ph * g.pstride + it], T, C, B, s_pose, s_vel, s_mass, s_cs, s_ce, sp);
+        }
+        __syncthreads();
+        SFX_TT(ts5);
+        SFX_TT_ADD(69, ts4, ts5);
+        fallback_vel(T, ctr, L, C, sp);
+        __syncthreads();
+        SFX_TT(ts6);
+        SFX_TT_ADD(70, ts5, ts6); SFX_TT_ADD(71, ts0, ts6); SFX_TT_ADD(72, 0ull, 1ull);
+    }
+    for (uint32_t i = tid; i < nb; i += NT) {
+        B.pose[i] = s_pose[i]; B.prev[i] = s_prev[i]; B.vel[i] = s_vel[i];
+    }
+    for (uint32_t e = nb + tid; e < n_entries; e += NT) {   // further colliders are where their bodies are (k_mirror)
+        const uint32_t b = B.cbody[e - nb];
+        B.pose[e] = s_pose[b]; B.vel[e] = s_vel[b];
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void k_solve_joints(uint32_t start, uint32_t cnt, BodyArrays B, JointArrays J,

@@ -663,3 +663,73 @@ def test_batches_shrink_when_their_pairs_touch_too_many_outside_colliders():
     assert reported >= 1 and clean >= 4, (reported, clean)
     assert w.stats().overflow == 0
     w.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12))
+def test_small_world_path_equals_launch_per_stage(seed):
+    """Worlds of at most 1024 bodies run their substeps in one workgroup with the bodies in LDS (k_small_substeps; one
+    launch per sfx_step).  Scheduling only: the states are bit-identical to the launch-per-stage path -- random soups with
+    every shape, local poses, several colliders per body (static and dynamic: the fallback list), joints of every kind
+    with damping, 1..8 substeps, strips and square tiles -- tick by tick with sfx_step and substep by substep; and the
+    one-workgroup world agrees with the oracle like any other."""
+    from oracle.oracle import ORDER_COLORED, OracleWorld
+    from starframe_amd._abi import CFG_MULTI_LAUNCH, CFG_ONE_WORKGROUP
+    from starframe_amd.world import World
+
+    rng = np.random.default_rng(7000 + seed)
+    n = int(rng.integers(30, 900))
+    s = scenes.random_soup(n, seed=500 + seed, extent=max(2.0, 0.15 * n ** 0.5) * float(rng.uniform(1.0, 2.0)), speed=float(rng.uniform(0.0, 1.5)),
+                           offsets=float(rng.choice([0.0, 0.3])), compounds=float(rng.choice([0.0, 0.2])),
+                           platforms=int(rng.choice([0, 12])), joints=float(rng.choice([0.0, 0.3, 0.8])))
+    cfg = dict(substeps=int(rng.integers(1, 9)), tile_cells=int(rng.choice([0, 2, 4])), tile_cells_y=int(rng.choice([0, 2, 4096])))
+    one = World.from_scene(s, flags=CFG_ONE_WORKGROUP, **cfg)
+    many = World.from_scene(s, flags=CFG_MULTI_LAUNCH, **cfg)
+    auto = World.from_scene(s, **cfg)      # changes path when the first counters arrive
+    o = OracleWorld.from_scene(s, **cfg)
+    for t in range(6):
+        if t % 2:
+            for w in (one, many, auto):
+                w.step(DT)
+        else:       # substep by substep (what a slab world does)
+            for w in (one, many, auto):
+                w.tick_begin(DT)
+                for _ in range(cfg["substeps"]):
+                    w.tick_substep()
+        o.step(DT, ORDER_COLORED)
+        if t == 2:
+            auto.sync()     # the counters are in: the next tick_begin adopts them
+        p1, r1 = one.poses()
+        v1, a1 = one.velocities()
+        for w in (many, auto):
+            p2, r2 = w.poses()
+            v2, a2 = w.velocities()
+            assert np.array_equal(p1.view(np.uint32), p2.view(np.uint32)) and np.array_equal(r1.view(np.uint32), r2.view(np.uint32)), (t, cfg)
+            assert np.array_equal(v1.view(np.uint32), v2.view(np.uint32)) and np.array_equal(a1.view(np.uint32), a2.view(np.uint32)), (t, cfg)
+        assert np.array_equal(one.aabbs().view(np.uint32), many.aabbs().view(np.uint32))    # the mirror entries too
+    assert one.stats().launches < many.stats().launches
+    assert one.stats().overflow == 0 and many.stats().overflow == 0
+    assert rel_err(p1, o.poses()[0], floor=1.0) <= 1e-5 and rel_err(v1, o.velocities()[0], floor=1.0) <= 1e-4
+    for w in (one, many, auto, o):
+        w.close()
+
+
+@pytest.mark.gpu
+def test_small_world_batches_one_after_the_other(monkeypatch):
+    """The one-workgroup kernel tabulates the colour runs of up to 64 batches in LDS; a world with more takes its batches
+    one after the other.  SFX_SMALL_TABLED=0 (read at every launch) forces that path: same bits again."""
+    from starframe_amd._abi import CFG_MULTI_LAUNCH, CFG_ONE_WORKGROUP
+    from starframe_amd.world import World
+
+    s = scenes.random_soup(700, seed=77, extent=6.0, compounds=0.2, joints=0.3, platforms=12)
+    monkeypatch.setenv("SFX_SMALL_TABLED", "0")
+    one = World.from_scene(s, flags=CFG_ONE_WORKGROUP, substeps=3)
+    many = World.from_scene(s, flags=CFG_MULTI_LAUNCH, substeps=3)
+    for _ in range(4):
+        one.step(DT)
+        many.step(DT)
+    assert one.stats().launches < many.stats().launches and one.stats().overflow == 0
+    for a, b in zip(one.poses() + one.velocities(), many.poses() + many.velocities()):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    one.close()
+    many.close()
