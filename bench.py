@@ -23,7 +23,8 @@ The JSON line also carries
                  events recorded by libsfx on its own stream, against the 8 TB/s HBM peak; the other
                  two under roofline.other_kernels;
   cpu_baseline : this repository's single-threaded CPU restatement (oracle/, kind "port")
-                 timed on this host on a bounded number of frames of the same settled scene.
+                 timed on this host on a bounded number of frames of the same settled scene;
+                 cpu_baseline.openmp: the same source built with -fopenmp on all host threads.
                  It is NOT starframe's Rust tick, which was unavailable.
 """
 import argparse
@@ -122,6 +123,7 @@ def cpu_baseline(scene, budget_s=15.0):
     n_dyn = scene.n_dynamic()
     w.close()
     return {
+        "openmp": cpu_baseline_openmp(scene, n_dyn),
         "value": n_dyn * scene.substeps * frames / el,
         "unit": "body-substeps/s",
         "cores": 1,
@@ -131,6 +133,30 @@ def cpu_baseline(scene, budget_s=15.0):
         "ms_per_step": 1e3 * el / frames,
         "cpu_model": cpu_model(),
     }
+
+
+def cpu_baseline_openmp(scene, n_dyn, budget_s=8.0):
+    """The same restatement built with -fopenmp (oracle/libsfx_oracle_omp.so; SURVEY.md 8d "OpenMP-coloured variant,
+    reported separately"): coloured order, the units of one phase, the manifolds and the per-body loops side by side on
+    the host's threads, same bits as the serial build.  Its broadphase stays serial."""
+    from oracle.oracle import ORDER_COLORED, OracleWorld, load
+
+    try:
+        threads = int(load(True).sfo_threads())
+        w = OracleWorld.from_scene(scene, openmp=True)
+    except Exception as e:  # the variant is optional: no libgomp, no figure
+        return {"error": str(e)}
+    t0 = time.perf_counter()
+    w.step(DT, ORDER_COLORED)
+    first = time.perf_counter() - t0
+    frames = int(max(1, min(200, budget_s / max(first, 1e-6))))
+    t0 = time.perf_counter()
+    for _ in range(frames):
+        w.step(DT, ORDER_COLORED)
+    el = time.perf_counter() - t0
+    w.close()
+    return {"value": n_dyn * scene.substeps * frames / el, "unit": "body-substeps/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} ticks, coloured order, OpenMP over the units of a phase", "ms_per_step": 1e3 * el / frames}
 
 
 def cpu_model():

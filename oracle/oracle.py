@@ -17,28 +17,29 @@ from starframe_amd.world import WorldBase
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsfx_oracle.so")
+OMP_LIB_PATH = os.path.join(HERE, "libsfx_oracle_omp.so")   # the same source with -fopenmp: same bits, several threads
 
 ORDER_SEQUENTIAL = 0
 ORDER_COLORED = 1
 
-_lib = None
+_libs = {}
 
 
 def build():
-    subprocess.check_call(["make", "-s", "-C", HERE])
+    subprocess.check_call(["make", "-s", "-C", HERE, "all"])
 
 
-def load():
-    global _lib
-    if _lib is not None:
-        return _lib
-    src_newer = (not os.path.exists(LIB_PATH)) or any(
-        os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(LIB_PATH)
+def load(openmp=False):
+    if openmp in _libs:
+        return _libs[openmp]
+    path = OMP_LIB_PATH if openmp else LIB_PATH
+    src_newer = (not os.path.exists(path)) or any(
+        os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(path)
         for f in ("sfx_oracle.c", "sfx_oracle.h")
     )
     if src_newer:
         build()
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     P, vp = C.POINTER, C.c_void_p
     lib.sfo_create.argtypes = [P(SfxConfig)]
     lib.sfo_create.restype = vp
@@ -77,15 +78,16 @@ def load():
     lib.sfo_query_aabbs.restype = C.c_size_t
     lib.sfo_query_rays.argtypes = [vp, C.c_uint32, P(C.c_float), P(C.c_float), C.c_uint32, vp, C.c_int]
     lib.sfo_query_rays.restype = C.c_int
-    _lib = lib
+    lib.sfo_threads.restype = C.c_int
+    _libs[openmp] = lib
     return lib
 
 
 class OracleWorld(WorldBase):
     prefix = "sfo_"
 
-    def __init__(self, cfg=None, **cfg_kw):
-        self.lib = load()
+    def __init__(self, cfg=None, openmp=False, **cfg_kw):
+        self.lib = load(openmp)
         self.cfg = cfg or make_config(**cfg_kw)
         self.handle = C.c_void_p(self.lib.sfo_create(C.byref(self.cfg)))
         if not self.handle:

@@ -14,6 +14,9 @@
  *
  * Build: gcc -O2 -ffp-contract=off -fPIC -shared (oracle/Makefile).
  */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "sfx_oracle.h"
 
 #include <float.h>
@@ -89,6 +92,8 @@ struct sfo_world {
     int order_valid;
     int tick_open, tick_order;
     uint32_t tick_nbatch;
+    uint32_t phase_end[5]; /* batches of phase ph (4 = the fallback list) = [phase_end[ph-1], phase_end[ph]): the units of one
+                            * phase share no dynamic body (the OpenMP build solves them side by side) */
     float tick_h;
     pair_rec* rec;
     uint32_t n_contacts, n_manifolds, n_manifolds2;
@@ -997,13 +1002,20 @@ static void build_order(sfo_world* w, float frame_dt) {
     uint32_t* bb = (uint32_t*)malloc((np ? np : 1) * sizeof(uint32_t));
     for (uint32_t e = 0; e < np; ++e) { ba[e] = w->cbody[w->pa[e]]; bb[e] = w->cbody[w->pb[e]]; }
     /* batches: phase by phase, inside a phase tile by tile (independent of each other), the
-     * fallback list last; inside a batch colour-major */
+     * fallback list last; inside a batch colour-major.  The units of one phase share no dynamic body, so their reach
+     * tests and colourings do not touch each other's scratch entries: the OpenMP build runs them side by side; the
+     * order is then written unit by unit, serially, exactly as the serial build does. */
+    uint32_t* unk = (uint32_t*)calloc((size_t)ntiles + 1, sizeof(uint32_t)); /* pairs kept per unit of the phase */
+    uint32_t* unc = (uint32_t*)calloc((size_t)ntiles + 1, sizeof(uint32_t)); /* its colours */
     for (uint32_t ph = 0; ph <= 4; ++ph) {
-        for (uint32_t t = 0; t <= ntiles; ++t) {
-            if (ph < 4) {
-                if (t == ntiles) continue;
-            } else if (t != ntiles) continue;
+        const uint32_t first = ph < 4 ? 0u : ntiles, last = ph < 4 ? ntiles : ntiles + 1u;
+        uint32_t left_ph = 0, ovf_ph = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : left_ph) reduction(| : ovf_ph) if (last - first > 16)
+#endif
+        for (uint32_t t = first; t < last; ++t) {
             uint32_t s0 = tstart[t], cnt = tstart[t + 1] - s0;
+            unk[t] = 0;
             if (!cnt) continue;
             const uint32_t* idx = &bytile[s0];
             if (ph < 4) { /* tile-owned pairs: only those within reach are coloured and solved */
@@ -1011,14 +1023,22 @@ static void build_order(sfo_world* w, float frame_dt) {
                 for (uint32_t q = 0; q < cnt; ++q) {
                     uint32_t e = bytile[s0 + q];
                     if (w->pclass[e] != ph) continue; /* the unit (tile t, class ph) */
-                    if (pair_in_reach(w, w->pa[e], w->pb[e], frame_dt)) kept[nk++] = e;
+                    if (pair_in_reach(w, w->pa[e], w->pb[e], frame_dt)) kept[s0 + nk++] = e;
                     else w->color[e] = PRUNED_COLOR;
                 }
-                idx = kept; cnt = nk;
+                idx = &kept[s0]; cnt = nk;
                 if (!cnt) continue;
             }
-            uint32_t nc = color_edges(&cs, cnt, idx, ba, bb, w->pa, w->pb, dyn, w->cfg.color_rounds,
-                                      w->color, &w->n_leftover, &ovf);
+            uint32_t lo = 0, ov = 0;
+            unc[t] = color_edges(&cs, cnt, idx, ba, bb, w->pa, w->pb, dyn, w->cfg.color_rounds, w->color, &lo, &ov);
+            unk[t] = cnt;
+            left_ph += lo; ovf_ph |= ov;
+        }
+        w->n_leftover += left_ph; ovf |= ovf_ph;
+        for (uint32_t t = first; t < last; ++t) {
+            const uint32_t cnt = unk[t], nc = unc[t];
+            if (!cnt) continue;
+            const uint32_t* idx = ph < 4 ? &kept[tstart[t]] : &bytile[tstart[t]];
             if (nc > w->n_colors) w->n_colors = nc;
             for (uint32_t c = 0; c < nc; ++c)
                 for (uint32_t q = 0; q < cnt; ++q) {
@@ -1027,7 +1047,9 @@ static void build_order(sfo_world* w, float frame_dt) {
                 }
             w->batch_end[w->n_batches++] = w->n_order;
         }
+        w->phase_end[ph] = w->n_batches;
     }
+    free(unk); free(unc);
     color_scratch_free(&cs);
     if (ovf) w->overflow = 1;
     w->order_valid = 1;
@@ -1037,6 +1059,9 @@ static void build_order(sfo_world* w, float frame_dt) {
 }
 
 static void broadphase_core(sfo_world* w, float frame_dt) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (w->n > 4096)
+#endif
     for (uint32_t i = 0; i < w->n; ++i) compute_aabb(w, i, frame_dt, &w->aabb[4 * i]);
     grid_pairs(w);
     w->order_valid = 0;
@@ -1384,6 +1409,9 @@ static void rotate_by(float* c, float* s, float dth) {
 static void integrate(sfo_world* w, float h) {
     float gx = w->cfg.gravity[0], gy = w->cfg.gravity[1];
     float dl = 1.0f / (1.0f + h * w->cfg.linear_damping), da = 1.0f / (1.0f + h * w->cfg.angular_damping);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (w->nb > 4096)
+#endif
     for (uint32_t i = 0; i < w->nb; ++i) {
         w->prev_pos[2 * i] = w->pos[2 * i]; w->prev_pos[2 * i + 1] = w->pos[2 * i + 1];
         w->prev_rot[2 * i] = w->rot[2 * i]; w->prev_rot[2 * i + 1] = w->rot[2 * i + 1];
@@ -1404,6 +1432,9 @@ static void integrate(sfo_world* w, float h) {
 
 /* [XPBD-RB] Alg. 2 lines 12-16; omega is the exact inverse of rotate_by: tan(dtheta)/h */
 static void derive_velocities(sfo_world* w, float inv_h) {
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (w->nb > 4096)
+#endif
     for (uint32_t i = 0; i < w->nb; ++i) {
         if (!is_dynamic(w, i)) continue;
         w->vel[2 * i] = (w->pos[2 * i] - w->prev_pos[2 * i]) * inv_h;
@@ -1855,9 +1886,22 @@ int sfo_tick_substep(sfo_world* w) {
     uint32_t n_ord = nbatch ? w->batch_end[nbatch - 1] : 0;
     /* the manifolds are taken between COLLIDERS (entries, which mirror their bodies), the solves act on the BODIES */
     mirror_entries(w);
+    /* (OpenMP build, libsfx_oracle_omp.so: every manifold is independent; in the coloured order the units of one phase
+     * share no dynamic body, so they run side by side, each in its own order -- the same bits as the serial build) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (n_ord > 2048)
+#endif
     for (uint32_t k = 0; k < n_ord; ++k) prepare_pair(w, w->pa[w->order[k]], w->pb[w->order[k]], &w->rec[w->order[k]]);
-    for (uint32_t k = 0; k < n_ord; ++k)
-        solve_pos_pair(w, w->cbody[w->pa[w->order[k]]], w->cbody[w->pb[w->order[k]]], &w->rec[w->order[k]], max_corr);
+    const int phased = order != SFO_ORDER_SEQUENTIAL;
+    for (uint32_t ph = 0; ph < (phased ? 5u : 1u); ++ph) {
+        const uint32_t b0 = phased ? (ph ? w->phase_end[ph - 1] : 0u) : 0u, b1 = phased ? w->phase_end[ph] : nbatch;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 8) if (b1 - b0 > 16)
+#endif
+        for (uint32_t bt = b0; bt < b1; ++bt)
+            for (uint32_t k = bt ? w->batch_end[bt - 1] : 0u; k < w->batch_end[bt]; ++k)
+                solve_pos_pair(w, w->cbody[w->pa[w->order[k]]], w->cbody[w->pb[w->order[k]]], &w->rec[w->order[k]], max_corr);
+    }
     derive_velocities(w, inv_h);
     for (uint32_t k = 0; k < w->m; ++k) { /* joint damping, in the joints' solve order */
         uint32_t jk = order == SFO_ORDER_SEQUENTIAL ? k : w->joint_perm[k];
@@ -1865,13 +1909,16 @@ int sfo_tick_substep(sfo_world* w) {
         if (jk < w->m_dist) damp_joint(w, &w->joints[jk], h);
         else damp_angle(w, &w->angles[jk - w->m_dist], h);
     }
-    for (uint32_t bt = 0, k0 = 0; bt < nbatch; ++bt) {
-        uint32_t k1 = w->batch_end[bt];
-        for (uint32_t k = k0; k < k1; ++k) {
-            uint32_t e = w->order[k];
-            if (w->rec[e].count) solve_vel_pair(w, w->cbody[w->pa[e]], w->cbody[w->pb[e]], &w->rec[e], h, inv_h);
-        }
-        k0 = k1;
+    for (uint32_t ph = 0; ph < (phased ? 5u : 1u); ++ph) {
+        const uint32_t b0 = phased ? (ph ? w->phase_end[ph - 1] : 0u) : 0u, b1 = phased ? w->phase_end[ph] : nbatch;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 8) if (b1 - b0 > 16)
+#endif
+        for (uint32_t bt = b0; bt < b1; ++bt)
+            for (uint32_t k = bt ? w->batch_end[bt - 1] : 0u; k < w->batch_end[bt]; ++k) {
+                uint32_t e = w->order[k];
+                if (w->rec[e].count) solve_vel_pair(w, w->cbody[w->pa[e]], w->cbody[w->pb[e]], &w->rec[e], h, inv_h);
+            }
     }
     mirror_entries(w);
     /* stats of the last substep, measured on the records */
@@ -1884,6 +1931,15 @@ int sfo_tick_substep(sfo_world* w) {
             if (w->rec[e].lam[k] > 0.0f) w->n_contacts++;
     }
     return SFX_OK;
+}
+
+/* threads the solves use: 1 in the serial build (libsfx_oracle.so), omp_get_max_threads() in libsfx_oracle_omp.so */
+int sfo_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
 }
 
 int sfo_step(sfo_world* w, float frame_dt, int order) {

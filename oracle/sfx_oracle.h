@@ -89,6 +89,11 @@ size_t sfo_query_aabbs(const sfo_world* w, uint32_t n, const float* boxes, uint3
 int sfo_query_rays(const sfo_world* w, uint32_t n, const float* rays, const float* max_t, uint32_t mask,
                    sfx_ray_hit* out, int brute);
 
+/* threads the tick uses: 1 for libsfx_oracle.so; libsfx_oracle_omp.so (the same source built with -fopenmp, make
+ * libsfx_oracle_omp.so) runs the per-body loops, the manifolds and -- in the coloured order -- the units of one phase
+ * side by side and gives the same bits (tests/test_oracle_kat.py); SURVEY.md 8d "OpenMP-coloured variant" */
+int sfo_threads(void);
+
 #ifdef __cplusplus
 }
 #endif

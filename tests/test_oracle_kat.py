@@ -465,3 +465,26 @@ def test_swinging_offset_shape_widens_its_aabb_pad():
     pad = 10.0 * 0.2 * DT                                  # |omega| |offset| dt
     np.testing.assert_allclose(A[0], (0.2 - 0.06 - pad, -0.06 - pad, 0.2 + 0.06 + pad, 0.06 + pad), atol=1e-6)
     np.testing.assert_allclose(A[1], (5.0 - 0.06, -0.06, 5.0 + 0.06, 0.06), atol=1e-6)
+
+
+def test_openmp_build_of_the_oracle_gives_the_same_bits():
+    """oracle/libsfx_oracle_omp.so = the same source with -fopenmp (bench.py reports it beside the serial baseline): per-body
+    loops, manifolds, reach tests + colouring and the solves of the units of one phase run on several threads; poses,
+    velocities, colours and owner units are bit-identical to the serial build."""
+    import numpy as np
+    from oracle.oracle import ORDER_COLORED, OracleWorld, load
+    from starframe_amd import scenes
+
+    assert load(True).sfo_threads() >= 1 and load(False).sfo_threads() == 1
+    for s in (scenes.random_soup(1500, seed=5, extent=8.0, compounds=0.2, joints=0.4, platforms=12),
+              scenes.mixed_pile(n=12000, width=120)):
+        a, b = OracleWorld.from_scene(s), OracleWorld.from_scene(s, openmp=True)
+        for _ in range(3):
+            a.step(1.0 / 60.0, ORDER_COLORED)
+            b.step(1.0 / 60.0, ORDER_COLORED)
+        for x, y in zip(a.poses() + a.velocities(), b.poses() + b.velocities()):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        for x, y in zip(a.pair_colors(), b.pair_colors()):
+            assert np.array_equal(x, y)
+        a.close()
+        b.close()
