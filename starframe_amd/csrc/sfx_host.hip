@@ -88,7 +88,7 @@ struct sfx_world {
     std::vector<float> h_poly;
     DevBuf<float4> pose, prev, vel, shape, lpose, poly, mats, aabb, sorted_aabb;
     DevBuf<float2> mass;
-    DevBuf<uint4> filt;
+    DevBuf<uint4> filt, sorted_filt;   // filter words by entry id / in slot order (written by k_finalize_slots)
     // broadphase.  `zero` is one allocation cleared by a single memset per tick:
     // [Counters][cell_start: ncell + 1 + pad][tile_cnt: ntiles + 1 + pad][tile_fill: ntiles][tile_flag: ntiles][tile_batch: ntiles]
     DevBuf<uint32_t> zero;
@@ -499,7 +499,7 @@ int broadphase(sfx_world* w, float dt) {
     { Prof p(w, SFX_K_SCATTER, n);
       hipLaunchKernelGGL(k_finalize_slots, dim3(gb), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->tmp_id.p,
                          w->bucket.p, w->aabb.p, w->cellxy.p, w->large_tmp.p, w->large_cap, w->sorted_id.p,
-                         w->sorted_aabb.p, w->sorted_cell.p, w->ctr); }
+                         w->sorted_aabb.p, w->sorted_cell.p, w->ctr, w->filt.p, w->sorted_filt.p); }
     PairArrays P;
     P.slot_cnt = w->slot_cnt.p; P.slot_off = w->slot_off.p; P.tile_cnt = w->tile_cnt; P.tile_fill = w->tile_fill; P.tile_flag = w->tile_flag;
     P.rawp = w->rawp.p; P.fpairs = w->fpairs.p; P.hit_tmp = w->hit_tmp.p; P.max_pairs = w->max_pairs; P.fb_cap = w->fb_cap;
@@ -507,7 +507,7 @@ int broadphase(sfx_world* w, float dt) {
     const uint32_t gp = std::min(std::max(cdiv(n + 1, kBlock / kGroup), 1u), 8192u);
     { Prof p(w, SFX_K_PAIR_COUNT, n);
       hipLaunchKernelGGL(k_pairs<false>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
-                         w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }
+                         w->sorted_aabb.p, w->sorted_cell.p, w->sorted_filt.p, P, w->ctr, w->large_cap); }
     { Prof p(w, SFX_K_TILE_LIST, w->ntiles);
       if (n / std::max(w->ntiles, 1u) >= 32u)
           hipLaunchKernelGGL(k_tile_count<64>, dim3(cdiv(w->ntiles, kBlock / 64)), dim3(kBlock), 0, w->stream, g, w->cell_start,
@@ -528,7 +528,7 @@ int broadphase(sfx_world* w, float dt) {
     }
     { Prof p(w, SFX_K_PAIR_FILL, n);
       hipLaunchKernelGGL(k_pairs<true>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
-                         w->sorted_aabb.p, w->sorted_cell.p, w->filt.p, P, w->ctr, w->large_cap); }
+                         w->sorted_aabb.p, w->sorted_cell.p, w->sorted_filt.p, P, w->ctr, w->large_cap); }
     ReachParams RP;
     RP.pose = w->pose.p; RP.vel = w->vel.p; RP.lpose = w->lpose.p; RP.poly = w->poly.p;
     RP.margin = w->cfg.aabb_margin; RP.vel_pad_max = w->cfg.vel_pad_max; RP.dt = dt; RP.sm = w->cfg.speculative_margin;
@@ -538,7 +538,7 @@ int broadphase(sfx_world* w, float dt) {
                          w->ntiles, w->max_pairs, w->rawp.p, w->shape.p, RP); }
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
       hipLaunchKernelGGL(k_batch_color<kBatchP>, dim3(w->color_grid, (w->tly == w->gyl) ? 2u : 4u, w->group > 1u ? 2u : 1u), dim3(kColorThreads), 0, w->stream, g, w->group,
-                         w->cell_start, w->sorted_id.p, w->filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
+                         w->cell_start, w->sorted_id.p, w->sorted_filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
                          w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->bbody.p, (uint32_t)w->bbody.n, w->bruns.p, (uint32_t)(w->bruns.n / 64), w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
@@ -598,7 +598,7 @@ int alloc_entries(sfx_world* w, uint32_t n_entries) {
     w->halo_guard = 0.0f;
     const size_t c = std::max(n, 1u);
     ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
-    ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->lpose, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c);
+    ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->lpose, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c); ALLOC(w, w->sorted_filt, c);
     ALLOC(w, w->bucket, c); ALLOC(w, w->tmp_id, c); ALLOC(w, w->sorted_id, c); ALLOC(w, w->large_tmp, c);
     ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->slot_off, 2 * ((size_t)n + 1)); ALLOC(w, w->hit_tmp, kHitTmp * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
     ALLOC(w, w->used, c); ALLOC(w, w->claim, c * kClaim);
@@ -751,7 +751,7 @@ void sfx_destroy(sfx_world* w) {
     for (auto& e : w->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : w->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     w->pose.release(); w->prev.release(); w->vel.release(); w->shape.release(); w->lpose.release(); w->poly.release();
-    w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release();
+    w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release(); w->sorted_filt.release();
     w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
     w->active.release(); w->batches.release(); w->torder.release(); w->done.release(); w->bbody.release(); w->bruns.release(); w->rawp.release(); w->tpair.release();
     w->fpairs.release(); w->fsorted.release(); w->hit_tmp.release();
@@ -1443,7 +1443,7 @@ int build_query_index(sfx_world* w, const QueryBuffers& Q) {
     { Prof p(w, SFX_K_QUERY, n);
       hipLaunchKernelGGL(k_finalize_slots, dim3(gb), dim3(kBlock), 0, w->stream, n, g, qcs, Q.tmp_id, Q.bucket,
                          Q.aabb, Q.cellxy, Q.large_tmp, w->large_cap, Q.sorted_id, Q.sorted_aabb,
-                         Q.sorted_cell, qctr); }
+                         Q.sorted_cell, qctr, (const uint4*)nullptr, (uint4*)nullptr); }
     { Prof p(w, SFX_K_QUERY, n);
       hipLaunchKernelGGL(k_query_bounds, dim3(std::min(gb, 1024u)), dim3(kBlock), 0, w->stream, qcs, w->ncell,
                          Q.sorted_aabb, Q.bounds); }

@@ -397,7 +397,10 @@ __global__ __launch_bounds__(kBlock) void k_finalize_slots(uint32_t n, GridParam
                                                             const float4* __restrict__ aabb, const int2* __restrict__ cellxy,
                                                             const uint32_t* __restrict__ large_tmp, uint32_t large_cap,
                                                             uint32_t* __restrict__ sorted_id, float4* __restrict__ sorted_aabb,
-                                                            int2* __restrict__ sorted_cell, Counters* __restrict__ ctr) {
+                                                            int2* __restrict__ sorted_cell, Counters* __restrict__ ctr,
+                                                            const uint4* __restrict__ filt, uint4* __restrict__ sorted_filt) {
+    // (sorted_filt, may be null: the filter words in slot order too, so that the pair passes read a candidate's box,
+    // cell, id and filter side by side instead of its filter through its id)
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t ns = cell_start[g.ncell_all];   // grid-sorted slots: the small colliders, then the medium ones
     const uint32_t nl = min(ctr->n_large, large_cap);
@@ -412,6 +415,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize_slots(uint32_t n, GridParam
         sorted_id[dst] = i;
         sorted_aabb[dst] = aabb[i];
         sorted_cell[dst] = cellxy[i];
+        if (sorted_filt) sorted_filt[dst] = filt[i];
     } else if (p - ns < nl) {
         const uint32_t i = large_tmp[p - ns];
         uint32_t rank = 0;
@@ -420,6 +424,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize_slots(uint32_t n, GridParam
         sorted_id[dst] = i;
         sorted_aabb[dst] = aabb[i];
         sorted_cell[dst] = make_int2(0, 0);
+        if (sorted_filt) sorted_filt[dst] = filt[i];
     }
 }
 
@@ -492,7 +497,7 @@ template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, const uint32_t* __restrict__ cell_start,
                                                    const uint32_t* __restrict__ sorted_id,
                                                    const float4* __restrict__ sorted_aabb,
-                                                   const int2* __restrict__ sorted_cell, const uint4* __restrict__ filt,
+                                                   const int2* __restrict__ sorted_cell, const uint4* __restrict__ sorted_filt,
                                                    PairArrays P, Counters* __restrict__ ctr, uint32_t large_cap) {
     const int lane = threadIdx.x & 63;
     const int gl = lane & (kGroup - 1);          // lane inside the group
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
         float4 Ai = make_float4(0, 0, 0, 0);
         uint4 fi = make_uint4(0, 0, 0, 0);
         int2 c = make_int2(0, 0);
-        if (live) { i = sorted_id[p]; Ai = sorted_aabb[p]; fi = filt[i]; c = sorted_cell[p]; }
+        if (live) { i = sorted_id[p]; Ai = sorted_aabb[p]; fi = sorted_filt[p]; c = sorted_cell[p]; }
         const int32_t txp = c.x >> g.tlx, typ = c.y >> g.tly;
         const uint32_t T0 = tile_of(txp, typ, g), T1 = tile_of(txp - 1, typ, g);
         // stream bases (fill pass): lane 0 of the group reserves, the group reads them by shuffle
@@ -622,11 +627,15 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                 cls = ddx ? (ddy ? 3u : 1u) : (ddy ? 2u : 0u);
             }
             if (x < L) {
-                bool ok = true;
-                if (r < 5) { const int2 cq = sorted_cell[q]; ok = (cq.x == ncx && cq.y == ncy); }
-                if (ok && aabb_overlap(Ai, sorted_aabb[q])) {
-                    j = sorted_id[q];
-                    const uint4 fj = filt[j];
+                // the candidate's cell, box, id and filter words: four loads side by side (the slot order makes them
+                // sequential), nothing waits for another
+                const int2 cq = sorted_cell[q];
+                const float4 Aq = sorted_aabb[q];
+                const uint32_t jq = sorted_id[q];
+                const uint4 fj = sorted_filt[q];
+                const bool ok = r >= 5 || (cq.x == ncx && cq.y == ncy);
+                if (ok && aabb_overlap(Ai, Aq)) {
+                    j = jq;
                     hit = pair_filter(fi, fj);
                     if (r == 5 && small_slot && (fj.w & kFiltDynamic)) st = 2;  // small against a large dynamic collider
                     if ((fi.w | fj.w) & kFiltFurther) st = 2;  // a further collider of a dynamic body: solved on the body
@@ -669,9 +678,11 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                 int st = 0;   // small + medium: the small collider's tile, unless the medium one is dynamic
                 if (x < L1) {
                     const int2 cq = sorted_cell[q];
-                    if (cq.x == X0 + (int32_t)(k1 % nx1) && cq.y == Y0 + (int32_t)(k1 / nx1) && aabb_overlap(Ai, sorted_aabb[q])) {
-                        j = sorted_id[q];
-                        const uint4 fj = filt[j];
+                    const float4 Aq = sorted_aabb[q];
+                    const uint32_t jq = sorted_id[q];
+                    const uint4 fj = sorted_filt[q];
+                    if (cq.x == X0 + (int32_t)(k1 % nx1) && cq.y == Y0 + (int32_t)(k1 / nx1) && aabb_overlap(Ai, Aq)) {
+                        j = jq;
                         hit = pair_filter(fi, fj);
                         if (fj.w & kFiltDynamic) st = 2;
                         if ((fi.w | fj.w) & kFiltFurther) st = 2;
@@ -961,7 +972,7 @@ constexpr int kColorThreads = SFX_COLOR_THREADS;
 template <uint32_t MP>
 __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uint32_t group, const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ sorted_id,
-                                                         const uint4* __restrict__ filt,
+                                                         const uint4* __restrict__ filt /* in slot order (sorted_filt) */,
                                                          const uint32_t* __restrict__ tile_start,
                                                          const uint32_t* __restrict__ list, const uint4* __restrict__ rawp,
                                                          uint4* __restrict__ tpair, BatchDesc* __restrict__ batches,
@@ -1046,8 +1057,7 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
             __syncthreads();
             const uint32_t nb = min(S.off[4u * c], MB), np_all = min(s_poff[c], MP);
             for (uint32_t l = tid; l < nb; l += kBlock) {
-                const uint32_t gid = sorted_id[batch_slot(S, 4u * c, l)];
-                s_dyn[l] = (uint8_t)(filt[gid].w & kFiltDynamic);
+                s_dyn[l] = (uint8_t)(filt[batch_slot(S, 4u * c, l)].w & kFiltDynamic);   // (filt: the filter words in slot order)
                 s_mark[l] = 0u;
                 s_used[l] = 0ull;
 #pragma unroll
