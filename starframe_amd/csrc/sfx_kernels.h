@@ -970,7 +970,7 @@ __global__ __launch_bounds__(kBlock) void k_reach(const uint32_t* __restrict__ t
 #endif
 constexpr int kColorThreads = SFX_COLOR_THREADS;
 template <uint32_t MP>
-__global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uint32_t group, const uint32_t* __restrict__ cell_start,
+__global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, uint32_t group, const uint32_t* __restrict__ cell_start,
                                                          const uint32_t* __restrict__ sorted_id,
                                                          const uint4* __restrict__ filt /* in slot order (sorted_filt) */,
                                                          const uint32_t* __restrict__ tile_start,
@@ -1132,35 +1132,55 @@ __global__ __launch_bounds__(kColorThreads) void k_batch_color(GridParams g, uin
                 if (s_mark[l] && s_boff + s_remap[l] < bbody_cap) bbody[s_boff + s_remap[l]] = sorted_id[batch_slot(S, 4u * c, l)];
             SFX_TT(tc1);
 #define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
+            // A thread owns the same (at most MP / threads) edges in every round: their ends, keys, dynamic flags, colour and
+            // proposal stay in registers, so a round is one LDS read (the ends' used colours / the claims) and one LDS
+            // atomic per edge and phase instead of a chain of dependent reads.
+            constexpr uint32_t EPT = (MP + kBlock - 1) / kBlock;
+            uint32_t e_l[EPT], e_a[EPT], e_b[EPT];
+            uint8_t e_col[EPT], e_prop[EPT], e_dyn[EPT];
+#pragma unroll
+            for (uint32_t k = 0; k < EPT; ++k) {
+                const uint32_t e = tid + k * kBlock;
+                e_l[k] = 0u; e_a[k] = 0u; e_b[k] = 0u; e_dyn[k] = 0u; e_prop[k] = SFX_NO_COLOR;
+                e_col[k] = 0u;   // (anything but SFX_NO_COLOR: an edge that does not exist is never open)
+                if (e < np) {
+                    const uint32_t la = s_la[e], lb = s_lb[e];
+                    e_l[k] = la | (lb << 16); e_a[k] = s_a[e]; e_b[k] = s_b[e]; e_col[k] = s_col[e];
+                    e_dyn[k] = (uint8_t)((TDYN(la) ? 1u : 0u) | (TDYN(lb) ? 2u : 0u));
+                }
+            }
             for (uint32_t r = 0; r < rounds && any_open; ++r) {  // everything coloured: later rounds would do nothing
                 SFX_TT_ADD(98, 0ull, 1ull);
-                for (uint32_t e = tid; e < np; e += kBlock) {  // propose
-                    if (s_col[e] != SFX_NO_COLOR) continue;
-                    const uint32_t la = s_la[e], lb = s_lb[e];
-                    const bool da = TDYN(la), db = TDYN(lb);
+#pragma unroll
+                for (uint32_t k = 0; k < EPT; ++k) {  // propose
+                    if (e_col[k] != SFX_NO_COLOR) continue;
+                    const uint32_t la = e_l[k] & 0xFFFFu, lb = e_l[k] >> 16;
+                    const bool da = e_dyn[k] & 1u, db = e_dyn[k] & 2u;
                     const unsigned long long freem = ~((da ? s_used[la] : 0ull) | (db ? s_used[lb] : 0ull));
-                    if (freem == 0ull) { s_prop[e] = SFX_NO_COLOR; atomicOr(&s_ovf, 1u); continue; }
+                    if (freem == 0ull) { e_prop[k] = SFX_NO_COLOR; atomicOr(&s_ovf, 1u); continue; }
                     const uint32_t cc = (uint32_t)__builtin_ctzll(freem);  // first fit
-                    const uint32_t h = edge_hash(s_a[e], s_b[e], r);
-                    s_prop[e] = (uint8_t)cc;
-                    const unsigned long long p = edge_prio(s_a[e], s_b[e], r, h);
+                    const uint32_t h = edge_hash(e_a[k], e_b[k], r);
+                    e_prop[k] = (uint8_t)cc;
+                    const unsigned long long p = edge_prio(e_a[k], e_b[k], r, h);
                     if (da) atomicMin(&s_claim[la * kClaim + (cc & (kClaim - 1u))], p);
                     if (db) atomicMin(&s_claim[lb * kClaim + (cc & (kClaim - 1u))], p);
                 }
                 __syncthreads();
                 open_edges = 0;
-                for (uint32_t e = tid; e < np; e += kBlock) {  // resolve
-                    if (s_col[e] != SFX_NO_COLOR) continue;
-                    const uint32_t cc = s_prop[e];
+#pragma unroll
+                for (uint32_t k = 0; k < EPT; ++k) {  // resolve
+                    if (e_col[k] != SFX_NO_COLOR) continue;
+                    const uint32_t cc = e_prop[k];
                     if (cc == SFX_NO_COLOR) { open_edges = 1; continue; }
-                    const uint32_t la = s_la[e], lb = s_lb[e];
-                    const bool da = TDYN(la), db = TDYN(lb);
-                    const uint32_t h = edge_hash(s_a[e], s_b[e], r);
-                    const unsigned long long p = edge_prio(s_a[e], s_b[e], r, h);
+                    const uint32_t la = e_l[k] & 0xFFFFu, lb = e_l[k] >> 16;
+                    const bool da = e_dyn[k] & 1u, db = e_dyn[k] & 2u;
+                    const uint32_t h = edge_hash(e_a[k], e_b[k], r);
+                    const unsigned long long p = edge_prio(e_a[k], e_b[k], r, h);
                     const bool win = (!da || s_claim[la * kClaim + (cc & (kClaim - 1u))] == p) &&
                                      (!db || s_claim[lb * kClaim + (cc & (kClaim - 1u))] == p);
                     if (win) {
-                        s_col[e] = (uint8_t)cc;
+                        e_col[k] = (uint8_t)cc;
+                        s_col[tid + k * kBlock] = (uint8_t)cc;
                         if (da) atomicOr(&s_used[la], 1ull << cc);
                         if (db) atomicOr(&s_used[lb], 1ull << cc);
                     } else {
