@@ -88,6 +88,9 @@ struct sfx_world {
     std::vector<float> h_poly;
     DevBuf<float4> pose, prev, vel, shape, lpose, poly, mats, aabb, sorted_aabb;
     DevBuf<float2> mass;
+    uint32_t vel_epoch = 0;        // derive-on-load: stamp of the current substep's velocity solve (sfx_step only)
+    uint32_t vel_prev_epoch = 0;   // stamp of the previous substep of this tick when it left bodies underived, else 0
+    bool in_step = false;          // sfx_step is driving the substeps (it sees the whole tick)
     DevBuf<uint4> filt, sorted_filt;   // filter words by entry id / in slot order (written by k_finalize_slots)
     // broadphase.  `zero` is one allocation cleared by a single memset per tick:
     // [Counters][cell_start: ncell + 1 + pad][tile_cnt: ntiles + 1 + pad][tile_fill: ntiles][tile_flag: ntiles][tile_batch: ntiles]
@@ -1171,7 +1174,16 @@ int sfx_tick_substep(sfx_world* w) {
     const uint32_t gb = cdiv(std::max(w->nb, 1u), kBlock);   // integration and derive walk the bodies
     const uint32_t njc = (uint32_t)w->joint_color_start.size() - 1;
     { Prof p(w, SFX_K_INTEGRATE, w->nb);
-      hipLaunchKernelGGL(k_integrate, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
+      hipLaunchKernelGGL(k_integrate, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp, w->vel_prev_epoch); }
+    // Derive-on-load (sfx_kernels.h): inside sfx_step, with no joint damping between the derive and the velocity solve and
+    // no halos read between substeps, the velocity solve derives a body's velocity where it first loads it and the bodies
+    // it does not touch are derived by the next integration (or by one k_derive after the last substep): three launches of
+    // k_derive less per tick.  SFX_FUSE_DERIVE=0 keeps the separate pass.
+    static const bool fuse_derive_off = [] { const char* e = getenv("SFX_FUSE_DERIVE"); return e && e[0] == '0'; }();
+    const bool fuse_derive = w->in_step && !fuse_derive_off && !w->joint_damped && w->n_halo_send == 0 && w->n_halo_recv == 0;
+    const bool last_substep = w->substeps_done + 1u >= w->cfg.substeps;
+    if (fuse_derive && ++w->vel_epoch == 0u) w->vel_epoch = 1u;   // (0 means "off")
+    const uint32_t vstamp = fuse_derive ? w->vel_epoch : 0u;
     for (uint32_t jc = 0; jc < njc; ++jc) {
         const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
         if (!cnt) continue;
@@ -1205,9 +1217,9 @@ int sfx_tick_substep(sfx_world* w) {
     auto launch_vel = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
         fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;
         const uint32_t nt = tvv == 0 ? 512u : tvv == 1 ? 256u : 128u;
-        if (tvv == 2) hipLaunchKernelGGL(k_tile_vel<128>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
-        else if (tvv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
-        else hipLaunchKernelGGL(k_tile_vel<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp);
+        if (tvv == 2) hipLaunchKernelGGL(k_tile_vel<128>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp, vstamp);
+        else if (tvv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp, vstamp);
+        else hipLaunchKernelGGL(k_tile_vel<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp, vstamp);
     };
     mirror_entries(w);   // the narrowphase reads colliders (entries), the solves write bodies
     {   // manifolds of all solver pairs at the poses integration and joints left (one pair per lane)
@@ -1227,8 +1239,10 @@ int sfx_tick_substep(sfx_world* w) {
             launch_pos(w->tile_grid[ph], ph, 1u, 0u, (ph + 1 == nph ? kTileFallback : 0) | kTileStaticFirst);
         }
     }
-    { Prof p(w, SFX_K_DERIVE_VEL, w->nb);
-      hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp); }
+    if (!fuse_derive) {
+      Prof p(w, SFX_K_DERIVE_VEL, w->nb);
+      hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp, 0u);
+    }
     for (uint32_t jc = 0; w->joint_damped && jc < njc; ++jc) {
         const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
         if (!cnt) continue;
@@ -1244,6 +1258,11 @@ int sfx_tick_substep(sfx_world* w) {
             launch_vel(w->tile_grid[ph], ph, 1u, 0u, (ph + 1 == nph ? kTileFallback : 0) | kTileStaticFirst);
         }
     }
+    if (fuse_derive && last_substep) {   // the bodies no pair touched in the last substep
+      Prof p(w, SFX_K_DERIVE_VEL, w->nb);
+      hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp, vstamp);
+    }
+    w->vel_prev_epoch = (fuse_derive && !last_substep) ? vstamp : 0u;
     HIPCHK(w, hipGetLastError());
     return substeps_done(w, 1u, true);
 }
@@ -1272,7 +1291,10 @@ static int substeps_done(sfx_world* w, uint32_t count, bool mirror) {
 int sfx_step(sfx_world* w, float frame_dt) {
     int rc = sfx_tick_begin(w, frame_dt);
     if (rc == SFX_OK && small_world(w)) return small_substeps(w, w->cfg.substeps);   // the whole tick in one launch
+    w->in_step = true;   // the substeps below are the whole tick: velocities may stay underived between them
     for (uint32_t s = 0; rc == SFX_OK && s < w->cfg.substeps; ++s) rc = sfx_tick_substep(w);
+    w->in_step = false;
+    if (rc != SFX_OK) w->vel_prev_epoch = 0u;
     return rc;
 }
 

@@ -147,14 +147,21 @@ __device__ __forceinline__ void integrate_body(float4& p, float4& q, float4& v, 
     rotate_by(p.z, p.w, v.z * sp.h);
 }
 
+// Derive-on-load (DESIGN.md "Kernels / velocities derived where they are first read"): inside sfx_step the velocity solve
+// derives a body's velocity when it first loads it and stamps the velocity record's unused fourth word with the substep's
+// epoch; a body no pair touched is derived by the NEXT substep's integration (`derive_first`: the epoch whose stamp says
+// "done"), or by one k_derive at the end of the tick.  0 = off (every body was derived by k_derive).
+__device__ __forceinline__ void derive_body(const float4& p, const float4& q, float4& v, const StepParams& sp);
+
 __global__ __launch_bounds__(kBlock) void k_integrate(uint32_t n, float4* __restrict__ pose, float4* __restrict__ prev,
                                                       float4* __restrict__ vel, const float2* __restrict__ mass,
-                                                      StepParams sp) {
+                                                      StepParams sp, uint32_t derive_first) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 p = pose[i], q;
     float4 v = vel[i];
     const float2 w = mass[i];
+    if (derive_first && (w.x > 0.0f || w.y > 0.0f) && __float_as_uint(v.w) != derive_first) derive_body(p, prev[i], v, sp);
     integrate_body(p, q, v, w, sp);
     prev[i] = q;
     if (w.x > 0.0f || w.y > 0.0f) vel[i] = v;
@@ -178,14 +185,16 @@ __device__ __forceinline__ void derive_body(const float4& p, const float4& q, fl
     }
 }
 
+// `done` != 0: bodies whose velocity record carries that stamp were derived by the velocity solve already
 __global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, const float4* __restrict__ pose,
                                                     const float4* __restrict__ prev, float4* __restrict__ vel,
-                                                    const float2* __restrict__ mass, StepParams sp) {
+                                                    const float2* __restrict__ mass, StepParams sp, uint32_t done) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const float2 w = mass[i];
     if (!(w.x > 0.0f || w.y > 0.0f)) return;
     float4 v = vel[i];
+    if (done && __float_as_uint(v.w) == done) return;
     derive_body(pose[i], prev[i], v, sp);
     vel[i] = v;
 }
@@ -1598,7 +1607,7 @@ __device__ __forceinline__ void fallback_pos(const TileArrays& T, const Counters
 }
 
 __device__ __forceinline__ void fallback_vel(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
-                                             const ContactArrays& C, const StepParams& sp) {
+                                             const ContactArrays& C, const StepParams& sp, uint32_t vstamp = 0u) {
     const uint32_t nfb = min(ctr->n_fb, T.fb_cap);
     if (nfb == 0) return;
     const uint32_t nc = ctr->n_fb_colors;
@@ -1613,8 +1622,13 @@ __device__ __forceinline__ void fallback_vel(const TileArrays& T, const Counters
             float4 pa = B.pose[ab.x], pb = B.pose[ab.y];
             float4 va = B.vel[ab.x], vb = B.vel[ab.y];
             const float2 wa = B.mass[ab.x], wb = B.mass[ab.y];
+            bool da = false, db = false;   // derive-on-load: this pair is the first to read the body's velocity this substep
+            if (vstamp) {
+                if ((wa.x > 0.0f || wa.y > 0.0f) && __float_as_uint(va.w) != vstamp) { derive_body(pa, B.prev[ab.x], va, sp); va.w = __uint_as_float(vstamp); da = true; }
+                if ((wb.x > 0.0f || wb.y > 0.0f) && __float_as_uint(vb.w) != vstamp) { derive_body(pb, B.prev[ab.y], vb, sp); vb.w = __uint_as_float(vstamp); db = true; }
+            }
             const int ch = solve_vel_rec(r, pa, va, wa, pb, vb, wb, sp);
-            if (ch) {
+            if (ch || da || db) {
                 if (wa.x > 0.0f || wa.y > 0.0f) { B.vel[ab.x] = va; if (ch & 2) B.pose[ab.x] = pa; }
                 if (wb.x > 0.0f || wb.y > 0.0f) { B.vel[ab.y] = vb; if (ch & 2) B.pose[ab.y] = pb; }
             }
@@ -1973,7 +1987,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
 template <int NT>
 __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph0, uint32_t nph, uint32_t epoch, int flags, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
-                                                  StepParams sp) {
+                                                  StepParams sp, uint32_t vstamp) {
     __shared__ float4 s_pose[kMaxBX];
     __shared__ float4 s_vel[kMaxBX];
     __shared__ float2 s_mass[kMaxBX];
@@ -2012,8 +2026,15 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         SFX_TT(tvw);
         for (uint32_t l = tid; l < nb; l += NT) {
             const uint32_t gid = s_gid[l];
-            s_pose[l] = B.pose[gid];
-            s_vel[l] = B.vel[gid];
+            const float4 ps = B.pose[gid];
+            float4 vs = B.vel[gid];
+            if (vstamp) {   // derive-on-load: the first batch of the sweep to read a body derives its velocity and stamps it
+                const float4 q = B.prev[gid];   // (fetched beside the others: no load waits for the stamp)
+                const float2 w = s_mass[l];
+                if ((w.x > 0.0f || w.y > 0.0f) && __float_as_uint(vs.w) != vstamp) { derive_body(ps, q, vs, sp); vs.w = __uint_as_float(vstamp); }
+            }
+            s_pose[l] = ps;
+            s_vel[l] = vs;
         }
         __syncthreads();
         nxt.in_range = ncol > 0u && half < s_ce[0];
@@ -2081,7 +2102,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         }
 #endif
     }
-    if ((flags & kTileFallback) && ctr->n_fb != 0u && last_workgroup(ctr)) fallback_vel(T, ctr, B, C, sp);
+    if ((flags & kTileFallback) && ctr->n_fb != 0u && last_workgroup(ctr)) fallback_vel(T, ctr, B, C, sp, vstamp);
 #ifdef SFX_TILE_TIMING
     if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[49 + 2 * (epoch & 15u)], wall_clock64());    // latest kernel exit
 #endif

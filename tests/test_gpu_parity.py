@@ -733,3 +733,30 @@ def test_small_world_batches_one_after_the_other(monkeypatch):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     one.close()
     many.close()
+
+
+@pytest.mark.gpu
+def test_velocities_derived_where_first_read_equal_the_separate_pass():
+    """Inside sfx_step the velocity solve derives a body's velocity when it first loads it (stamp in the velocity record's
+    fourth word), bodies no pair touches are derived by the next integration or by one k_derive at the end of the tick.
+    Same bits as sfx_tick_begin + sfx_tick_substep, which keep the separate k_derive pass after every position solve:
+    a soup with free-flying bodies (no pair at all), statics, compounds on the fallback list and undamped joints."""
+    from starframe_amd._abi import CFG_MULTI_LAUNCH
+    from starframe_amd.world import World
+
+    s = scenes.random_soup(2500, seed=21, extent=16.0, compounds=0.15, joints=0.3, platforms=12, speed=1.5)
+    s.constraints["damping"] = 0.0
+    s.angle_constraints["damping"] = 0.0
+    a = World.from_scene(s, flags=CFG_MULTI_LAUNCH, substeps=5)   # sfx_step: derive-on-load
+    b = World.from_scene(s, flags=CFG_MULTI_LAUNCH, substeps=5)   # substep by substep: k_derive every substep
+    for t in range(8):
+        a.step(DT)
+        b.tick_begin(DT)
+        for _ in range(5):
+            b.tick_substep()
+        for x, y in zip(a.poses() + a.velocities(), b.poses() + b.velocities()):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32)), t
+    assert a.stats().n_fallback > 0 and a.stats().overflow == 0
+    assert a.stats().launches < b.stats().launches
+    a.close()
+    b.close()
