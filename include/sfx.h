@@ -58,6 +58,8 @@ typedef enum sfx_shape_type {
  * 2x2 tile block holds more grid-sorted colliders, hands its pairs to the fallback list */
 #define SFX_TILE_MAX_PAIRS 2048u
 #define SFX_TILE_MAX_BODIES 1024u
+#define SFX_TILE_WHOLE_GRID 0xFFFFu  /* sfx_config.tile_cells: one tile for the whole grid */
+#define SFX_ONE_TILE_COLLIDERS 512u   /* automatic tiling: worlds up to this many colliders are one tile */
 #define SFX_FALLBACK_TILE 0xFFFFFFFFu
 
 /* physics config struct (BASELINE.json:5 "physics config") */
@@ -73,8 +75,11 @@ typedef struct sfx_config {
     uint32_t grid_log2[2];  /* wrapped grid is 2^gx by 2^gy cells; 0 = auto          */
     uint32_t max_pairs;     /* candidate pair capacity; 0 = 12 * bodies              */
     uint32_t color_rounds;  /* parallel colouring rounds before the serial finish; 0 = 12 */
-    uint32_t tile_cells;    /* solver tile width in grid cells: 2, 4 or 8; 0 = 2 (a tile is at least two
-                               cells wide and high: DESIGN.md "Tiles, classes, phases")            */
+    uint32_t tile_cells;    /* solver tile width in grid cells: 2, 4 or 8 (a tile is at least two cells wide
+                               and high: DESIGN.md "Tiles, classes, phases"), or SFX_TILE_WHOLE_GRID: ONE
+                               tile, the whole grid -- every pair is an interior pair, one unit, one
+                               colouring, no seam phases.  0 = automatic (with tile_cells_y == 0): the whole
+                               grid for a world of at most SFX_ONE_TILE_COLLIDERS colliders at upload, else 2 */
     uint32_t tile_cells_y;  /* solver tile height in grid cells, a power of two >= 2; anything >= the
                                grid height makes full-height strips: then a sweep has two
                                phases (interior pairs, seam pairs) instead of four.  0 = automatic,
@@ -94,13 +99,13 @@ typedef struct sfx_config {
     uint32_t flags;         /* SFX_CFG_* */
 } sfx_config;
 
-#define SFX_CFG_MULTI_LAUNCH 1u  /* never take the one-workgroup path.  Default: a tiny, sparse world (at most 512 bodies
-                                    and, by the last counters read back, at most 1024 pairs in at most 8 colours) runs
-                                    its substeps in ONE workgroup with the bodies in LDS -- one launch per sfx_step, one
-                                    per sfx_tick_substep -- with bit-identical results (scheduling only)   */
-#define SFX_CFG_ONE_WORKGROUP 8u /* a world of at most 2048 bodies takes the one-workgroup path whatever its pair and
-                                    colour counts, from its first tick on (slower than the default for most worlds
-                                    above a few hundred bodies: measured in DESIGN.md)                              */
+#define SFX_CFG_MULTI_LAUNCH 1u  /* never take the one-workgroup path.  Default: a world that is ONE tile (tile_cells:
+                                    automatic up to SFX_ONE_TILE_COLLIDERS colliders) runs its substeps in ONE
+                                    workgroup with the bodies in LDS -- one launch per sfx_step, one per
+                                    sfx_tick_substep -- with bit-identical results (scheduling only)       */
+#define SFX_CFG_ONE_WORKGROUP 8u /* a world of at most 2048 bodies takes the one-workgroup path whatever its tiling
+                                    (slower than the default for tiled worlds above a few hundred bodies: measured
+                                    in DESIGN.md)                                                                   */
 #define SFX_CFG_NO_FRICTION 2u   /* skip static + dynamic friction (debug)          */
 #define SFX_CFG_ONE_LEVEL 4u     /* broadphase grid without its second level: every collider too large for a base
                                     cell goes on the flat list (tested against everything)                     */

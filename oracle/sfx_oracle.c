@@ -107,7 +107,8 @@ static void resolve_defaults(sfx_config* c) {
     if (c->color_rounds == 0) c->color_rounds = 12;
     if (c->color_rounds > 60) c->color_rounds = 60;
     /* tiles are at least two cells wide and high: the seams of one class then never share a body (tile order below) */
-    if (c->tile_cells >= 8) c->tile_cells = 8;
+    if (c->tile_cells == 0 || c->tile_cells == SFX_TILE_WHOLE_GRID) { /* automatic / one tile: resolve_grid */ }
+    else if (c->tile_cells >= 8) c->tile_cells = 8;
     else if (c->tile_cells >= 4) c->tile_cells = 4;
     else c->tile_cells = 2;
     if (c->restitution_threshold == 0.0f) c->restitution_threshold = 2.0f;
@@ -316,6 +317,14 @@ static void resolve_grid(sfo_world* w) {
     if (w->tly < gy && gy < w->tly + 2) w->tly = gy; /* fewer than four tile rows: one row (strips) */
     if (gx > 12) gx = 12;
     if (gy > 12) gy = 12;
+    /* [DESIGN] one tile for the whole grid (DESIGN.md "Contract / tiles"): asked for, or automatic for small worlds --
+     * every pair is then an interior pair of the one unit: one colouring, no seam phase */
+    uint32_t nshape = 0;
+    for (uint32_t i = 0; i < w->n; ++i) nshape += w->col[i].type != SFX_SHAPE_NONE;
+    if (w->cfg.tile_cells == SFX_TILE_WHOLE_GRID ||
+        (w->cfg.tile_cells == 0 && w->cfg.tile_cells_y == 0 && nshape <= SFX_ONE_TILE_COLLIDERS)) {
+        w->tlx = gx; w->tly = gy;
+    }
     w->gxl = gx; w->gyl = gy;
 }
 
@@ -387,7 +396,7 @@ void sfo_resolved_config(const sfo_world* w, sfx_config* out) {
     out->grid_log2[0] = w->gxl;
     out->grid_log2[1] = w->gyl;
     out->max_pairs = w->max_pairs;
-    out->tile_cells = 1u << w->tlx;
+    out->tile_cells = (w->tlx == w->gxl && w->tly == w->gyl) ? SFX_TILE_WHOLE_GRID : 1u << w->tlx;
     out->tile_cells_y = 1u << w->tly;
 }
 
@@ -961,7 +970,9 @@ static void build_order(sfo_world* w, float frame_dt) {
         w->owner[e] = own;
         w->pclass[e] = 0;
         if (own != SFO_FALLBACK && w->is_small[a] && w->is_small[b]) {
-            int ddx = txa != txb, ddy = ly ? (tya != tyb) : 0; /* one tile row: every home tile is in it */
+            /* (wrapped tile coordinates: with one tile column / row every home tile is the same one) */
+            int ddx = (((uint32_t)txa ^ (uint32_t)txb) & ((1u << lx) - 1u)) != 0;
+            int ddy = (((uint32_t)tya ^ (uint32_t)tyb) & ((1u << ly) - 1u)) != 0;
             w->pclass[e] = (uint8_t)(ddx ? (ddy ? 3 : 1) : (ddy ? 2 : 0));
         }
         if (own != SFO_FALLBACK) tcnt[own]++;
@@ -971,7 +982,7 @@ static void build_order(sfo_world* w, float frame_dt) {
         if (!tcnt[t]) continue;
         uint32_t tx = t & ((1u << lx) - 1u), ty = t >> lx, nb = 0;
         for (int dy = 0; dy < (ly ? 2 : 1); ++dy) /* one tile row (strips): the block is two tiles, not four */
-            for (int dx = 0; dx < 2; ++dx) nb += tbodies[wrapped_tile(w, (int32_t)tx + dx, (int32_t)ty + dy)];
+            for (int dx = 0; dx < (lx ? 2 : 1); ++dx) nb += tbodies[wrapped_tile(w, (int32_t)tx + dx, (int32_t)ty + dy)];
         if (tcnt[t] > SFX_TILE_MAX_PAIRS || nb > SFX_TILE_MAX_BODIES) { tover[t] = 1; continue; }
         if (tcnt[t] > w->max_tile_pairs) w->max_tile_pairs = tcnt[t];
         if (nb > w->max_tile_bodies) w->max_tile_bodies = nb;

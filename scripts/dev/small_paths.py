@@ -8,6 +8,11 @@ DT = 1.0 / 60.0
 cases = {
     "pyramid (496 boxes, 10 substeps)": scenes.pyramid(),
     "soup 300": scenes.random_soup(300, seed=1, extent=4.0),
+    "soup 150 dense": scenes.random_soup(150, seed=6, extent=2.0),
+    "soup 500": scenes.random_soup(500, seed=7, extent=5.0),
+    "soup 500 dense": scenes.random_soup(500, seed=8, extent=3.5),
+    "soup 400 + joints + compounds": scenes.random_soup(400, seed=9, extent=5.0, joints=0.5, compounds=0.2),
+    "circles 500": scenes.circles_container(n=500, width=30, floor_hw=5.0, wall_hh=8.0),
     "soup 1000": scenes.random_soup(1000, seed=2, extent=7.0),
     "soup 2000": scenes.random_soup(2000, seed=3, extent=10.0),
     "soup 600 + joints + compounds": scenes.random_soup(600, seed=4, extent=6.0, joints=0.5, compounds=0.2),

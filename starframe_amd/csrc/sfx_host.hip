@@ -230,7 +230,8 @@ void resolve_defaults(sfx_config& c) {
     if (c.substeps == 0) c.substeps = 1;
     if (c.color_rounds == 0) c.color_rounds = 12;
     if (c.color_rounds > 60) c.color_rounds = 60;
-    c.tile_cells = c.tile_cells >= 8 ? 8u : c.tile_cells >= 4 ? 4u : 2u;   // at least two cells: DESIGN.md "Contract / tiles"
+    if (c.tile_cells != 0u && c.tile_cells != SFX_TILE_WHOLE_GRID)   // (0: automatic, WHOLE_GRID: one tile -- resolve_grid)
+        c.tile_cells = c.tile_cells >= 8 ? 8u : c.tile_cells >= 4 ? 4u : 2u;   // at least two cells: DESIGN.md "Contract / tiles"
     if (c.speculative_margin == 0.0f) c.speculative_margin = 0.005f;
     if (c.speculative_margin < 0.0f) c.speculative_margin = 0.0f;
     if (c.restitution_threshold == 0.0f) c.restitution_threshold = 2.0f;
@@ -341,6 +342,14 @@ void resolve_grid(sfx_world* w) {
     }
     w->tly = std::min(w->tly, gy);
     if (w->tly < gy && gy < w->tly + 2u) w->tly = gy;   // fewer than four tile rows: one row (strips)
+    // one tile for the whole grid (DESIGN.md "Contract / tiles"): asked for, or automatic for small worlds -- every pair is
+    // then an interior pair of the one unit: one colouring, no seam phase.  Same rule as the oracle's.
+    uint32_t nshape = 0;
+    for (uint32_t i = 0; i < w->n; ++i) nshape += w->h_col[i].type != SFX_SHAPE_NONE;
+    if (w->cfg.tile_cells == SFX_TILE_WHOLE_GRID ||
+        (w->cfg.tile_cells == 0u && w->cfg.tile_cells_y == 0u && nshape <= SFX_ONE_TILE_COLLIDERS)) {
+        w->tlx = gx; w->tly = gy;
+    }
     w->gxl = gx; w->gyl = gy;
     w->ncell = (1u << gx) * (1u << gy);
     // second level: cells eight times as wide on the same torus (gx >= tile width + 2 >= 3 and gy >= 3 above)
@@ -1115,15 +1124,13 @@ int sfx_tick_begin(sfx_world* w, float frame_dt) {
 static int substeps_done(sfx_world* w, uint32_t count, bool mirror);
 
 // Small worlds (sfx_kernels.h k_small_substeps): whole substeps in one workgroup, the bodies in LDS.  Measured on MI355X
-// (profiles/r02/small_world_paths.log): it saves launches (a dependent launch boundary is ~1.5 us) but gives up the
-// device -- one workgroup steps through the colours of ALL batches of a phase where the launch-per-stage path runs every
-// batch on a CU of its own with its own colour count -- so it wins only for tiny, sparse worlds (pyramid of 496 boxes
-// x1.06, 8 chains of 60 links x1.11) and loses from a few hundred bodies with ten colours on (soup of 300: x0.83,
-// 1000 circles: x0.72).  Taken by itself only there: at most 512 bodies and, by the last counters read back, at most
-// 1024 pairs in at most 8 colours; SFX_CFG_ONE_WORKGROUP takes it for any world of at most kSmallBodies bodies,
-// SFX_CFG_MULTI_LAUNCH (or SFX_SMALL_WORLDS=0 in the environment) never.  Not under profiling (the launch-per-stage
-// path has the per-stage events).  Both paths give the same bits, so a world may change between them from tick to tick.
-constexpr uint32_t kAutoSmallBodies = 512, kAutoSmallPairs = 1024, kAutoSmallColors = 8;
+// (profiles/r02/small_world_paths.log): it saves launches and hand-offs but gives up the device -- one workgroup steps through
+// the colours of ALL batches of a phase where the launch-per-stage path runs every batch on a CU of its own -- so it wins
+// where there is one batch anyway: the worlds that are ONE tile (automatic up to SFX_ONE_TILE_COLLIDERS colliders: x1.02 to
+// x1.39 on every scene tried) and loses on tiled worlds from a few hundred bodies on (1000 circles x0.70, soup of 2000 x0.37).
+// Taken by itself exactly for one-tile worlds; SFX_CFG_ONE_WORKGROUP takes it for any world of at most kSmallBodies bodies,
+// SFX_CFG_MULTI_LAUNCH (or SFX_SMALL_WORLDS=0 in the environment) never.  Not under profiling (the launch-per-stage path has
+// the per-stage events).  Both paths give the same bits.
 static const bool g_small_off = [] { const char* e = getenv("SFX_SMALL_WORLDS"); return e && e[0] == '0'; }();
 
 static bool small_world(const sfx_world* w) {
@@ -1131,7 +1138,7 @@ static bool small_world(const sfx_world* w) {
         w->joint_color_start.size() > (size_t)SFX_MAX_COLORS + 1)
         return false;
     if (w->cfg.flags & SFX_CFG_ONE_WORKGROUP) return true;
-    return w->nb <= kAutoSmallBodies && w->ctr_valid && w->stale.n_pairs <= kAutoSmallPairs && w->stale.n_colors <= kAutoSmallColors;
+    return w->tlx == w->gxl && w->tly == w->gyl;
 }
 
 static int small_substeps(sfx_world* w, uint32_t nsub) {

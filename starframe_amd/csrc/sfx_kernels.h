@@ -631,8 +631,9 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
             // home tiles lie; it rides in the two top bits of the pair's second slot word
             uint32_t cls = 0u;
             if (small_slot && r >= 1 && r < 5) {
-                const bool ddx = (ncx >> g.tlx) != txp;
-                const bool ddy = g.tly != g.gyl && (ncy >> g.tly) != typ;   // one tile row (strips): every home tile is in it
+                // (wrapped tile coordinates: with one tile column / row every home tile is the same one)
+                const bool ddx = ((uint32_t)((ncx >> g.tlx) ^ txp) & ((1u << (g.gxl - g.tlx)) - 1u)) != 0u;
+                const bool ddy = ((uint32_t)((ncy >> g.tly) ^ typ) & ((1u << (g.gyl - g.tly)) - 1u)) != 0u;
                 cls = ddx ? (ddy ? 3u : 1u) : (ddy ? 2u : 0u);
             }
             if (x < L) {
@@ -734,12 +735,13 @@ __device__ __forceinline__ void block_ranges(uint32_t t, const GridParams& g, co
     const uint32_t lx = g.gxl - g.tlx;
     const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
     const bool one_row = g.tly == g.gyl;  // strips: the block is two tiles, the upper two would repeat them
+    const bool one_col = g.tlx == g.gxl;  // one tile column (the whole grid as one tile): the right-hand ones likewise
     uint32_t run = 0;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const uint32_t tk = tile_of(tx + (k & 1), ty + (k >> 1), g);
         R.ts[k] = cell_start[tk << (g.tlx + g.tly)];
-        R.te[k] = (one_row && k >= 2) ? R.ts[k] : cell_start[(tk + 1u) << (g.tlx + g.tly)];
+        R.te[k] = ((one_row && k >= 2) || (one_col && (k & 1))) ? R.ts[k] : cell_start[(tk + 1u) << (g.tlx + g.tly)];
         R.off[k] = run;
         run += R.te[k] - R.ts[k];
     }
@@ -906,7 +908,7 @@ __device__ __forceinline__ void batch_ranges(const uint32_t* __restrict__ tiles,
         const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
         const uint32_t tk = tile_of(tx + (int32_t)(k & 1u), ty + (int32_t)(k >> 1), g);
         const uint32_t a = cell_start[tk << (g.tlx + g.tly)];
-        const uint32_t b = (g.tly == g.gyl && k >= 2u) ? a : cell_start[(tk + 1u) << (g.tlx + g.tly)];
+        const uint32_t b = ((g.tly == g.gyl && k >= 2u) || (g.tlx == g.gxl && (k & 1u))) ? a : cell_start[(tk + 1u) << (g.tlx + g.tly)];
         S.rs[threadIdx.x] = a;
         S.off[threadIdx.x + 1] = b - a;  // lengths first, prefix below
     }

@@ -115,7 +115,7 @@ def test_default_config(libsfx):
     libsfx.sfx_default_config(C.byref(cfg))
     assert cfg.struct_size == C.sizeof(_abi.SfxConfig)
     assert cfg.substeps == 4 and abs(cfg.gravity[1] + 9.81) < 1e-6
-    assert cfg.color_rounds == 12 and cfg.tile_cells == 2
+    assert cfg.color_rounds == 12 and cfg.tile_cells == 0   # 0: automatic (one tile for small worlds, else 2 cells)
 
 
 def test_create_fails_loudly_without_gpu(libsfx):

@@ -760,3 +760,49 @@ def test_velocities_derived_where_first_read_equal_the_separate_pass():
     assert a.stats().launches < b.stats().launches
     a.close()
     b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,extent,kw,one", [
+    (300, 4.0, dict(), True),                                   # automatic: at most SFX_ONE_TILE_COLLIDERS colliders
+    (300, 4.0, dict(tile_cells=2), False),                      # tiles asked for
+    (800, 9.0, dict(tile_cells=0xFFFF), True),                  # one tile asked for, within a tile's capacity
+    (450, 5.0, dict(tile_cells=0xFFFF, tile_cells_y=2), True),  # (the height is then the grid's too)
+    (1000, 4.5, dict(tile_cells=0xFFFF), True),                 # more pairs than a tile holds: all on the fallback list
+], ids=["auto", "tiles_asked", "whole_grid", "whole_grid_y", "whole_grid_overfull"])
+def test_one_tile_worlds_match_oracle(n, extent, kw, one):
+    """The whole grid as ONE tile (DESIGN.md "Contract / tiles"): every pair -- also those across the torus' wrap lines --
+    is an interior pair of the one unit: one colouring, no seam phase.  Pairs, units, colours and three ticks against
+    the oracle; such a world runs its substeps in one workgroup unless told otherwise, with the same bits."""
+    from oracle.oracle import ORDER_COLORED
+    from starframe_amd._abi import CFG_MULTI_LAUNCH
+
+    s = scenes.random_soup(n, seed=31, extent=extent, offsets=0.3, compounds=0.1 if n < 1000 else 0.0)
+    g, o = make_pair(s, **kw)
+    m, _ = make_pair(s, flags=CFG_MULTI_LAUNCH, **kw)
+    g.broadphase(DT)
+    o.broadphase(DT)
+    assert np.array_equal(g.pairs(), o.pairs())
+    gk, gc, gt = colors_by_key(*g.pair_colors())
+    ok, oc, ot = colors_by_key(*o.pair_colors())
+    assert np.array_equal(gk, ok) and np.array_equal(gt, ot) and np.array_equal(gc, oc)
+    gs, os_ = g.stats(), o.stats()
+    assert (gs.n_pairs, gs.n_solver_pairs, gs.n_fallback, gs.n_colors) == (os_.n_pairs, os_.n_solver_pairs, os_.n_fallback, os_.n_colors)
+    tile_units = gt[gt != 0xFFFFFFFF] if len(gt) else gt
+    if one:
+        assert np.all(tile_units == 0)            # unit = class << 28 | tile: the interior class of tile 0
+    else:
+        assert len(np.unique(tile_units)) > 1
+    if n == 1000:
+        assert gs.n_fallback == gs.n_pairs > 2048
+    for _ in range(3):
+        g.step(DT)
+        m.step(DT)
+        o.step(DT, ORDER_COLORED)
+    assert g.stats().overflow == 0 and o.stats().overflow == 0
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= TOL and rel_err(g.poses()[1], o.poses()[1], floor=1.0) <= TOL
+    assert rel_err(g.velocities()[0], o.velocities()[0], floor=1.0) <= 1e-4
+    for a, b in zip(g.poses() + g.velocities(), m.poses() + m.velocities()):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    if one and n <= 2048:
+        assert g.stats().launches < m.stats().launches      # one launch for the substeps

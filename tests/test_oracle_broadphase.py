@@ -199,7 +199,17 @@ def test_auto_grid_and_cell_resolution():
     assert rc.cell_size > 0.4
     assert rc.grid_log2[0] == rc.grid_log2[1] == 5
     assert rc.max_pairs == 12 * s.n
-    assert rc.tile_cells == 2 and rc.tile_cells_y == 32   # sparse scene: automatic full-height strips
+    assert rc.tile_cells == 0xFFFF and rc.tile_cells_y == 32   # at most SFX_ONE_TILE_COLLIDERS colliders: the whole grid is ONE tile
+    w.broadphase(1.0 / 60.0)
+    k, c, t = w.pair_colors()
+    assert len(k) and np.all(t == 0)                            # ... every pair an interior pair of the one unit
+    rc = OracleWorld.from_scene(s, tile_cells=2).resolved_config()
+    assert rc.tile_cells == 2 and rc.tile_cells_y == 32         # asked for tiles: sparse scene, automatic full-height strips
+    big = scenes.random_soup(1000, seed=2, extent=6.0)
+    rc = OracleWorld.from_scene(big).resolved_config()
+    assert rc.tile_cells == 2                                   # larger worlds are tiled
+    rc = OracleWorld.from_scene(big, tile_cells=0xFFFF).resolved_config()
+    assert rc.tile_cells == 0xFFFF                              # unless one tile is asked for
 
 
 @pytest.mark.parametrize("speed", [0.0, 1.5])
