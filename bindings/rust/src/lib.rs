@@ -32,6 +32,8 @@ pub const SFX_MAX_COLORS: usize = 64;
 pub const SFX_MAX_TAN_CORRECTION: f32 = 0.25;
 pub const SFX_TILE_MAX_PAIRS: u32 = 2048;
 pub const SFX_TILE_MAX_BODIES: u32 = 1024;
+pub const SFX_TILE_WHOLE_GRID: u32 = 0xFFFF;
+pub const SFX_ONE_TILE_COLLIDERS: u32 = 512;
 pub const SFX_CFG_MULTI_LAUNCH: u32 = 1;
 pub const SFX_CFG_NO_FRICTION: u32 = 2;
 pub const SFX_CFG_ONE_LEVEL: u32 = 4;
@@ -72,7 +74,7 @@ pub struct sfx_config {
     pub grid_log2: [u32; 2],
     pub max_pairs: u32,
     pub color_rounds: u32,
-    pub tile_cells: u32,   // 2, 4 or 8 grid cells; 0 = 2
+    pub tile_cells: u32,   // 2, 4 or 8 grid cells, or SFX_TILE_WHOLE_GRID; 0 = automatic (one tile up to 512 colliders, else 2)
     pub tile_cells_y: u32, // 0 = automatic (strips for wide, shallow scenes)
     pub restitution_threshold: f32,
     pub max_depenetration_velocity: f32, // 0 = unlimited
