@@ -34,6 +34,7 @@ pub const SFX_TILE_MAX_PAIRS: u32 = 2048;
 pub const SFX_TILE_MAX_BODIES: u32 = 1024;
 pub const SFX_TILE_WHOLE_GRID: u32 = 0xFFFF;
 pub const SFX_ONE_TILE_COLLIDERS: u32 = 512;
+pub const SFX_ONE_TILE_LARGE: u32 = 64;
 pub const SFX_CFG_MULTI_LAUNCH: u32 = 1;
 pub const SFX_CFG_NO_FRICTION: u32 = 2;
 pub const SFX_CFG_ONE_LEVEL: u32 = 4;

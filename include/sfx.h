@@ -59,7 +59,8 @@ typedef enum sfx_shape_type {
 #define SFX_TILE_MAX_PAIRS 2048u
 #define SFX_TILE_MAX_BODIES 1024u
 #define SFX_TILE_WHOLE_GRID 0xFFFFu  /* sfx_config.tile_cells: one tile for the whole grid */
-#define SFX_ONE_TILE_COLLIDERS 512u   /* automatic tiling: worlds up to this many colliders are one tile */
+#define SFX_ONE_TILE_COLLIDERS 512u   /* automatic tiling: worlds up to this many colliders are one tile ...            */
+#define SFX_ONE_TILE_LARGE 64u        /* ... unless more than this many of them may be too large for a base grid cell */
 #define SFX_FALLBACK_TILE 0xFFFFFFFFu
 
 /* physics config struct (BASELINE.json:5 "physics config") */
@@ -79,7 +80,8 @@ typedef struct sfx_config {
                                and high: DESIGN.md "Tiles, classes, phases"), or SFX_TILE_WHOLE_GRID: ONE
                                tile, the whole grid -- every pair is an interior pair, one unit, one
                                colouring, no seam phases.  0 = automatic (with tile_cells_y == 0): the whole
-                               grid for a world of at most SFX_ONE_TILE_COLLIDERS colliders at upload, else 2 */
+                               grid for a world of at most SFX_ONE_TILE_COLLIDERS colliders at upload, of
+                               which at most SFX_ONE_TILE_LARGE larger than a grid cell; else 2          */
     uint32_t tile_cells_y;  /* solver tile height in grid cells, a power of two >= 2; anything >= the
                                grid height makes full-height strips: then a sweep has two
                                phases (interior pairs, seam pairs) instead of four.  0 = automatic,

@@ -319,10 +319,16 @@ static void resolve_grid(sfo_world* w) {
     if (gy > 12) gy = 12;
     /* [DESIGN] one tile for the whole grid (DESIGN.md "Contract / tiles"): asked for, or automatic for small worlds --
      * every pair is then an interior pair of the one unit: one colouring, no seam phase */
-    uint32_t nshape = 0;
-    for (uint32_t i = 0; i < w->n; ++i) nshape += w->col[i].type != SFX_SHAPE_NONE;
+    /* (automatic only while the colliders that may be too large for a base cell -- the ones a tile's batch keeps in its
+     * SFX_ONE_TILE_LARGE outside-body slots -- all fit one batch: a level of many platforms stays tiled) */
+    uint32_t nshape = 0, nbig = 0;
+    for (uint32_t i = 0; i < w->n; ++i) {
+        if (w->col[i].type == SFX_SHAPE_NONE) continue;
+        nshape++;
+        if (!(shape_diameter(w, &w->col[i]) + 2.0f * (w->cfg.aabb_margin + w->cfg.vel_pad_max) <= 0.9f * cell)) nbig++;
+    }
     if (w->cfg.tile_cells == SFX_TILE_WHOLE_GRID ||
-        (w->cfg.tile_cells == 0 && w->cfg.tile_cells_y == 0 && nshape <= SFX_ONE_TILE_COLLIDERS)) {
+        (w->cfg.tile_cells == 0 && w->cfg.tile_cells_y == 0 && nshape <= SFX_ONE_TILE_COLLIDERS && nbig <= SFX_ONE_TILE_LARGE)) {
         w->tlx = gx; w->tly = gy;
     }
     w->gxl = gx; w->gyl = gy;

@@ -344,10 +344,17 @@ void resolve_grid(sfx_world* w) {
     if (w->tly < gy && gy < w->tly + 2u) w->tly = gy;   // fewer than four tile rows: one row (strips)
     // one tile for the whole grid (DESIGN.md "Contract / tiles"): asked for, or automatic for small worlds -- every pair is
     // then an interior pair of the one unit: one colouring, no seam phase.  Same rule as the oracle's.
-    uint32_t nshape = 0;
-    for (uint32_t i = 0; i < w->n; ++i) nshape += w->h_col[i].type != SFX_SHAPE_NONE;
+    // (automatic only while the colliders that may be too large for a base cell -- the ones a batch keeps in its kMaxExt
+    // outside-body slots -- all fit one batch: a level of many platforms stays tiled)
+    static_assert(SFX_ONE_TILE_LARGE <= kMaxExt, "one batch holds every large collider of a one-tile world");
+    uint32_t nshape = 0, nbig = 0;
+    for (uint32_t i = 0; i < w->n; ++i) {
+        if (w->h_col[i].type == SFX_SHAPE_NONE) continue;
+        nshape++;
+        if (!(shape_diameter(w, w->h_col[i]) + 2.0f * (w->cfg.aabb_margin + w->cfg.vel_pad_max) <= 0.9f * cell)) nbig++;
+    }
     if (w->cfg.tile_cells == SFX_TILE_WHOLE_GRID ||
-        (w->cfg.tile_cells == 0u && w->cfg.tile_cells_y == 0u && nshape <= SFX_ONE_TILE_COLLIDERS)) {
+        (w->cfg.tile_cells == 0u && w->cfg.tile_cells_y == 0u && nshape <= SFX_ONE_TILE_COLLIDERS && nbig <= SFX_ONE_TILE_LARGE)) {
         w->tlx = gx; w->tly = gy;
     }
     w->gxl = gx; w->gyl = gy;

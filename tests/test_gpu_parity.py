@@ -806,3 +806,24 @@ def test_one_tile_worlds_match_oracle(n, extent, kw, one):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     if one and n <= 2048:
         assert g.stats().launches < m.stats().launches      # one launch for the substeps
+
+
+@pytest.mark.gpu
+def test_small_level_with_many_platforms_stays_tiled():
+    """A small world whose large colliders (wider than a grid cell: platforms) outnumber the 64 outside-body slots of a
+    batch is NOT made one tile by itself: tiles spread them.  Sixty bodies falling over a hundred platforms: no overflow,
+    the oracle's pairs, colours and poses; asked for as one tile, the same world reports the overflow on both sides."""
+    from oracle.oracle import ORDER_COLORED
+    from starframe_amd.world import SfxError
+
+    s = scenes.random_soup(60, seed=3, extent=12.0, platforms=100, speed=0.5)
+    g, o = make_pair(s, cell_size=0.6)
+    assert o.resolved_config().tile_cells == 2
+    for _ in range(30):
+        g.step(DT)
+        o.step(DT, ORDER_COLORED)
+    assert g.stats().overflow == 0 and o.stats().overflow == 0
+    assert np.array_equal(g.pairs(), o.pairs())
+    assert rel_err(g.poses()[0], o.poses()[0], floor=1.0) <= 1e-4   # (thirty ticks: roundoff grows)
+    g.close()
+    o.close()

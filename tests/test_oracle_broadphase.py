@@ -210,6 +210,10 @@ def test_auto_grid_and_cell_resolution():
     assert rc.tile_cells == 2                                   # larger worlds are tiled
     rc = OracleWorld.from_scene(big, tile_cells=0xFFFF).resolved_config()
     assert rc.tile_cells == 0xFFFF                              # unless one tile is asked for
+    level = scenes.random_soup(60, seed=3, extent=12.0, platforms=100)   # a level: 100 platforms wider than a cell
+    rc = OracleWorld.from_scene(level, cell_size=0.6).resolved_config()
+    assert rc.tile_cells == 2                                   # more large colliders than one batch keeps: tiled
+    assert OracleWorld.from_scene(level).resolved_config().tile_cells == 0xFFFF   # (automatic cells are as large as its big boxes)
 
 
 @pytest.mark.parametrize("speed", [0.0, 1.5])
