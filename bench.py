@@ -73,19 +73,22 @@ def penetration_mm(w):
             "p99": round(1e3 * float(p99), 2), "max": round(1e3 * float(d.max()), 2)}
 
 
-def kernel_bytes(st):
+def kernel_bytes(st, derive_bodies=0):
     """Algorithmic (compulsory) bytes of ONE launch of each contact-sweep kernel (one launch per substep),
     from the tick's measured counts.  DESIGN.md "Kernels": P = solver pairs, M = touching pairs (manifolds),
     M2 = of which with two points.
       k_narrow   : P x (16 order (ids + slot) + 2 x (16 pose + 16 shape) read, 8 count written)
                    + M x (2 x 16 velocity read; 16 normal/friction + 16 anchors + 8 lambda + 8 pre-velocity written) + M2 x 16
       k_tile_pos : P x (16 pair + 8 count read) + M x (32 record + 2 x (16 pose + 8 mass) read; 8 lambda + 2 x 16 pose written) + M2 x 16
-      k_tile_vel : P x (16 + 8 read) + M x (48 record + 2 x (16 pose + 16 velocity + 8 mass) read; 2 x 16 velocity written) + M2 x 16"""
+      k_tile_vel : P x (16 + 8 read) + M x (48 record + 2 x (16 pose + 16 velocity + 8 mass) read; 2 x 16 velocity written) + M2 x 16
+                   + derive_bodies x 16: inside sfx_step the kernel also derives the velocities (DESIGN.md "Velocities derived where
+                   they are first read"): the start-of-substep pose of every dynamic body, read once; pose, mass and the
+                   velocity written are in the pair terms already"""
     P, M, M2 = float(st.n_solver_pairs), float(st.n_manifolds), float(st.n_manifolds2)
     return {
         "narrow": P * 88.0 + M * 80.0 + M2 * 16.0,
         "solve_pos": P * 24.0 + M * 120.0 + M2 * 16.0,
-        "solve_vel": P * 24.0 + M * 160.0 + M2 * 16.0,
+        "solve_vel": P * 24.0 + M * 160.0 + M2 * 16.0 + 16.0 * derive_bodies,
     }
 
 
@@ -339,7 +342,8 @@ def main():
     w.set_profiling(False)
     st2 = w.stats()
     pen = penetration_mm(w) if slab is None else None   # after everything timed: it runs a broadphase of its own
-    kb = kernel_bytes(st2)
+    derive_bodies = scene.n_dynamic() if slab is None else 0   # sfx_step derives on load; the slab driver steps substep by substep
+    kb = kernel_bytes(st2, derive_bodies)
     per_kernel = {}
     for cls, nbytes in kb.items():
         k = kt[cls]
@@ -354,7 +358,7 @@ def main():
     measured_over = f"{prof_frames} further ticks after the timed region (the dominant kernel was not among --live-events)"
     if dom in kt_live and kt_live[dom]["launches"]:
         k = kt_live[dom]
-        nbytes = kernel_bytes(st)[dom]
+        nbytes = kernel_bytes(st, derive_bodies)[dom]
         live_ticks = len(range(0, args.steps, every))
         per_launch = k["launches"] / (live_ticks * scene.substeps)
         dur = 1e-3 * k["total_ms"] / k["launches"]
