@@ -184,6 +184,77 @@ def load_traffic(cls):
         return None
 
 
+def free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* as torchrun sets them), relay rank 0's JSON line, return non-zero when any rank failed.  The parent makes no
+    GPU call and never falls through to the N = 1 workload.  The first rank to fail ends the others (by their process
+    ids): ranks left alone would wait for it in a collective for ever."""
+    import subprocess
+
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR=os.environ.get("MASTER_ADDR", "127.0.0.1"),
+               MASTER_PORT=os.environ.get("MASTER_PORT") or str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc, line = 0, b""
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                try:
+                    if r == 0:
+                        out, _ = procs[0].communicate(timeout=0.5)   # drains the pipe while waiting
+                        line = out or b""
+                    else:
+                        procs[r].wait(timeout=0.5)
+                except subprocess.TimeoutExpired:
+                    continue
+                pending.discard(r)
+                if procs[r].returncode != 0:
+                    rc = rc or procs[r].returncode or 1
+                    print(f"bench.py: rank {r} exited with {procs[r].returncode}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if rc == 0:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    return rc
+
+
+def dry_run(args, rank, world):
+    """Everything of the launch that needs no GPU: the environment, the rendezvous (gloo) and one collective."""
+    fail = os.environ.get("SFX_BENCH_FAIL_RANK")
+    if fail is not None and int(fail) == rank:
+        raise SystemExit(3)
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([1.0])
+        dist.all_reduce(t)
+        assert int(t.item()) == world
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -207,15 +278,26 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks that SHARE GPU 0, process group over gloo, halos through host memory: everything of the "
                          "N > 1 path except RCCL (cuts, ghosts, guard, re-cuts, gather, timing); the line says so and is no result")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="argument handling, self-launch and rendezvous only (gloo, no GPU, no library): prints a line with "
+                         "n_gpus and \"dry_run\": true; what tests/test_bench_launch.py runs on the CPU")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started plainly (`python bench.py --gpus N`, the way the driver starts the N = 1 line): this process becomes
+        # the launcher -- it never touches the GPU -- and runs one child per GPU with the torchrun environment
+        raise SystemExit(self_launch(args.gpus))
     rank, local_rank, world = dist_env()
+    if world != args.gpus:
+        raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}: start N ranks (torchrun) or none (bench.py starts them itself)")
+    if args.dry_run:
+        return dry_run(args, rank, world)
     # stdout carries the one JSON line and nothing else: what libraries print to file descriptor 1 (RCCL's version
     # banner at communicator creation) goes to stderr until the line is printed
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
 
     from starframe_amd import scenes
     from starframe_amd.world import World
