@@ -95,7 +95,8 @@ typedef struct sfx_config {
                                substeps 73 bodies -- and deeper piles collapse       */
     float speculative_margin; /* the narrowphase keeps contact points up to this far apart
                                (negative depth; they only push once they penetrate);
-                               0 = 0.005 m; negative = none                              */
+                               0 = 0.010 m (contacts that open and close inside a sweep are otherwise missed:
+                               measured in DESIGN.md "Jitter"); negative = none          */
     float linear_damping;   /* 1/s: v *= 1 / (1 + h * c) every substep; 0 = none        */
     float angular_damping;  /* 1/s, same for the angular velocity                       */
     uint32_t flags;         /* SFX_CFG_* */

@@ -38,14 +38,25 @@ typedef struct {
     float r;
 } core_t;
 
-/* per candidate pair solver record: what the position solve leaves for the velocity pass */
+/* per candidate pair solver record ([DESIGN] DESIGN.md "Contract / frozen rows"): everything of the pair's constraint
+ * rows that depends on geometry and mass only, computed ONCE per substep by the narrowphase at the poses it sees
+ * (prepare_pair), so that the solves are a handful of multiply-adds per pair: no anchor is rotated, nothing is divided
+ * and no rotation is renormalised inside the sweeps */
 typedef struct {
-    uint32_t count;
-    float nx, ny;
-    float ra[2][2], rb[2][2]; /* body-local anchors */
-    float lam[2];             /* normal lambda of this substep */
-    float vn_pre[2];          /* normal relative velocity before the position solve */
-    float mu_s, mu_d, rest;
+    uint32_t count;     /* 0, 1 or 2 points */
+    uint32_t block;     /* count == 2 and both normal rows are solved as a block (K not near-singular) */
+    float nx, ny;       /* from a to b */
+    float mu_s, mu_d;
+    float ca[2], cb[2]; /* generalised lever arms of the normal rows AS THEY ACT on each side: ca = ra x n, cb = -(rb x n) */
+    float d0[2];        /* depth at the narrowphase poses */
+    float tgt[2];       /* normal velocity the velocity pass asks for: max(-e vn_pre, 0) */
+    float iK[2];        /* 1 / K00, 1 / K11 */
+    float i00, i01, i11, K01; /* K^-1 (with i01 = K01 / det) and K01 */
+    float cta, ctb;     /* lever arms of the tangent row t = (-ny, nx) at the mean anchor, as they act: ctb = -(mb x t) */
+    float Att, At[2];
+    float invS, invS0, invS1; /* 1 / Schur complement of the tangent row: every counted point active / only point 0 /
+                                 only point 1 (0 where it is not positive: no friction) */
+    float lam[2];       /* normal lambda of this substep */
 } pair_rec;
 
 struct sfo_world {
@@ -95,6 +106,8 @@ struct sfo_world {
     uint32_t phase_end[5]; /* batches of phase ph (4 = the fallback list) = [phase_end[ph-1], phase_end[ph]): the units of one
                             * phase share no dynamic body (the OpenMP build solves them side by side) */
     float tick_h;
+    float* dpos;   /* [3 nb] (dx, dy, dtheta) the position sweep of this substep has accumulated per body; applied once, before the derive */
+    float* dshift; /* [3 nb] static-friction pose shifts of the running velocity phase; applied at the end of the phase */
     pair_rec* rec;
     uint32_t n_contacts, n_manifolds, n_manifolds2;
     float max_depth;
@@ -115,7 +128,7 @@ static void resolve_defaults(sfx_config* c) {
     if (c->vel_pad_max == 0.0f) c->vel_pad_max = 0.03f;
     if (!(c->max_depenetration_velocity > 0.0f)) c->max_depenetration_velocity = INFINITY;
     if (c->vel_pad_max < 0.0f) c->vel_pad_max = 0.0f;
-    if (c->speculative_margin == 0.0f) c->speculative_margin = 0.005f;
+    if (c->speculative_margin == 0.0f) c->speculative_margin = 0.010f;
     if (c->speculative_margin < 0.0f) c->speculative_margin = 0.0f;
 }
 
@@ -134,7 +147,7 @@ void sfo_destroy(sfo_world* w) {
     free(w->poly_nrm); free(w->mats); free(w->joints); free(w->angles); free(w->joint_perm); free(w->joint_color);
     free(w->aabb); free(w->pa); free(w->pb); free(w->color); free(w->order); free(w->rec);
     free(w->ccx); free(w->ccy); free(w->is_small); free(w->owner); free(w->pclass); free(w->batch_end);
-    free(w->cbody);
+    free(w->cbody); free(w->dpos); free(w->dshift);
     free(w);
 }
 
@@ -378,6 +391,9 @@ int sfo_upload_colliders(sfo_world* w, uint32_t n, const sfx_collider* colliders
     w->color = (uint8_t*)malloc(w->max_pairs);
     w->order = (uint32_t*)malloc(w->max_pairs * sizeof(uint32_t));
     w->rec = (pair_rec*)calloc(w->max_pairs, sizeof(pair_rec));
+    free(w->dpos); free(w->dshift);
+    w->dpos = (float*)calloc(3u * (size_t)w->nb + 3, sizeof(float));
+    w->dshift = (float*)calloc(3u * (size_t)w->nb + 3, sizeof(float));
     w->owner = (uint32_t*)malloc(w->max_pairs * sizeof(uint32_t));
     w->pclass = (uint8_t*)calloc(w->max_pairs, 1);
     w->batch_end = (uint32_t*)malloc(((size_t)w->max_pairs + 2) * sizeof(uint32_t));
@@ -1432,6 +1448,7 @@ static void integrate(sfo_world* w, float h) {
     for (uint32_t i = 0; i < w->nb; ++i) {
         w->prev_pos[2 * i] = w->pos[2 * i]; w->prev_pos[2 * i + 1] = w->pos[2 * i + 1];
         w->prev_rot[2 * i] = w->rot[2 * i]; w->prev_rot[2 * i + 1] = w->rot[2 * i + 1];
+        w->dpos[3 * i] = 0.0f; w->dpos[3 * i + 1] = 0.0f; w->dpos[3 * i + 2] = 0.0f;
         if (w->inv_mass[i] > 0.0f) {
             w->vel[2 * i] = w->vel[2 * i] + gx * h;
             w->vel[2 * i + 1] = w->vel[2 * i + 1] + gy * h;
@@ -1447,6 +1464,14 @@ static void integrate(sfo_world* w, float h) {
     }
 }
 
+/* [DESIGN] "Contract / frozen rows": the solves accumulate a displacement (dx, dy, dtheta) per body; it is applied
+ * once -- the translation added, the rotation through rotate_by -- and a body that was not moved keeps its bits */
+static void apply_delta(sfo_world* w, uint32_t i, const float* d) {
+    w->pos[2 * i] = w->pos[2 * i] + d[0];
+    w->pos[2 * i + 1] = w->pos[2 * i + 1] + d[1];
+    if (d[2] != 0.0f) rotate_by(&w->rot[2 * i], &w->rot[2 * i + 1], d[2]);
+}
+
 /* [XPBD-RB] Alg. 2 lines 12-16; omega is the exact inverse of rotate_by: tan(dtheta)/h */
 static void derive_velocities(sfo_world* w, float inv_h) {
 #ifdef _OPENMP
@@ -1454,6 +1479,7 @@ static void derive_velocities(sfo_world* w, float inv_h) {
 #endif
     for (uint32_t i = 0; i < w->nb; ++i) {
         if (!is_dynamic(w, i)) continue;
+        apply_delta(w, i, &w->dpos[3 * i]); /* what the position sweep accumulated, once per body and substep */
         w->vel[2 * i] = (w->pos[2 * i] - w->prev_pos[2 * i]) * inv_h;
         w->vel[2 * i + 1] = (w->pos[2 * i + 1] - w->prev_pos[2 * i + 1]) * inv_h;
         float c = w->rot[2 * i], s = w->rot[2 * i + 1];
@@ -1491,37 +1517,49 @@ static float gen_inv_mass(const sfo_world* w, uint32_t i, float rx, float ry, fl
     return w->inv_mass[i] + w->inv_inertia[i] * (rn * rn);
 }
 
-/* world-space anchor of a body-local point */
-static void anchor_world(const sfo_world* w, uint32_t i, const float* loc, float* rx, float* ry) {
-    float c = w->rot[2 * i], s = w->rot[2 * i + 1];
-    *rx = c * loc[0] - s * loc[1];
-    *ry = s * loc[0] + c * loc[1];
-}
-
 /* [DESIGN] DESIGN.md "Contract / manifold block solve": the two normal constraints of a
  * manifold are solved together as a 2x2 LCP (lambda >= 0, no residual penetration), which
  * removes the point-order bias of a sequential solve that makes box stacks creep.
- * K is the effective inverse mass matrix along the shared normal, d the penetrations. */
-static void solve_lcp2(float K00, float K01, float K11, float d0, float d1, float* l0, float* l1) {
-    float det = K00 * K11 - K01 * K01;
-    if (det > 1e-6f * (K00 * K11)) {
-        float inv = 1.0f / det;
-        float a = (K11 * d0 - K01 * d1) * inv;
-        float b = (K00 * d1 - K01 * d0) * inv;
+ * The inverse of K comes from the record (prepare_pair): nothing is divided here. */
+static void solve_lcp2(const pair_rec* r, float d0, float d1, float* l0, float* l1) {
+    if (r->block) {
+        float a = r->i00 * d0 - r->i01 * d1;
+        float b = r->i11 * d1 - r->i01 * d0;
         if (a >= 0.0f && b >= 0.0f) { *l0 = a; *l1 = b; return; }
     }
-    float a = d0 / K00;
-    if (a >= 0.0f && d1 - K01 * a <= 0.0f) { *l0 = a; *l1 = 0.0f; return; }
-    float b = d1 / K11;
-    if (b >= 0.0f && d0 - K01 * b <= 0.0f) { *l0 = 0.0f; *l1 = b; return; }
-    if (d0 >= d1) { *l0 = fmaxf(d0, 0.0f) / K00; *l1 = 0.0f; }
-    else { *l0 = 0.0f; *l1 = fmaxf(d1, 0.0f) / K11; }
+    float a = d0 * r->iK[0];
+    if (a >= 0.0f && d1 - r->K01 * a <= 0.0f) { *l0 = a; *l1 = 0.0f; return; }
+    float b = d1 * r->iK[1];
+    if (b >= 0.0f && d0 - r->K01 * b <= 0.0f) { *l0 = 0.0f; *l1 = b; return; }
+    if (d0 >= d1) { *l0 = fmaxf(d0, 0.0f) * r->iK[0]; *l1 = 0.0f; }
+    else { *l0 = 0.0f; *l1 = fmaxf(d1, 0.0f) * r->iK[1]; }
 }
 
-/* [XPBD-RB] sec. 3.5, first half: narrowphase of one candidate pair at the poses of the
- * batch start ([DESIGN] DESIGN.md "Contract / batches": a batch is one tile in one phase, the
- * fallback list, or -- in sequential order -- the whole substep).  Leaves body-local anchors,
- * the normal, the pre-solve normal velocities and the combined material in the record. */
+/* y = K^-1 r restricted to the active normal constraints of a manifold (inverse from the record) */
+static void kinv_apply(const pair_rec* rec, int act0, int act1, float r0, float r1, float* y0, float* y1) {
+    *y0 = 0.0f; *y1 = 0.0f;
+    if (rec->count == 2 && act0 && act1) {
+        if (rec->block) {
+            *y0 = rec->i00 * r0 - rec->i01 * r1;
+            *y1 = rec->i11 * r1 - rec->i01 * r0;
+        } else {
+            *y0 = 0.5f * (r0 * rec->iK[0]); *y1 = 0.5f * (r1 * rec->iK[1]);
+        }
+    } else if (act0) {
+        *y0 = r0 * rec->iK[0];
+    } else if (rec->count == 2 && act1) {
+        *y1 = r1 * rec->iK[1];
+    }
+}
+
+static float inv_pos(float S) { return S > 0.0f ? 1.0f / S : 0.0f; }
+
+/* [XPBD-RB] sec. 3.5, first half: narrowphase of one solver pair (entries a, b: colliders, which mirror their
+ * bodies) at the poses the substep's integration and joints left, and -- [DESIGN] "Contract / frozen rows" --
+ * everything of the pair's constraint rows that depends on geometry and mass only: the lever arms of the normal rows
+ * and of the tangent row about the two BODIES' origins, the 2x2 effective mass of the normal rows and its inverse, the
+ * tangent row's couplings and Schur complements, the restitution targets.  The rows stay frozen for the substep (the
+ * classic linearisation of impulse solvers; first order in the substep's corrections). */
 static void prepare_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec) {
     manifold_t m;
     manifold(w, a, b, &m);
@@ -1532,191 +1570,179 @@ static void prepare_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec) {
     const sfx_material* mb = &w->mats[w->col[b].material];
     rec->mu_s = 0.5f * (ma->static_friction + mb->static_friction);
     rec->mu_d = 0.5f * (ma->dynamic_friction + mb->dynamic_friction);
-    rec->rest = fmaxf(ma->restitution, mb->restitution);
-    rec->nx = m.nx; rec->ny = m.ny;
-    float ca = w->rot[2 * a], sa = w->rot[2 * a + 1], cb = w->rot[2 * b], sb = w->rot[2 * b + 1];
+    const float rest = fmaxf(ma->restitution, mb->restitution);
+    const float gl = sqrtf(w->cfg.gravity[0] * w->cfg.gravity[0] + w->cfg.gravity[1] * w->cfg.gravity[1]);
+    const float vthr = w->cfg.restitution_threshold * gl * w->tick_h;
+    const float nx = m.nx, ny = m.ny;
+    rec->nx = nx; rec->ny = ny;
+    const uint32_t ba = w->cbody[a], bb = w->cbody[b];   /* the masses are the bodies' (entries beyond the bodies have none) */
+    const float ima = w->inv_mass[ba], iia = w->inv_inertia[ba], imb = w->inv_mass[bb], iib = w->inv_inertia[bb];
+    const float ims = ima + imb;
+    float rax[2] = {0, 0}, ray[2] = {0, 0}, rbx[2] = {0, 0}, rby[2] = {0, 0}, cna[2] = {0, 0}, cnb[2] = {0, 0};
+    rec->d0[1] = 0.0f; rec->tgt[1] = 0.0f;
     for (int k = 0; k < m.count; ++k) {
-        float ax = m.p1x[k] - w->pos[2 * a], ay = m.p1y[k] - w->pos[2 * a + 1];
-        float bx = m.p2x[k] - w->pos[2 * b], by = m.p2y[k] - w->pos[2 * b + 1];
-        rec->ra[k][0] = ca * ax + sa * ay; rec->ra[k][1] = ca * ay - sa * ax;
-        rec->rb[k][0] = cb * bx + sb * by; rec->rb[k][1] = cb * by - sb * bx;
+        rax[k] = m.p1x[k] - w->pos[2 * a]; ray[k] = m.p1y[k] - w->pos[2 * a + 1];
+        rbx[k] = m.p2x[k] - w->pos[2 * b]; rby[k] = m.p2y[k] - w->pos[2 * b + 1];
         /* pre-solve normal velocity of b relative to a (velocities are still the integrated ones) */
-        float rax, ray, rbx, rby;
-        anchor_world(w, a, rec->ra[k], &rax, &ray);
-        anchor_world(w, b, rec->rb[k], &rbx, &rby);
-        float vax = w->vel[2 * a] - w->angvel[a] * ray, vay = w->vel[2 * a + 1] + w->angvel[a] * rax;
-        float vbx = w->vel[2 * b] - w->angvel[b] * rby, vby = w->vel[2 * b + 1] + w->angvel[b] * rbx;
-        rec->vn_pre[k] = (vbx - vax) * m.nx + (vby - vay) * m.ny;
-    }
-}
-
-/* [XPBD-RB] sec. 3.5, second half: penetration re-evaluated from the record's anchors at the
- * current poses; the manifold's normal constraints solved as a block; poses updated.
- * Friction is not applied here but in the velocity pass (see solve_vel_pair). */
-static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec, float max_corr) {
-    int count = (int)rec->count;
-    if (!count) return;
-    float nx = rec->nx, ny = rec->ny;
-    float ima = w->inv_mass[a], iia = w->inv_inertia[a], imb = w->inv_mass[b], iib = w->inv_inertia[b];
-    float rax[2], ray[2], rbx[2], rby[2], d[2] = {0.0f, 0.0f}, cna[2] = {0.0f, 0.0f}, cnb[2] = {0.0f, 0.0f};
-    for (int k = 0; k < count; ++k) {
-        anchor_world(w, a, rec->ra[k], &rax[k], &ray[k]);
-        anchor_world(w, b, rec->rb[k], &rbx[k], &rby[k]);
-        d[k] = ((w->pos[2 * a] + rax[k]) - (w->pos[2 * b] + rbx[k])) * nx +
-               ((w->pos[2 * a + 1] + ray[k]) - (w->pos[2 * b + 1] + rby[k])) * ny;
-        d[k] = fminf(d[k], max_corr); /* [DESIGN] bounded depenetration per substep */
+        float vax = w->vel[2 * a] - w->angvel[a] * ray[k], vay = w->vel[2 * a + 1] + w->angvel[a] * rax[k];
+        float vbx = w->vel[2 * b] - w->angvel[b] * rby[k], vby = w->vel[2 * b + 1] + w->angvel[b] * rbx[k];
+        float vpre = (vbx - vax) * nx + (vby - vay) * ny;
+        float e = fabsf(vpre) <= vthr ? 0.0f : rest;
+        rec->tgt[k] = fmaxf(-e * vpre, 0.0f);
+        rec->d0[k] = (m.p1x[k] - m.p2x[k]) * nx + (m.p1y[k] - m.p2y[k]) * ny;
         cna[k] = rax[k] * ny - ray[k] * nx;
         cnb[k] = rbx[k] * ny - rby[k] * nx;
     }
-    float l0 = 0.0f, l1 = 0.0f;
-    float ims = ima + imb;
-    /* [DESIGN] effective masses: the sum of the inverse masses plus the SUM of the two bodies' angular terms (the sum of
-     * two terms does not depend on which body comes first: the device computes it on either side of the pair) */
-    float K00 = ims + (iia * (cna[0] * cna[0]) + iib * (cnb[0] * cnb[0]));
-    if (!(K00 > 0.0f)) return;
-    if (count == 2) {
-        float K11 = ims + (iia * (cna[1] * cna[1]) + iib * (cnb[1] * cnb[1]));
-        float K01 = ims + (iia * (cna[0] * cna[1]) + iib * (cnb[0] * cnb[1]));
-        solve_lcp2(K00, K01, K11, d[0], d[1], &l0, &l1);
-    } else {
-        l0 = fmaxf(d[0], 0.0f) / K00;
-    }
-    rec->lam[0] = l0; rec->lam[1] = l1;
-    float lt = l0 + l1;
-    if (!(lt > 0.0f)) return;
-    /* apply both normal impulses at once: a moves against n, b along n */
-    if (ima > 0.0f) {
-        w->pos[2 * a] = w->pos[2 * a] - (nx * lt) * ima;
-        w->pos[2 * a + 1] = w->pos[2 * a + 1] - (ny * lt) * ima;
-    }
-    if (iia > 0.0f) rotate_by(&w->rot[2 * a], &w->rot[2 * a + 1], -(iia * (cna[0] * l0 + cna[1] * l1)));
-    if (imb > 0.0f) {
-        w->pos[2 * b] = w->pos[2 * b] + (nx * lt) * imb;
-        w->pos[2 * b + 1] = w->pos[2 * b + 1] + (ny * lt) * imb;
-    }
-    if (iib > 0.0f) rotate_by(&w->rot[2 * b], &w->rot[2 * b + 1], iib * (cnb[0] * l0 + cnb[1] * l1));
-}
-
-static float rel_vel_n(const sfo_world* w, uint32_t a, uint32_t b, float rax, float ray, float rbx,
-                       float rby, float nx, float ny, float* vx, float* vy) {
-    float vax = w->vel[2 * a] - w->angvel[a] * ray, vay = w->vel[2 * a + 1] + w->angvel[a] * rax;
-    float vbx = w->vel[2 * b] - w->angvel[b] * rby, vby = w->vel[2 * b + 1] + w->angvel[b] * rbx;
-    *vx = vbx - vax; *vy = vby - vay;
-    return *vx * nx + *vy * ny;
-}
-
-/* y = K^-1 r restricted to the active normal constraints of a manifold */
-static void kinv_apply(const float* K, float K01, const int* act, int count, float r0, float r1,
-                       float* y0, float* y1) {
-    *y0 = 0.0f; *y1 = 0.0f;
-    if (count == 2 && act[0] && act[1]) {
-        float det = K[0] * K[1] - K01 * K01;
-        if (det > 1e-6f * (K[0] * K[1])) {
-            float inv = 1.0f / det;
-            *y0 = (K[1] * r0 - K01 * r1) * inv;
-            *y1 = (K[0] * r1 - K01 * r0) * inv;
+    /* effective masses: the sum of the inverse masses plus the sum of the two bodies' angular terms */
+    const float K00 = ims + (iia * (cna[0] * cna[0]) + iib * (cnb[0] * cnb[0]));
+    if (!(K00 > 0.0f)) { rec->count = 0; return; }
+    rec->iK[0] = 1.0f / K00; rec->iK[1] = 0.0f;
+    rec->block = 0; rec->i00 = rec->i01 = rec->i11 = rec->K01 = 0.0f;
+    if (rec->count == 2) {
+        const float K11 = ims + (iia * (cna[1] * cna[1]) + iib * (cnb[1] * cnb[1]));
+        const float K01 = ims + (iia * (cna[0] * cna[1]) + iib * (cnb[0] * cnb[1]));
+        if (!(K11 > 0.0f)) {
+            rec->count = 1;
         } else {
-            *y0 = 0.5f * (r0 / K[0]); *y1 = 0.5f * (r1 / K[1]);
+            rec->iK[1] = 1.0f / K11; rec->K01 = K01;
+            const float det = K00 * K11 - K01 * K01;
+            if (det > 1e-6f * (K00 * K11)) {
+                const float inv = 1.0f / det;
+                rec->block = 1; rec->i00 = K11 * inv; rec->i01 = K01 * inv; rec->i11 = K00 * inv;
+            }
         }
-    } else if (act[0]) {
-        *y0 = r0 / K[0];
-    } else if (count == 2 && act[1]) {
-        *y1 = r1 / K[1];
     }
-}
-
-/* [XPBD-RB] sec. 3.6, as a per-manifold block ([DESIGN] DESIGN.md "Contract / velocity pass"):
- *  1. restitution (eq. 34): the normal velocities of the active points are replaced by
- *     max(-e vn_pre, 0), both points solved together;
- *  2. friction once per manifold at the mean anchor, with compensating normal impulses so
- *     that step 1 stays satisfied: static (eq. 27-28, applied to velocity AND pose, i.e. the
- *     tangential displacement of this substep is undone) when the stopping impulse fits the
- *     static cone, else dynamic (eq. 30). */
-static void solve_vel_pair(sfo_world* w, uint32_t a, uint32_t b, const pair_rec* rec, float h, float inv_h) {
-    float nx = rec->nx, ny = rec->ny;
-    int count = (int)rec->count;
-    float l0 = rec->lam[0], l1 = count == 2 ? rec->lam[1] : 0.0f;
-    float lt = l0 + l1;
-    if (!(lt > 0.0f)) return;
-    float gl = sqrtf(w->cfg.gravity[0] * w->cfg.gravity[0] + w->cfg.gravity[1] * w->cfg.gravity[1]);
-    float vthr = w->cfg.restitution_threshold * gl * h;
-    float ima = w->inv_mass[a], iia = w->inv_inertia[a], imb = w->inv_mass[b], iib = w->inv_inertia[b];
-    float ims = ima + imb;
-    float rax[2], ray[2], rbx[2], rby[2], dv[2], cna[2] = {0.0f, 0.0f}, cnb[2] = {0.0f, 0.0f}, K[2];
-    int act[2];
-    act[1] = 0; dv[1] = 0.0f; cna[1] = 0.0f; cnb[1] = 0.0f; K[1] = 1.0f;
-    for (int k = 0; k < count; ++k) {
-        anchor_world(w, a, rec->ra[k], &rax[k], &ray[k]);
-        anchor_world(w, b, rec->rb[k], &rbx[k], &rby[k]);
-        float vx, vy;
-        float vn = rel_vel_n(w, a, b, rax[k], ray[k], rbx[k], rby[k], nx, ny, &vx, &vy);
-        float e = fabsf(rec->vn_pre[k]) <= vthr ? 0.0f : rec->rest;
-        dv[k] = fmaxf(-e * rec->vn_pre[k], 0.0f) - vn;
-        cna[k] = rax[k] * ny - ray[k] * nx;
-        cnb[k] = rbx[k] * ny - rby[k] * nx;
-        K[k] = ims + (iia * (cna[k] * cna[k]) + iib * (cnb[k] * cnb[k]));
-        act[k] = rec->lam[k] > 0.0f && K[k] > 0.0f;
-    }
-    float K01 = 0.0f;
-    if (count == 2) K01 = ims + (iia * (cna[0] * cna[1]) + iib * (cnb[0] * cnb[1]));
-    float p0, p1;
-    kinv_apply(K, K01, act, count, dv[0], dv[1], &p0, &p1);
-    {
-        float pt = p0 + p1;
-        float cra = cna[0] * p0 + cna[1] * p1, crb = cnb[0] * p0 + cnb[1] * p1;
-        w->vel[2 * a] = w->vel[2 * a] - (nx * pt) * ima;
-        w->vel[2 * a + 1] = w->vel[2 * a + 1] - (ny * pt) * ima;
-        w->angvel[a] = w->angvel[a] - iia * cra;
-        w->vel[2 * b] = w->vel[2 * b] + (nx * pt) * imb;
-        w->vel[2 * b + 1] = w->vel[2 * b + 1] + (ny * pt) * imb;
-        w->angvel[b] = w->angvel[b] + iib * crb;
-    }
-    if (w->cfg.flags & SFX_CFG_NO_FRICTION) return;
+    if (rec->count == 1) { cna[1] = 0.0f; cnb[1] = 0.0f; rec->d0[1] = 0.0f; rec->tgt[1] = 0.0f; }
+    rec->ca[0] = cna[0]; rec->ca[1] = cna[1]; rec->cb[0] = -cnb[0]; rec->cb[1] = -cnb[1];
+    /* the tangent row: t = (-ny, nx) at the mean anchor */
     float max_, may_, mbx_, mby_;
-    if (count == 2) {
+    if (rec->count == 2) {
         max_ = 0.5f * (rax[0] + rax[1]); may_ = 0.5f * (ray[0] + ray[1]);
         mbx_ = 0.5f * (rbx[0] + rbx[1]); mby_ = 0.5f * (rby[0] + rby[1]);
     } else { max_ = rax[0]; may_ = ray[0]; mbx_ = rbx[0]; mby_ = rby[0]; }
-    float vx, vy;
-    float vn = rel_vel_n(w, a, b, max_, may_, mbx_, mby_, nx, ny, &vx, &vy);
-    float vtx = vx - nx * vn, vty = vy - ny * vn;
-    float vt = sqrtf(vtx * vtx + vty * vty);
-    if (!(vt > EPS_LEN)) return;
-    float tx = vtx / vt, ty = vty / vt;
-    float cta = max_ * ty - may_ * tx, ctb = mbx_ * ty - mby_ * tx;
-    float Att = ims + (iia * (cta * cta) + iib * (ctb * ctb));
-    float At0 = iia * (cta * cna[0]) + iib * (ctb * cnb[0]);
-    float At1 = iia * (cta * cna[1]) + iib * (ctb * cnb[1]);
+    const float tx = -ny, ty = nx;
+    const float cta = max_ * ty - may_ * tx, ctb = mbx_ * ty - mby_ * tx;
+    rec->cta = cta; rec->ctb = -ctb;
+    const float Att = ims + (iia * (cta * cta) + iib * (ctb * ctb));
+    const float At0 = iia * (cta * cna[0]) + iib * (ctb * cnb[0]);
+    const float At1 = iia * (cta * cna[1]) + iib * (ctb * cnb[1]);
+    rec->Att = Att; rec->At[0] = At0; rec->At[1] = At1;
     float y0, y1;
-    kinv_apply(K, K01, act, count, At0, At1, &y0, &y1);
-    float S = Att - (At0 * y0 + At1 * y1);
-    if (!(S > 0.0f)) return;
-    float need = vt / S;
-    int is_static = need * h < rec->mu_s * lt;
-    float pt = is_static ? -need : -fminf(rec->mu_d * lt * inv_h, need);
-    float q0 = -(y0 * pt), q1 = -(y1 * pt);
-    /* total impulse on b (a gets the opposite): pt t + (q0 + q1) n, with torques */
-    float jx = tx * pt + nx * (q0 + q1), jy = ty * pt + ny * (q0 + q1);
-    float ja = (cta * pt + cna[0] * q0) + cna[1] * q1;
-    float jb = (ctb * pt + cnb[0] * q0) + cnb[1] * q1;
+    kinv_apply(rec, 1, rec->count == 2, At0, At1, &y0, &y1);
+    rec->invS = inv_pos(Att - (At0 * y0 + At1 * y1));
+    rec->invS0 = 0.0f; rec->invS1 = 0.0f;
+    if (rec->count == 2) {
+        rec->invS0 = inv_pos(Att - At0 * (At0 * rec->iK[0]));
+        rec->invS1 = inv_pos(Att - At1 * (At1 * rec->iK[1]));
+    }
+}
+
+/* [XPBD-RB] sec. 3.5, second half, on the frozen rows: the depth of a point is its depth at the narrowphase plus
+ * what the displacements accumulated since (dpos) change along its row; the manifold's normal constraints are solved
+ * as a block; the displacements of the two bodies grow.  Friction is not applied here but in the velocity pass. */
+static void solve_pos_pair(sfo_world* w, uint32_t a, uint32_t b, pair_rec* rec, float max_corr) {
+    int count = (int)rec->count;
+    if (!count) return;
+    const float nx = rec->nx, ny = rec->ny;
+    const float ima = w->inv_mass[a], iia = w->inv_inertia[a], imb = w->inv_mass[b], iib = w->inv_inertia[b];
+    float* Da = &w->dpos[3 * a];
+    float* Db = &w->dpos[3 * b];
+    const float la = Da[0] * nx + Da[1] * ny, lb = -(Db[0] * nx + Db[1] * ny);
+    float d[2] = {0.0f, 0.0f};
+    for (int k = 0; k < count; ++k) {
+        const float ga = la + Da[2] * rec->ca[k], gb = lb + Db[2] * rec->cb[k];
+        d[k] = rec->d0[k] + (ga + gb);
+        d[k] = fminf(d[k], max_corr); /* [DESIGN] bounded depenetration per substep */
+    }
+    float l0 = 0.0f, l1 = 0.0f;
+    if (count == 2) solve_lcp2(rec, d[0], d[1], &l0, &l1);
+    else l0 = fmaxf(d[0], 0.0f) * rec->iK[0];
+    rec->lam[0] = l0; rec->lam[1] = l1;
+    const float lt = l0 + l1;
+    if (!(lt > 0.0f)) return;
+    /* both normal impulses at once: a moves against n, b along n */
+    Da[0] = Da[0] - (nx * lt) * ima;
+    Da[1] = Da[1] - (ny * lt) * ima;
+    Da[2] = Da[2] - iia * (rec->ca[0] * l0 + rec->ca[1] * l1);
+    Db[0] = Db[0] + (nx * lt) * imb;
+    Db[1] = Db[1] + (ny * lt) * imb;
+    Db[2] = Db[2] - iib * (rec->cb[0] * l0 + rec->cb[1] * l1);
+}
+
+/* [XPBD-RB] sec. 3.6, as a per-manifold block ([DESIGN] DESIGN.md "Contract / velocity pass"), on the frozen rows:
+ *  1. restitution (eq. 34): the normal velocities of the active points are replaced by
+ *     max(-e vn_pre, 0), both points solved together;
+ *  2. friction once per manifold along t = (-ny, nx) at the mean anchor, with compensating normal impulses so
+ *     that step 1 stays satisfied: static (eq. 27-28, applied to velocity AND pose, i.e. the
+ *     tangential displacement of this substep is undone; the pose part accumulates in dshift and is applied at the end
+ *     of the phase) when the stopping impulse fits the static cone, else dynamic (eq. 30). */
+static void solve_vel_pair(sfo_world* w, uint32_t a, uint32_t b, const pair_rec* rec, float h, float inv_h) {
+    const float nx = rec->nx, ny = rec->ny;
+    const int count = (int)rec->count;
+    const float l0 = rec->lam[0], l1 = count == 2 ? rec->lam[1] : 0.0f;
+    const float lt = l0 + l1;
+    if (!(lt > 0.0f)) return;
+    const float ima = w->inv_mass[a], iia = w->inv_inertia[a], imb = w->inv_mass[b], iib = w->inv_inertia[b];
+    const int act0 = l0 > 0.0f, act1 = count == 2 && l1 > 0.0f;
+    {
+        const float la = w->vel[2 * a] * nx + w->vel[2 * a + 1] * ny, lb = -(w->vel[2 * b] * nx + w->vel[2 * b + 1] * ny);
+        float dv[2] = {0.0f, 0.0f};
+        for (int k = 0; k < count; ++k) {
+            const float ua = la + w->angvel[a] * rec->ca[k], ub = lb + w->angvel[b] * rec->cb[k];
+            dv[k] = rec->tgt[k] + (ua + ub);   /* target minus vn, vn = -(ua + ub) */
+        }
+        float p0, p1;
+        kinv_apply(rec, act0, act1, dv[0], dv[1], &p0, &p1);
+        const float pt = p0 + p1;
+        w->vel[2 * a] = w->vel[2 * a] - (nx * pt) * ima;
+        w->vel[2 * a + 1] = w->vel[2 * a + 1] - (ny * pt) * ima;
+        w->angvel[a] = w->angvel[a] - iia * (rec->ca[0] * p0 + rec->ca[1] * p1);
+        w->vel[2 * b] = w->vel[2 * b] + (nx * pt) * imb;
+        w->vel[2 * b + 1] = w->vel[2 * b + 1] + (ny * pt) * imb;
+        w->angvel[b] = w->angvel[b] - iib * (rec->cb[0] * p0 + rec->cb[1] * p1);
+    }
+    if (w->cfg.flags & SFX_CFG_NO_FRICTION) return;
+    const float tx = -ny, ty = nx;
+    const float wa = (w->vel[2 * a] * tx + w->vel[2 * a + 1] * ty) + w->angvel[a] * rec->cta;
+    const float wb = -(w->vel[2 * b] * tx + w->vel[2 * b + 1] * ty) + w->angvel[b] * rec->ctb;
+    const float vt = -(wa + wb);   /* of b relative to a along t, signed */
+    if (!(fabsf(vt) > EPS_LEN)) return;
+    float y0, y1;
+    kinv_apply(rec, act0, act1, rec->At[0], rec->At[1], &y0, &y1);
+    const float invS = (act0 && (act1 || count == 1)) ? rec->invS : (act0 ? rec->invS0 : rec->invS1);
+    const float need = vt * invS;
+    if (need == 0.0f) return;
+    const int is_static = fabsf(need) * h < rec->mu_s * lt;
+    const float pt = is_static ? -need : -copysignf(fminf(rec->mu_d * lt * inv_h, fabsf(need)), need);
+    const float q0 = -(y0 * pt), q1 = -(y1 * pt);
+    /* total impulse on b (a gets the opposite): pt t + (q0 + q1) n, with the torques of the frozen rows */
+    const float jx = tx * pt + nx * (q0 + q1), jy = ty * pt + ny * (q0 + q1);
+    const float ja = (rec->cta * pt + rec->ca[0] * q0) + rec->ca[1] * q1;
+    const float jb = (rec->ctb * pt + rec->cb[0] * q0) + rec->cb[1] * q1;
     w->vel[2 * a] = w->vel[2 * a] - jx * ima;
     w->vel[2 * a + 1] = w->vel[2 * a + 1] - jy * ima;
     w->angvel[a] = w->angvel[a] - iia * ja;
     w->vel[2 * b] = w->vel[2 * b] + jx * imb;
     w->vel[2 * b + 1] = w->vel[2 * b + 1] + jy * imb;
-    w->angvel[b] = w->angvel[b] + iib * jb;
+    w->angvel[b] = w->angvel[b] - iib * jb;
     if (is_static) {
-        if (ima > 0.0f) {
-            w->pos[2 * a] = w->pos[2 * a] - (jx * h) * ima;
-            w->pos[2 * a + 1] = w->pos[2 * a + 1] - (jy * h) * ima;
-        }
-        if (iia > 0.0f) rotate_by(&w->rot[2 * a], &w->rot[2 * a + 1], -(iia * (ja * h)));
-        if (imb > 0.0f) {
-            w->pos[2 * b] = w->pos[2 * b] + (jx * h) * imb;
-            w->pos[2 * b + 1] = w->pos[2 * b + 1] + (jy * h) * imb;
-        }
-        if (iib > 0.0f) rotate_by(&w->rot[2 * b], &w->rot[2 * b + 1], iib * (jb * h));
+        float* Sa = &w->dshift[3 * a];
+        float* Sb = &w->dshift[3 * b];
+        Sa[0] = Sa[0] - (jx * h) * ima;
+        Sa[1] = Sa[1] - (jy * h) * ima;
+        Sa[2] = Sa[2] - iia * (ja * h);
+        Sb[0] = Sb[0] + (jx * h) * imb;
+        Sb[1] = Sb[1] + (jy * h) * imb;
+        Sb[2] = Sb[2] - iib * (jb * h);
     }
+}
+
+/* end of a velocity phase: the static-friction shifts of the bodies of pair e are applied and cleared */
+static void apply_shift(sfo_world* w, uint32_t i) {
+    float* S = &w->dshift[3 * i];
+    if (S[0] == 0.0f && S[1] == 0.0f && S[2] == 0.0f) return;
+    if (is_dynamic(w, i)) apply_delta(w, i, S);
+    S[0] = 0.0f; S[1] = 0.0f; S[2] = 0.0f;
 }
 
 /* [XPBD-RB] sec. 3.3 / [XPBD] eq. 18: distance constraint with compliance, lambda restarts
@@ -1934,8 +1960,20 @@ int sfo_tick_substep(sfo_world* w) {
         for (uint32_t bt = b0; bt < b1; ++bt)
             for (uint32_t k = bt ? w->batch_end[bt - 1] : 0u; k < w->batch_end[bt]; ++k) {
                 uint32_t e = w->order[k];
-                if (w->rec[e].count) solve_vel_pair(w, w->cbody[w->pa[e]], w->cbody[w->pb[e]], &w->rec[e], h, inv_h);
+                if (!w->rec[e].count) continue;
+                solve_vel_pair(w, w->cbody[w->pa[e]], w->cbody[w->pb[e]], &w->rec[e], h, inv_h);
+                if (phased && ph == 4u) { /* the fallback list (one workgroup on global memory) applies its shifts pair by pair */
+                    apply_shift(w, w->cbody[w->pa[e]]);
+                    apply_shift(w, w->cbody[w->pb[e]]);
+                }
             }
+        /* the phase's static-friction shifts, once per body (the batches of a phase share no dynamic body) */
+        for (uint32_t k = b0 ? w->batch_end[b0 - 1] : 0u; k < (b1 ? w->batch_end[b1 - 1] : 0u); ++k) {
+            uint32_t e = w->order[k];
+            if (!w->rec[e].count) continue;
+            apply_shift(w, w->cbody[w->pa[e]]);
+            apply_shift(w, w->cbody[w->pb[e]]);
+        }
     }
     mirror_entries(w);
     /* stats of the last substep, measured on the records */

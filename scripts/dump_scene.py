@@ -31,7 +31,14 @@ if __name__ == "__main__":
     if settle:
         import bench
         s = bench.settle(s, 0, frames=settle)
-        if relax:
-            s = bench.settle(s, 0, frames=relax, damping=0.0, angular=0.0)
+        if relax:   # undamped ticks; the velocities are kept: the file is the steady (jittering) state bench.py times
+            from starframe_amd.world import World
+            w = World.from_scene(s)
+            for _ in range(relax):
+                w.step(bench.DT)
+            pos, rot = w.poses()
+            vel, ang = w.velocities()
+            w.close()
+            s = s.with_state(pos, rot, vel, ang, name=s.name + "_relaxed")
     dump(s, path)
     print(path, s.n, "bodies", "settled" if settle else "")

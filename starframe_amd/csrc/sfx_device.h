@@ -33,6 +33,8 @@ struct BodyArrays {
     float4* pose;
     float4* prev;
     float4* vel;
+    float4* dpos;        // (dx, dy, dtheta, -): what the position sweep of this substep has accumulated per body (DESIGN.md
+                         // "Contract / frozen rows"); zeroed by the integration, applied once where the velocity is derived
     const float2* mass;
     const float4* shape;
     const float4* lpose; // local pose of the shape in the body frame (ox, oy, cos, sin); read only where shape_local() says so
@@ -567,153 +569,198 @@ __device__ __forceinline__ void manifold(const float4& pa, const float4& sa, con
 }
 
 // ---- per-manifold solver records -----------------------------------------------------
-// What the narrowphase leaves for the solves, one record per solver pair slot (colour-sorted order): a
-// whole 64-byte line per slot, so that the narrowphase (which visits the slots in class order, i.e.
-// scattered) writes full lines and the colour loops (consecutive lanes, consecutive slots) read them
-// coalesced.
+// DESIGN.md "Contract / frozen rows": everything of a pair's constraint rows that depends on geometry and mass only is
+// computed ONCE per substep by the narrowphase (prepare_pair, one pair per lane, the stage that fills the device) and
+// kept in the pair's record: the lever arms of the normal rows and of the tangent row as they act on each side, the
+// inverse of the 2x2 effective mass, the tangent row's couplings and the reciprocals of its Schur complements, the
+// restitution targets.  The colour steps of the solves -- one wave's dependent chain each, the part of the tick that
+// does not parallelise -- are then a few dozen multiply-adds per pair on a displacement (position pass) or a velocity
+// (velocity pass) held in LDS: no anchor is rotated, nothing is divided and no rotation is renormalised inside them.
+//
+// One record = seven 16-byte words per pair slot (colour-sorted order), kept as seven PLANES: word i of slot s is
+// rec[i * nslots + s].  The colour loops take the pairs of a colour with consecutive lanes, so every load of a plane is
+// one contiguous run of 16-byte words (a record kept as one 128-byte block made each of the seven loads of a wave touch
+// 32 different lines, and the colour steps of both solves were bound by the address pipeline: measured in DESIGN.md):
+//   A (nx, ny, count | block << 8 as bits, 1 / K00)    B (ca0, cb0, d0_0, tgt0)    C (cta, ctb, mu_s, mu_d)    D (At0, invS, Att, -)
+//   two-point manifolds only:  E (ca1, cb1, d0_1, tgt1)    F (i00, i01, i11, K01)    G (1 / K11, At1, invS0, invS1)
+// The position pass reads A, B and E, F, G; the velocity pass all seven.
 struct ContactArrays {
-    float4* rec;     // one 64-byte line per slot: [4k] (nx, ny, mu_s, mu_d), [4k+1] point 0 anchors (ra.x, ra.y, rb.x, rb.y)
-                     // body-local, [4k+2] point 1 anchors, [4k+3] (restitution, count as bits, vn_pre0, vn_pre1)
+    float4* rec;
     float2* lam;     // (lambda0, lambda1) of this substep: written by the position solve, read by the velocity pass
+    uint32_t nslots; // plane stride
 };
+constexpr uint32_t kRecPlanes = 7;
+enum { kPlA = 0, kPlB, kPlC, kPlD, kPlE, kPlF, kPlG };
 
-__device__ __forceinline__ void anchor_world(const float4& pose, float lx, float ly, float& rx, float& ry) {
-    rx = pose.z * lx - pose.w * ly;
-    ry = pose.w * lx + pose.z * ly;
-}
-
-__device__ __forceinline__ void solve_lcp2(float K00, float K01, float K11, float d0, float d1, float& l0, float& l1) {
-    float det = K00 * K11 - K01 * K01;
-    if (det > 1e-6f * (K00 * K11)) {
-        float inv = 1.0f / det;
-        float a = (K11 * d0 - K01 * d1) * inv;
-        float b = (K00 * d1 - K01 * d0) * inv;
-        if (a >= 0.0f && b >= 0.0f) { l0 = a; l1 = b; return; }
-    }
-    float a = d0 / K00;
-    if (a >= 0.0f && d1 - K01 * a <= 0.0f) { l0 = a; l1 = 0.0f; return; }
-    float b = d1 / K11;
-    if (b >= 0.0f && d0 - K01 * b <= 0.0f) { l0 = 0.0f; l1 = b; return; }
-    if (d0 >= d1) { l0 = fmaxf(d0, 0.0f) / K00; l1 = 0.0f; }
-    else { l0 = 0.0f; l1 = fmaxf(d1, 0.0f) / K11; }
-}
-
-// What the narrowphase of one candidate pair leaves for the solves, in registers.
+// What the narrowphase of one candidate pair leaves for the solves, in registers (whole pair, one lane).
 struct PairRec {
     int count;             // 0, 1 or 2 points
+    bool block;            // count == 2 and the two normal rows are solved as a block
     float nx, ny;          // from a to b
-    float mu_s, mu_d, rest;
-    float la[2][2], lb[2][2];  // body-local anchors
-    float vpre[2];         // normal relative velocity before the position solve
+    float mu_s, mu_d;
+    float ca[2], cb[2];    // lever arms of the normal rows AS THEY ACT on each side: ca = ra x n, cb = -(rb x n)
+    float d0[2];           // depth at the narrowphase poses
+    float tgt[2];          // normal velocity the velocity pass asks for: max(-e vn_pre, 0)
+    float iK[2];           // 1 / K00, 1 / K11
+    float i00, i01, i11, K01;
+    float cta, ctb;        // lever arms of the tangent row t = (-ny, nx) at the mean anchor, as they act
+    float Att, At[2];
+    float invS, invS0, invS1;
     float l0, l1;          // normal lambdas of this substep
 };
 
-// Narrowphase of one candidate pair at the poses of the batch start (DESIGN.md "Contract /
-// batches"): manifold, body-local anchors, pre-solve normal velocities, combined material.
-__device__ __forceinline__ void prepare_pair(const float4& pa, const float4& sa, const float4& va,
-                                             const float4& pb, const float4& sb, const float4& vb,
+// y = K^-1 r restricted to the active normal rows (inverse from the record: nothing is divided).  Written as selects
+// between the candidates, not as branches: the colour steps are one wave's instruction chain, and a divergent branch
+// costs more scalar bookkeeping than the few multiplies it skips.  (Fields of the second point are only meaningful when
+// count == 2; what is computed from them otherwise is never selected.)
+__device__ __forceinline__ void kinv_rec(int count, bool block, float i00, float i01, float i11, float iK0, float iK1,
+                                         bool act0, bool act1, float r0, float r1, float& y0, float& y1) {
+    const float yb0 = i00 * r0 - i01 * r1, yb1 = i11 * r1 - i01 * r0;
+    const float ys0 = r0 * iK0, ys1 = r1 * iK1;
+    const float yh0 = 0.5f * ys0, yh1 = 0.5f * ys1;
+    const bool both = count == 2 && act0 && act1;
+    const float b0 = block ? yb0 : yh0, b1 = block ? yb1 : yh1;
+    const float s0 = act0 ? ys0 : 0.0f;
+    const float s1 = (!act0 && count == 2 && act1) ? ys1 : 0.0f;
+    y0 = both ? b0 : s0;
+    y1 = both ? b1 : s1;
+}
+
+__device__ __forceinline__ void lcp2_rec(bool block, float i00, float i01, float i11, float iK0, float iK1, float K01,
+                                         float d0, float d1, float& l0, float& l1) {
+    const float ab = i00 * d0 - i01 * d1, bb = i11 * d1 - i01 * d0;
+    const bool okb = block && ab >= 0.0f && bb >= 0.0f;
+    const float a1 = d0 * iK0;
+    const bool ok1 = a1 >= 0.0f && d1 - K01 * a1 <= 0.0f;
+    const float b2 = d1 * iK1;
+    const bool ok2 = b2 >= 0.0f && d0 - K01 * b2 <= 0.0f;
+    const bool ge = d0 >= d1;
+    const float f0 = ge ? fmaxf(d0, 0.0f) * iK0 : 0.0f, f1 = ge ? 0.0f : fmaxf(d1, 0.0f) * iK1;
+    const float t0 = ok2 ? 0.0f : f0, t1 = ok2 ? b2 : f1;
+    const float u0 = ok1 ? a1 : t0, u1 = ok1 ? 0.0f : t1;
+    l0 = okb ? ab : u0;
+    l1 = okb ? bb : u1;
+}
+
+__device__ __forceinline__ float inv_pos(float S) { return S > 0.0f ? 1.0f / S : 0.0f; }
+
+// Narrowphase of one solver pair at the poses the substep's integration and joints left (DESIGN.md "Contract / sweep
+// order") and the pair's frozen rows.  pa / pb, va / vb: pose and velocity of the two ENTRIES (colliders; a further
+// collider mirrors its body); wa / wb: the masses of their BODIES; ca / cb: the poses of the two shapes.
+__device__ __forceinline__ void prepare_pair(const float4& pa, const float4& sa, const float4& va, const float2& wa,
+                                             const float4& pb, const float4& sb, const float4& vb, const float2& wb,
                                              const float4& ca /* pose of a's shape */, const float4& cb,
                                              const float4* __restrict__ poly, const float4* __restrict__ mats,
-                                             float sm, PairRec& r) {
+                                             float sm, float vthr, PairRec& r) {
     Manifold m;
     manifold(ca, sa, cb, sb, poly, sm, m);
     r.count = m.count;
     r.l0 = 0.0f; r.l1 = 0.0f;
-    r.nx = 0.0f; r.ny = 0.0f; r.mu_s = 0.0f; r.mu_d = 0.0f; r.rest = 0.0f;
-    r.la[0][0] = r.la[0][1] = r.lb[0][0] = r.lb[0][1] = 0.0f;
-    r.la[1][0] = r.la[1][1] = r.lb[1][0] = r.lb[1][1] = 0.0f;
-    r.vpre[0] = r.vpre[1] = 0.0f;
+    r.block = false;
+    r.nx = 0.0f; r.ny = 0.0f; r.mu_s = 0.0f; r.mu_d = 0.0f;
+    r.ca[0] = r.ca[1] = r.cb[0] = r.cb[1] = 0.0f;
+    r.d0[0] = r.d0[1] = r.tgt[0] = r.tgt[1] = 0.0f;
+    r.iK[0] = r.iK[1] = 0.0f; r.i00 = r.i01 = r.i11 = r.K01 = 0.0f;
+    r.cta = r.ctb = r.Att = r.At[0] = r.At[1] = 0.0f;
+    r.invS = r.invS0 = r.invS1 = 0.0f;
     if (m.count == 0) return;
     const float4 ma = mats[shape_material(sa)], mb = mats[shape_material(sb)];
     r.mu_s = 0.5f * (ma.y + mb.y);
     r.mu_d = 0.5f * (ma.z + mb.z);
-    r.rest = fmaxf(ma.x, mb.x);
-    r.nx = m.nx; r.ny = m.ny;
+    const float rest = fmaxf(ma.x, mb.x);
+    const float nx = m.nx, ny = m.ny;
+    r.nx = nx; r.ny = ny;
+    const float ima = wa.x, iia = wa.y, imb = wb.x, iib = wb.y;
+    const float ims = ima + imb;
+    float rax[2], ray[2], rbx[2], rby[2], cna[2], cnb[2];
+    rax[1] = ray[1] = rbx[1] = rby[1] = 0.0f; cna[1] = cnb[1] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (k < m.count) {
-            float ax = m.p1x[k] - pa.x, ay = m.p1y[k] - pa.y;
-            float bx = m.p2x[k] - pb.x, by = m.p2y[k] - pb.y;
-            r.la[k][0] = pa.z * ax + pa.w * ay; r.la[k][1] = pa.z * ay - pa.w * ax;
-            r.lb[k][0] = pb.z * bx + pb.w * by; r.lb[k][1] = pb.z * by - pb.w * bx;
-            float rax, ray, rbx, rby;
-            anchor_world(pa, r.la[k][0], r.la[k][1], rax, ray);
-            anchor_world(pb, r.lb[k][0], r.lb[k][1], rbx, rby);
-            float vax = va.x - va.z * ray, vay = va.y + va.z * rax;
-            float vbx = vb.x - vb.z * rby, vby = vb.y + vb.z * rbx;
-            r.vpre[k] = (vbx - vax) * m.nx + (vby - vay) * m.ny;
+            rax[k] = m.p1x[k] - pa.x; ray[k] = m.p1y[k] - pa.y;
+            rbx[k] = m.p2x[k] - pb.x; rby[k] = m.p2y[k] - pb.y;
+            const float vax = va.x - va.z * ray[k], vay = va.y + va.z * rax[k];
+            const float vbx = vb.x - vb.z * rby[k], vby = vb.y + vb.z * rbx[k];
+            const float vpre = (vbx - vax) * nx + (vby - vay) * ny;
+            const float e = fabsf(vpre) <= vthr ? 0.0f : rest;
+            r.tgt[k] = fmaxf(-e * vpre, 0.0f);
+            r.d0[k] = (m.p1x[k] - m.p2x[k]) * nx + (m.p1y[k] - m.p2y[k]) * ny;
+            cna[k] = rax[k] * ny - ray[k] * nx;
+            cnb[k] = rbx[k] * ny - rby[k] * nx;
         }
+    }
+    const float K00 = ims + (iia * (cna[0] * cna[0]) + iib * (cnb[0] * cnb[0]));
+    if (!(K00 > 0.0f)) { r.count = 0; return; }
+    r.iK[0] = 1.0f / K00;
+    if (r.count == 2) {
+        const float K11 = ims + (iia * (cna[1] * cna[1]) + iib * (cnb[1] * cnb[1]));
+        const float K01 = ims + (iia * (cna[0] * cna[1]) + iib * (cnb[0] * cnb[1]));
+        if (!(K11 > 0.0f)) {
+            r.count = 1;
+        } else {
+            r.iK[1] = 1.0f / K11; r.K01 = K01;
+            const float det = K00 * K11 - K01 * K01;
+            if (det > 1e-6f * (K00 * K11)) {
+                const float inv = 1.0f / det;
+                r.block = true; r.i00 = K11 * inv; r.i01 = K01 * inv; r.i11 = K00 * inv;
+            }
+        }
+    }
+    if (r.count == 1) { cna[1] = 0.0f; cnb[1] = 0.0f; r.d0[1] = 0.0f; r.tgt[1] = 0.0f; }
+    r.ca[0] = cna[0]; r.ca[1] = cna[1]; r.cb[0] = -cnb[0]; r.cb[1] = -cnb[1];
+    float max_, may_, mbx_, mby_;
+    if (r.count == 2) {
+        max_ = 0.5f * (rax[0] + rax[1]); may_ = 0.5f * (ray[0] + ray[1]);
+        mbx_ = 0.5f * (rbx[0] + rbx[1]); mby_ = 0.5f * (rby[0] + rby[1]);
+    } else { max_ = rax[0]; may_ = ray[0]; mbx_ = rbx[0]; mby_ = rby[0]; }
+    const float tx = -ny, ty = nx;
+    const float cta = max_ * ty - may_ * tx, ctb = mbx_ * ty - mby_ * tx;
+    r.cta = cta; r.ctb = -ctb;
+    const float Att = ims + (iia * (cta * cta) + iib * (ctb * ctb));
+    const float At0 = iia * (cta * cna[0]) + iib * (ctb * cnb[0]);
+    const float At1 = iia * (cta * cna[1]) + iib * (ctb * cnb[1]);
+    r.Att = Att; r.At[0] = At0; r.At[1] = At1;
+    float y0, y1;
+    kinv_rec(r.count, r.block, r.i00, r.i01, r.i11, r.iK[0], r.iK[1], true, r.count == 2, At0, At1, y0, y1);
+    r.invS = inv_pos(Att - (At0 * y0 + At1 * y1));
+    if (r.count == 2) {
+        r.invS0 = inv_pos(Att - At0 * (At0 * r.iK[0]));
+        r.invS1 = inv_pos(Att - At1 * (At1 * r.iK[1]));
     }
 }
 
-// Position solve of one prepared pair at the current poses: penetration re-evaluated from the
-// anchors, the manifold's normal constraints solved as a block, poses updated in registers.
-// Returns true when the poses changed.  Mueller et al. 2020 sec. 3.5.
-__device__ __forceinline__ bool solve_pos_rec(PairRec& r, float4& pa, const float2& wa, float4& pb, const float2& wb,
+// Position solve of one prepared pair on the two bodies' displacements Da, Db = (dx, dy, dtheta, -) accumulated since
+// the narrowphase: the depth of a point is its depth there plus what the displacements change along its frozen row;
+// the manifold's normal constraints are solved as a block; the displacements grow.  Returns true when they changed.
+// Mueller et al. 2020 sec. 3.5.
+__device__ __forceinline__ bool solve_pos_rec(PairRec& r, float4& Da, const float2& wa, float4& Db, const float2& wb,
                                               float max_corr) {
     if (r.count == 0) return false;
     const float nx = r.nx, ny = r.ny;
-    const float ima = wa.x, iia = wa.y, imb = wb.x, iib = wb.y;
-    float d[2], cna[2], cnb[2];
-    d[1] = 0.0f; cna[1] = 0.0f; cnb[1] = 0.0f;
+    const float la = Da.x * nx + Da.y * ny, lb = -(Db.x * nx + Db.y * ny);
+    float d[2];
+    d[1] = 0.0f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (k < r.count) {
-            float rax, ray, rbx, rby;
-            anchor_world(pa, r.la[k][0], r.la[k][1], rax, ray);
-            anchor_world(pb, r.lb[k][0], r.lb[k][1], rbx, rby);
-            d[k] = ((pa.x + rax) - (pb.x + rbx)) * nx + ((pa.y + ray) - (pb.y + rby)) * ny;
+            const float ga = la + Da.z * r.ca[k], gb = lb + Db.z * r.cb[k];
+            d[k] = r.d0[k] + (ga + gb);
             d[k] = fminf(d[k], max_corr);  // bounded depenetration per substep
-            cna[k] = rax * ny - ray * nx;
-            cnb[k] = rbx * ny - rby * nx;
         }
     }
     float l0 = 0.0f, l1 = 0.0f;
-    const float ims = ima + imb;
-    // effective masses: the sum of the two inverse masses plus the SUM of the two bodies' angular terms (a sum of two is the
-    // same whichever body comes first: solve_pos_side computes it on either side of the pair)
-    const float K00 = ims + (iia * (cna[0] * cna[0]) + iib * (cnb[0] * cnb[0]));
-    if (!(K00 > 0.0f)) return false;
-    if (r.count == 2) {
-        float K11 = ims + (iia * (cna[1] * cna[1]) + iib * (cnb[1] * cnb[1]));
-        float K01 = ims + (iia * (cna[0] * cna[1]) + iib * (cnb[0] * cnb[1]));
-        solve_lcp2(K00, K01, K11, d[0], d[1], l0, l1);
-    } else {
-        l0 = fmaxf(d[0], 0.0f) / K00;
-    }
+    if (r.count == 2) lcp2_rec(r.block, r.i00, r.i01, r.i11, r.iK[0], r.iK[1], r.K01, d[0], d[1], l0, l1);
+    else l0 = fmaxf(d[0], 0.0f) * r.iK[0];
     r.l0 = l0; r.l1 = l1;
     const float lt = l0 + l1;
     if (!(lt > 0.0f)) return false;
-    if (ima > 0.0f) {
-        pa.x = pa.x - (nx * lt) * ima;
-        pa.y = pa.y - (ny * lt) * ima;
-    }
-    if (iia > 0.0f) rotate_by(pa.z, pa.w, -(iia * (cna[0] * l0 + cna[1] * l1)));
-    if (imb > 0.0f) {
-        pb.x = pb.x + (nx * lt) * imb;
-        pb.y = pb.y + (ny * lt) * imb;
-    }
-    if (iib > 0.0f) rotate_by(pb.z, pb.w, iib * (cnb[0] * l0 + cnb[1] * l1));
+    Da.x = Da.x - (nx * lt) * wa.x;
+    Da.y = Da.y - (ny * lt) * wa.x;
+    Da.z = Da.z - wa.y * (r.ca[0] * l0 + r.ca[1] * l1);
+    Db.x = Db.x + (nx * lt) * wb.x;
+    Db.y = Db.y + (ny * lt) * wb.x;
+    Db.z = Db.z - wb.y * (r.cb[0] * l0 + r.cb[1] * l1);
     return true;
-}
-
-__device__ __forceinline__ void kinv_apply(float K0, float K1, float K01, bool act0, bool act1, int count,
-                                           float r0, float r1, float& y0, float& y1) {
-    y0 = 0.0f; y1 = 0.0f;
-    if (count == 2 && act0 && act1) {
-        float det = K0 * K1 - K01 * K01;
-        if (det > 1e-6f * (K0 * K1)) {
-            float inv = 1.0f / det;
-            y0 = (K1 * r0 - K01 * r1) * inv;
-            y1 = (K0 * r1 - K01 * r0) * inv;
-        } else {
-            y0 = 0.5f * (r0 / K0); y1 = 0.5f * (r1 / K1);
-        }
-    } else if (act0) {
-        y0 = r0 / K0;
-    } else if (count == 2 && act1) {
-        y1 = r1 / K1;
-    }
 }
 
 struct StepParams {
@@ -725,116 +772,91 @@ struct StepParams {
     uint32_t flags;
 };
 
-// Velocity pass of one prepared pair: restitution block, then friction with compensating
-// normal impulses (static friction also shifts the poses).  Works on registers; returns bit 0
-// when the velocities changed and bit 1 when the poses changed.  Mueller et al. 2020 sec. 3.6.
-__device__ __forceinline__ int solve_vel_rec(const PairRec& r, float4& pa, float4& va, const float2& wa,
-                                             float4& pb, float4& vb, const float2& wb, const StepParams& sp) {
+// a displacement (dx, dy, dtheta) applied to a pose: the translation added, the rotation through rotate_by; a body that
+// was not turned keeps the bits of its rotation
+__device__ __forceinline__ void apply_delta(float4& p, const float4& d) {
+    p.x = p.x + d.x;
+    p.y = p.y + d.y;
+    if (d.z != 0.0f) rotate_by(p.z, p.w, d.z);
+}
+
+// Velocity pass of one prepared pair on the frozen rows: restitution block, then friction along t = (-ny, nx) with
+// compensating normal impulses; static friction also shifts the poses: the shift accumulates in Sa, Sb = (dx, dy,
+// dtheta, -) and is applied by the caller (at the end of the phase; the fallback list applies it pair by pair).
+// Returns bit 0 when the velocities changed and bit 1 when the shifts did.  Mueller et al. 2020 sec. 3.6.
+__device__ __forceinline__ int solve_vel_rec(const PairRec& r, float4& va, const float2& wa, float4& vb, const float2& wb,
+                                             float4& Sa, float4& Sb, const StepParams& sp) {
     const int count = r.count;
     if (count == 0) return 0;
     const float l0 = r.l0, l1 = count == 2 ? r.l1 : 0.0f;
     const float lt = l0 + l1;
     if (!(lt > 0.0f)) return 0;
-    const float nx = r.nx, ny = r.ny, mu_s = r.mu_s, mu_d = r.mu_d, rest = r.rest;
+    const float nx = r.nx, ny = r.ny;
     const float ima = wa.x, iia = wa.y, imb = wb.x, iib = wb.y;
-    const float ims = ima + imb;
-    float rax[2], ray[2], rbx[2], rby[2], dv[2], cna[2], cnb[2], K[2];
-    bool act[2];
-    act[1] = false; dv[1] = 0.0f; cna[1] = 0.0f; cnb[1] = 0.0f; K[1] = 1.0f;
-    rax[1] = ray[1] = rbx[1] = rby[1] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (k < count) {
-            const float lam = k == 0 ? r.l0 : r.l1;
-            const float vpre = r.vpre[k];
-            anchor_world(pa, r.la[k][0], r.la[k][1], rax[k], ray[k]);
-            anchor_world(pb, r.lb[k][0], r.lb[k][1], rbx[k], rby[k]);
-            float vax = va.x - va.z * ray[k], vay = va.y + va.z * rax[k];
-            float vbx = vb.x - vb.z * rby[k], vby = vb.y + vb.z * rbx[k];
-            float vn = (vbx - vax) * nx + (vby - vay) * ny;
-            float e = fabsf(vpre) <= sp.vthr ? 0.0f : rest;
-            dv[k] = fmaxf(-e * vpre, 0.0f) - vn;
-            cna[k] = rax[k] * ny - ray[k] * nx;
-            cnb[k] = rbx[k] * ny - rby[k] * nx;
-            K[k] = ims + (iia * (cna[k] * cna[k]) + iib * (cnb[k] * cnb[k]));
-            act[k] = lam > 0.0f && K[k] > 0.0f;
-        }
-    }
-    float K01 = 0.0f;
-    if (count == 2) K01 = ims + (iia * (cna[0] * cna[1]) + iib * (cnb[0] * cnb[1]));
-    float p0, p1;
-    kinv_apply(K[0], K[1], K01, act[0], act[1], count, dv[0], dv[1], p0, p1);
+    const bool act0 = l0 > 0.0f, act1 = count == 2 && l1 > 0.0f;
     {
-        float pt = p0 + p1;
-        float cra = cna[0] * p0 + cna[1] * p1, crb = cnb[0] * p0 + cnb[1] * p1;
-        va.x = va.x - (nx * pt) * ima;
-        va.y = va.y - (ny * pt) * ima;
-        va.z = va.z - iia * cra;
-        vb.x = vb.x + (nx * pt) * imb;
-        vb.y = vb.y + (ny * pt) * imb;
-        vb.z = vb.z + iib * crb;
-    }
-    bool shift = false;
-    if (!(sp.flags & SFX_CFG_NO_FRICTION)) {
-        float max_, may_, mbx_, mby_;
-        if (count == 2) {
-            max_ = 0.5f * (rax[0] + rax[1]); may_ = 0.5f * (ray[0] + ray[1]);
-            mbx_ = 0.5f * (rbx[0] + rbx[1]); mby_ = 0.5f * (rby[0] + rby[1]);
-        } else { max_ = rax[0]; may_ = ray[0]; mbx_ = rbx[0]; mby_ = rby[0]; }
-        float vax = va.x - va.z * may_, vay = va.y + va.z * max_;
-        float vbx = vb.x - vb.z * mby_, vby = vb.y + vb.z * mbx_;
-        float vx = vbx - vax, vy = vby - vay;
-        float vn = vx * nx + vy * ny;
-        float vtx = vx - nx * vn, vty = vy - ny * vn;
-        float vt = sqrtf(vtx * vtx + vty * vty);
-        if (vt > SFX_EPS_LEN) {
-            float tx = vtx / vt, ty = vty / vt;
-            float cta = max_ * ty - may_ * tx, ctb = mbx_ * ty - mby_ * tx;
-            float Att = ims + (iia * (cta * cta) + iib * (ctb * ctb));
-            float At0 = iia * (cta * cna[0]) + iib * (ctb * cnb[0]);
-            float At1 = iia * (cta * cna[1]) + iib * (ctb * cnb[1]);
-            float y0, y1;
-            kinv_apply(K[0], K[1], K01, act[0], act[1], count, At0, At1, y0, y1);
-            float S = Att - (At0 * y0 + At1 * y1);
-            if (S > 0.0f) {
-                float need = vt / S;
-                bool is_static = need * sp.h < mu_s * lt;
-                float pt = is_static ? -need : -fminf(mu_d * lt * sp.inv_h, need);
-                float q0 = -(y0 * pt), q1 = -(y1 * pt);
-                float jx = tx * pt + nx * (q0 + q1), jy = ty * pt + ny * (q0 + q1);
-                float ja = (cta * pt + cna[0] * q0) + cna[1] * q1;
-                float jb = (ctb * pt + cnb[0] * q0) + cnb[1] * q1;
-                va.x = va.x - jx * ima;
-                va.y = va.y - jy * ima;
-                va.z = va.z - iia * ja;
-                vb.x = vb.x + jx * imb;
-                vb.y = vb.y + jy * imb;
-                vb.z = vb.z + iib * jb;
-                if (is_static) {
-                    shift = true;
-                    if (ima > 0.0f) {
-                        pa.x = pa.x - (jx * sp.h) * ima;
-                        pa.y = pa.y - (jy * sp.h) * ima;
-                    }
-                    if (iia > 0.0f) rotate_by(pa.z, pa.w, -(iia * (ja * sp.h)));
-                    if (imb > 0.0f) {
-                        pb.x = pb.x + (jx * sp.h) * imb;
-                        pb.y = pb.y + (jy * sp.h) * imb;
-                    }
-                    if (iib > 0.0f) rotate_by(pb.z, pb.w, iib * (jb * sp.h));
-                }
+        const float la = va.x * nx + va.y * ny, lb = -(vb.x * nx + vb.y * ny);
+        float dv[2];
+        dv[0] = dv[1] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k < count) {
+                const float ua = la + va.z * r.ca[k], ub = lb + vb.z * r.cb[k];
+                dv[k] = r.tgt[k] + (ua + ub);
             }
         }
+        float p0, p1;
+        kinv_rec(count, r.block, r.i00, r.i01, r.i11, r.iK[0], r.iK[1], act0, act1, dv[0], dv[1], p0, p1);
+        const float pt = p0 + p1;
+        va.x = va.x - (nx * pt) * ima;
+        va.y = va.y - (ny * pt) * ima;
+        va.z = va.z - iia * (r.ca[0] * p0 + r.ca[1] * p1);
+        vb.x = vb.x + (nx * pt) * imb;
+        vb.y = vb.y + (ny * pt) * imb;
+        vb.z = vb.z - iib * (r.cb[0] * p0 + r.cb[1] * p1);
     }
-    return shift ? 3 : 1;
+    if (sp.flags & SFX_CFG_NO_FRICTION) return 1;
+    const float tx = -ny, ty = nx;
+    const float wta = (va.x * tx + va.y * ty) + va.z * r.cta;
+    const float wtb = -(vb.x * tx + vb.y * ty) + vb.z * r.ctb;
+    const float vt = -(wta + wtb);
+    if (!(fabsf(vt) > SFX_EPS_LEN)) return 1;
+    float y0, y1;
+    kinv_rec(count, r.block, r.i00, r.i01, r.i11, r.iK[0], r.iK[1], act0, act1, r.At[0], r.At[1], y0, y1);
+    float invS = r.invS1;   // (assignments, not a conditional between members: that becomes an address select and the record goes to scratch memory)
+    if (act0) invS = r.invS0;
+    if (act0 && (act1 || count == 1)) invS = r.invS;
+    const float need = vt * invS;
+    if (need == 0.0f) return 1;
+    const bool is_static = fabsf(need) * sp.h < r.mu_s * lt;
+    const float pt = is_static ? -need : -copysignf(fminf(r.mu_d * lt * sp.inv_h, fabsf(need)), need);
+    const float q0 = -(y0 * pt), q1 = -(y1 * pt);
+    const float jx = tx * pt + nx * (q0 + q1), jy = ty * pt + ny * (q0 + q1);
+    const float ja = (r.cta * pt + r.ca[0] * q0) + r.ca[1] * q1;
+    const float jb = (r.ctb * pt + r.cb[0] * q0) + r.cb[1] * q1;
+    va.x = va.x - jx * ima;
+    va.y = va.y - jy * ima;
+    va.z = va.z - iia * ja;
+    vb.x = vb.x + jx * imb;
+    vb.y = vb.y + jy * imb;
+    vb.z = vb.z - iib * jb;
+    if (!is_static) return 1;
+    Sa.x = Sa.x - (jx * sp.h) * ima;
+    Sa.y = Sa.y - (jy * sp.h) * ima;
+    Sa.z = Sa.z - iia * (ja * sp.h);
+    Sb.x = Sb.x + (jx * sp.h) * imb;
+    Sb.y = Sb.y + (jy * sp.h) * imb;
+    Sb.z = Sb.z - iib * (jb * sp.h);
+    return 3;
 }
 
 // ---- the same two solves with TWO LANES PER PAIR (the tile kernels): lane 2k holds body a of a pair, lane 2k + 1 body b.
-// A lane computes what belongs to its own body (anchors, lever arms, angular terms, the update of its pose and velocity)
-// and takes the other body's few numbers from its neighbour lane (one DPP move each); what belongs to the pair (depths,
-// the 2x2 solve, friction) both lanes compute, on identical inputs, to identical bits.  With the normal SIGNED per lane
-// (n for a, -n for b) the code is the same on both sides and equals solve_pos_rec / solve_vel_rec bit for bit: negations
-// are exact, sums of two are commutative, and rounding is symmetric in the sign.
+// A lane computes what belongs to its own body (its projections on the frozen rows, the update of its displacement or
+// velocity) and takes the other body's projections from its neighbour lane (one DPP move each); what belongs to the pair
+// (depths, the 2x2 solve, friction) both lanes compute, on identical inputs, to identical bits.  With the normal SIGNED
+// per lane (n for a, -n for b) and the lever arms stored as they act, the code is the same on both sides and equals
+// solve_pos_rec / solve_vel_rec bit for bit: negations are exact, sums of two are commutative, and rounding is symmetric
+// in the sign.
 __device__ __forceinline__ float other_side(float x) {   // the neighbour lane's value (lanes 2k <-> 2k + 1: quad_perm [1,0,3,2])
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xF, 0xF, false));
 }
@@ -842,136 +864,89 @@ __device__ __forceinline__ float other_side(float x) {   // the neighbour lane's
 // One side of a prepared pair, in registers.
 struct SideRec {
     int count;             // 0, 1 or 2 points
+    bool block;
     float nx, ny;          // the normal as this side sees it: from this body to the other
-    float mu_s, mu_d, rest;
-    float l[2][2];         // this body's local anchors
-    float vpre[2];
+    float mu_s, mu_d;
+    float c[2];            // this side's lever arms of the normal rows, as they act
+    float ct;              // ... of the tangent row
+    float d0[2], tgt[2];
+    float iK[2], i00, i01, i11, K01;
+    float At[2];
+    float invS, invS0, invS1;
     float l0, l1;
 };
 
-// returns true when the pose changed; r.l0 / r.l1 = the multipliers (the same on both lanes)
-__device__ __forceinline__ bool solve_pos_side(SideRec& r, float4& p, const float2& w, float max_corr) {
-    const float nx = r.nx, ny = r.ny, im = w.x, ii = w.y;
-    float d[2], cn[2];
-    d[1] = 0.0f; cn[1] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (k < r.count) {
-            float rx, ry;
-            anchor_world(p, r.l[k][0], r.l[k][1], rx, ry);
-            const float qx = p.x + rx, qy = p.y + ry;
-            const float ox = other_side(qx), oy = other_side(qy);
-            d[k] = (qx - ox) * nx + (qy - oy) * ny;
-            d[k] = fminf(d[k], max_corr);
-            cn[k] = rx * ny - ry * nx;
-        }
-    }
-    float l0 = 0.0f, l1 = 0.0f;
-    const float ims = im + other_side(im);
-    const float t00 = ii * (cn[0] * cn[0]);
-    const float K00 = ims + (t00 + other_side(t00));
-    if (!(K00 > 0.0f)) return false;
-    if (r.count == 2) {
-        const float t11 = ii * (cn[1] * cn[1]), t01 = ii * (cn[0] * cn[1]);
-        const float K11 = ims + (t11 + other_side(t11));
-        const float K01 = ims + (t01 + other_side(t01));
-        solve_lcp2(K00, K01, K11, d[0], d[1], l0, l1);
-    } else {
-        l0 = fmaxf(d[0], 0.0f) / K00;
-    }
+// returns true when the displacement changed; r.l0 / r.l1 = the multipliers (the same on both lanes)
+__device__ __forceinline__ bool solve_pos_side(SideRec& r, float4& D, const float2& w, float max_corr) {
+    const float nx = r.nx, ny = r.ny;
+    const float l = D.x * nx + D.y * ny;
+    const bool two = r.count == 2;
+    const float g0 = l + D.z * r.c[0], g1 = l + D.z * r.c[1];
+    const float d0 = fminf(r.d0[0] + (g0 + other_side(g0)), max_corr);
+    const float d1 = fminf(r.d0[1] + (g1 + other_side(g1)), max_corr);   // (meaningful for two points only)
+    float m0, m1;
+    lcp2_rec(r.block, r.i00, r.i01, r.i11, r.iK[0], r.iK[1], r.K01, d0, d1, m0, m1);
+    const float l0 = two ? m0 : fmaxf(d0, 0.0f) * r.iK[0];
+    const float l1 = two ? m1 : 0.0f;
     r.l0 = l0; r.l1 = l1;
     const float lt = l0 + l1;
     if (!(lt > 0.0f)) return false;
-    if (im > 0.0f) {
-        p.x = p.x - (nx * lt) * im;
-        p.y = p.y - (ny * lt) * im;
-    }
-    if (ii > 0.0f) rotate_by(p.z, p.w, -(ii * (cn[0] * l0 + cn[1] * l1)));
+    D.x = D.x - (nx * lt) * w.x;
+    D.y = D.y - (ny * lt) * w.x;
+    D.z = D.z - w.y * (r.c[0] * l0 + r.c[1] * l1);
     return true;
 }
 
-// bit 0: the velocity changed, bit 1: the pose changed (static friction)
-__device__ __forceinline__ int solve_vel_side(const SideRec& r, float4& p, float4& v, const float2& w, const StepParams& sp) {
+// bit 0: the velocity changed, bit 1: the shift did (static friction)
+__device__ __forceinline__ int solve_vel_side(const SideRec& r, float4& v, float4& S, const float2& w, const StepParams& sp) {
     const int count = r.count;
     const float l0 = r.l0, l1 = count == 2 ? r.l1 : 0.0f;
     const float lt = l0 + l1;
-    const float nx = r.nx, ny = r.ny, mu_s = r.mu_s, mu_d = r.mu_d, rest = r.rest;
+    const float nx = r.nx, ny = r.ny;
     const float im = w.x, ii = w.y;
-    const float ims = im + other_side(im);
-    float rx[2], ry[2], dv[2], cn[2], K[2];
-    bool act[2];
-    act[1] = false; dv[1] = 0.0f; cn[1] = 0.0f; K[1] = 1.0f;
-    rx[1] = ry[1] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        if (k < count) {
-            const float lam = k == 0 ? r.l0 : r.l1;
-            const float vpre = r.vpre[k];
-            anchor_world(p, r.l[k][0], r.l[k][1], rx[k], ry[k]);
-            const float ux = v.x - v.z * ry[k], uy = v.y + v.z * rx[k];
-            const float ox = other_side(ux), oy = other_side(uy);
-            const float vn = (ox - ux) * nx + (oy - uy) * ny;
-            const float e = fabsf(vpre) <= sp.vthr ? 0.0f : rest;
-            dv[k] = fmaxf(-e * vpre, 0.0f) - vn;
-            cn[k] = rx[k] * ny - ry[k] * nx;
-            const float tkk = ii * (cn[k] * cn[k]);
-            K[k] = ims + (tkk + other_side(tkk));
-            act[k] = lam > 0.0f && K[k] > 0.0f;
-        }
-    }
-    float K01 = 0.0f;
-    if (count == 2) { const float t01 = ii * (cn[0] * cn[1]); K01 = ims + (t01 + other_side(t01)); }
-    float p0, p1;
-    kinv_apply(K[0], K[1], K01, act[0], act[1], count, dv[0], dv[1], p0, p1);
+    const bool act0 = l0 > 0.0f, act1 = count == 2 && l1 > 0.0f;
     {
+        const float l = v.x * nx + v.y * ny;
+        const float u0 = l + v.z * r.c[0], u1 = l + v.z * r.c[1];
+        const float dv0 = r.tgt[0] + (u0 + other_side(u0));
+        const float dv1 = r.tgt[1] + (u1 + other_side(u1));   // (meaningful for two points only: kinv_rec selects)
+        float p0, p1;
+        kinv_rec(count, r.block, r.i00, r.i01, r.i11, r.iK[0], r.iK[1], act0, act1, dv0, dv1, p0, p1);
         const float pt = p0 + p1;
-        const float cr = cn[0] * p0 + cn[1] * p1;
         v.x = v.x - (nx * pt) * im;
         v.y = v.y - (ny * pt) * im;
-        v.z = v.z - ii * cr;
+        v.z = v.z - ii * (r.c[0] * p0 + r.c[1] * p1);
     }
-    bool shift = false;
-    if (!(sp.flags & SFX_CFG_NO_FRICTION)) {
-        float mx, my;
-        if (count == 2) { mx = 0.5f * (rx[0] + rx[1]); my = 0.5f * (ry[0] + ry[1]); }
-        else { mx = rx[0]; my = ry[0]; }
-        const float ux = v.x - v.z * my, uy = v.y + v.z * mx;
-        const float vx = other_side(ux) - ux, vy = other_side(uy) - uy;
-        const float vn = vx * nx + vy * ny;
-        const float vtx = vx - nx * vn, vty = vy - ny * vn;
-        const float vt = sqrtf(vtx * vtx + vty * vty);
-        if (vt > SFX_EPS_LEN) {
-            const float tx = vtx / vt, ty = vty / vt;
-            const float ct = mx * ty - my * tx;
-            const float att = ii * (ct * ct), a0 = ii * (ct * cn[0]), a1 = ii * (ct * cn[1]);
-            const float Att = ims + (att + other_side(att));
-            const float At0 = a0 + other_side(a0);
-            const float At1 = a1 + other_side(a1);
-            float y0, y1;
-            kinv_apply(K[0], K[1], K01, act[0], act[1], count, At0, At1, y0, y1);
-            const float S = Att - (At0 * y0 + At1 * y1);
-            if (S > 0.0f) {
-                const float need = vt / S;
-                const bool is_static = need * sp.h < mu_s * lt;
-                const float pt = is_static ? -need : -fminf(mu_d * lt * sp.inv_h, need);
-                const float q0 = -(y0 * pt), q1 = -(y1 * pt);
-                const float jx = tx * pt + nx * (q0 + q1), jy = ty * pt + ny * (q0 + q1);
-                const float jr = (ct * pt + cn[0] * q0) + cn[1] * q1;
-                v.x = v.x - jx * im;
-                v.y = v.y - jy * im;
-                v.z = v.z - ii * jr;
-                if (is_static) {
-                    shift = true;
-                    if (im > 0.0f) {
-                        p.x = p.x - (jx * sp.h) * im;
-                        p.y = p.y - (jy * sp.h) * im;
-                    }
-                    if (ii > 0.0f) rotate_by(p.z, p.w, -(ii * (jr * sp.h)));
-                }
-            }
-        }
-    }
-    return shift ? 3 : 1;
+    if (sp.flags & SFX_CFG_NO_FRICTION) return 1;
+    const float tx = -ny, ty = nx;
+    const float wt = (v.x * tx + v.y * ty) + v.z * r.ct;
+    const float vt = -(wt + other_side(wt));
+    if (!(fabsf(vt) > SFX_EPS_LEN)) return 1;
+    float y0, y1;
+    kinv_rec(count, r.block, r.i00, r.i01, r.i11, r.iK[0], r.iK[1], act0, act1, r.At[0], r.At[1], y0, y1);
+    float invS = r.invS1;   // (assignments, not a conditional between members: that becomes an address select and the record goes to scratch memory)
+    if (act0) invS = r.invS0;
+    if (act0 && (act1 || count == 1)) invS = r.invS;
+    const float need = vt * invS;
+    if (need == 0.0f) return 1;
+    const bool is_static = fabsf(need) * sp.h < r.mu_s * lt;
+    const float pt = is_static ? -need : -copysignf(fminf(r.mu_d * lt * sp.inv_h, fabsf(need)), need);
+    const float q0 = -(y0 * pt), q1 = -(y1 * pt);
+    const float jx = tx * pt + nx * (q0 + q1), jy = ty * pt + ny * (q0 + q1);
+    const float jr = (r.ct * pt + r.c[0] * q0) + r.c[1] * q1;
+    v.x = v.x - jx * im;
+    v.y = v.y - jy * im;
+    v.z = v.z - ii * jr;
+    if (!is_static) return 1;
+    S.x = S.x - (jx * sp.h) * im;
+    S.y = S.y - (jy * sp.h) * im;
+    S.z = S.z - ii * (jr * sp.h);
+    return 3;
+}
+
+__device__ __forceinline__ void anchor_world(const float4& pose, float lx, float ly, float& rx, float& ry) {
+    rx = pose.z * lx - pose.w * ly;
+    ry = pose.w * lx + pose.z * ly;
 }
 
 // joints: distance constraints (Mueller et al. 2020 sec. 3.3, XPBD compliance) and angle constraints

@@ -86,7 +86,7 @@ struct sfx_world {
     DevBuf<uint32_t> cbody;
     std::vector<sfx_collider> h_col;
     std::vector<float> h_poly;
-    DevBuf<float4> pose, prev, vel, shape, lpose, poly, mats, aabb, sorted_aabb;
+    DevBuf<float4> pose, prev, vel, dpos, shape, lpose, poly, mats, aabb, sorted_aabb;   // dpos: sfx_device.h BodyArrays
     DevBuf<float2> mass;
     uint32_t vel_epoch = 0;        // derive-on-load: stamp of the current substep's velocity solve (sfx_step only)
     uint32_t vel_prev_epoch = 0;   // stamp of the previous substep of this tick when it left bodies underived, else 0
@@ -103,6 +103,7 @@ struct sfx_world {
     DevBuf<BatchDesc> batches;
     DevBuf<uint4> torder;
     DevBuf<uint32_t> done, bbody, bruns;
+    DevBuf<float2> bmass;   // masses in bbody order
     uint32_t epoch = 0;            // one per fused multi-phase launch; never reset, so T.done needs no clearing
     // workgroups of the solve kernels the device holds at once, per workgroup size variant (512, 256 threads)
     uint32_t resident_pos_v[3] = {0, 0, 0}, resident_vel_v[3] = {0, 0, 0};
@@ -144,7 +145,7 @@ struct sfx_world {
     hipStream_t own_stream_handle = nullptr;
     DevBuf<unsigned long long> dbg;  // -DSFX_TILE_TIMING builds: stage timing of k_tile_pos
     // contact records
-    DevBuf<float4> c_rec;   // 4 per slot: one 64-byte line
+    DevBuf<float4> c_rec;   // kRecPlanes planes of one 16-byte word per slot (sfx_device.h ContactArrays)
     DevBuf<float2> c_lam;
     // joints (colour-sorted)
     DevBuf<uint2> j_bodies;
@@ -232,7 +233,7 @@ void resolve_defaults(sfx_config& c) {
     if (c.color_rounds > 60) c.color_rounds = 60;
     if (c.tile_cells != 0u && c.tile_cells != SFX_TILE_WHOLE_GRID)   // (0: automatic, WHOLE_GRID: one tile -- resolve_grid)
         c.tile_cells = c.tile_cells >= 8 ? 8u : c.tile_cells >= 4 ? 4u : 2u;   // at least two cells: DESIGN.md "Contract / tiles"
-    if (c.speculative_margin == 0.0f) c.speculative_margin = 0.005f;
+    if (c.speculative_margin == 0.0f) c.speculative_margin = 0.010f;
     if (c.speculative_margin < 0.0f) c.speculative_margin = 0.0f;
     if (c.restitution_threshold == 0.0f) c.restitution_threshold = 2.0f;
     if (c.vel_pad_max == 0.0f) c.vel_pad_max = 0.03f;
@@ -421,7 +422,7 @@ int collect_profile(sfx_world* w) {
 
 BodyArrays body_arrays(sfx_world* w) {
     BodyArrays B;
-    B.pose = w->pose.p; B.prev = w->prev.p; B.vel = w->vel.p; B.mass = w->mass.p;
+    B.pose = w->pose.p; B.prev = w->prev.p; B.vel = w->vel.p; B.dpos = w->dpos.p; B.mass = w->mass.p;
     B.shape = w->shape.p; B.lpose = w->lpose.p; B.filt = w->filt.p; B.poly = w->poly.p; B.mats = w->mats.p;
     B.cbody = w->cbody.p; B.nb = w->nb;
     return B;
@@ -429,7 +430,7 @@ BodyArrays body_arrays(sfx_world* w) {
 
 ContactArrays contact_arrays(sfx_world* w) {
     ContactArrays C;
-    C.rec = w->c_rec.p; C.lam = w->c_lam.p;
+    C.rec = w->c_rec.p; C.lam = w->c_lam.p; C.nslots = w->max_pairs + w->fb_cap;
     return C;
 }
 
@@ -470,7 +471,7 @@ uint32_t edge_grid(uint32_t cap) { return std::min(std::max(cdiv(cap, kBlock), 1
 TileArrays tile_arrays(sfx_world* w) {
     TileArrays T;
     T.cell_start = w->cell_start; T.sorted_id = w->sorted_id.p; T.tile_start = w->tile_cnt;
-    T.active = w->active.p; T.batches = w->batches.p; T.tpair = w->tpair.p; T.torder = w->torder.p; T.bbody = w->bbody.p; T.bruns = w->bruns.p; T.tile_batch = w->tile_batch; T.done = w->done.p; T.fsorted = w->fsorted.p;
+    T.active = w->active.p; T.batches = w->batches.p; T.tpair = w->tpair.p; T.torder = w->torder.p; T.bbody = w->bbody.p; T.bmass = w->bmass.p; T.bruns = w->bruns.p; T.tile_batch = w->tile_batch; T.done = w->done.p; T.fsorted = w->fsorted.p;
     T.max_pairs = w->max_pairs; T.fb_cap = w->fb_cap;
     T.dbg = w->dbg.p;
     return T;
@@ -558,7 +559,7 @@ int broadphase(sfx_world* w, float dt) {
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
       hipLaunchKernelGGL(k_batch_color<kBatchP>, dim3(w->color_grid, (w->tly == w->gyl) ? 2u : 4u, w->group > 1u ? 2u : 1u), dim3(kColorThreads), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->sorted_filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
-                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->bbody.p, (uint32_t)w->bbody.n, w->bruns.p, (uint32_t)(w->bruns.n / 64), w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
+                         w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->bbody.p, (uint32_t)w->bbody.n, w->mass.p, w->bmass.p, w->bruns.p, (uint32_t)(w->bruns.n / 64), w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
     HIPCHK(w, hipGetLastError());
     return SFX_OK;
@@ -616,7 +617,8 @@ int alloc_entries(sfx_world* w, uint32_t n_entries) {
     w->n_halo_send = w->n_halo_recv = 0;   // the halo lists and the guard's snapshot index the old entries
     w->halo_guard = 0.0f;
     const size_t c = std::max(n, 1u);
-    ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->mass, c);
+    ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->dpos, c); ALLOC(w, w->mass, c);
+    HIPCHK(w, hipMemset(w->dpos.p, 0, sizeof(float4) * c));   // entries that are never integrated (further colliders) keep a zero displacement
     ALLOC(w, w->filt, c); ALLOC(w, w->shape, c); ALLOC(w, w->lpose, c); ALLOC(w, w->aabb, c); ALLOC(w, w->sorted_aabb, c); ALLOC(w, w->sorted_filt, c);
     ALLOC(w, w->bucket, c); ALLOC(w, w->tmp_id, c); ALLOC(w, w->sorted_id, c); ALLOC(w, w->large_tmp, c);
     ALLOC(w, w->slot_cnt, 3 * ((size_t)n + 1)); ALLOC(w, w->slot_off, 2 * ((size_t)n + 1)); ALLOC(w, w->hit_tmp, kHitTmp * ((size_t)n + 1)); ALLOC(w, w->cellxy, c); ALLOC(w, w->sorted_cell, c);
@@ -769,10 +771,10 @@ void sfx_destroy(sfx_world* w) {
     (void)hipStreamSynchronize(w->stream);
     for (auto& e : w->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : w->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
-    w->pose.release(); w->prev.release(); w->vel.release(); w->shape.release(); w->lpose.release(); w->poly.release();
+    w->pose.release(); w->prev.release(); w->vel.release(); w->dpos.release(); w->shape.release(); w->lpose.release(); w->poly.release();
     w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release(); w->sorted_filt.release();
     w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
-    w->active.release(); w->batches.release(); w->torder.release(); w->done.release(); w->bbody.release(); w->bruns.release(); w->rawp.release(); w->tpair.release();
+    w->active.release(); w->batches.release(); w->torder.release(); w->done.release(); w->bbody.release(); w->bmass.release(); w->bruns.release(); w->rawp.release(); w->tpair.release();
     w->fpairs.release(); w->fsorted.release(); w->hit_tmp.release();
     w->sorted_id.release(); w->large_tmp.release(); w->slot_cnt.release(); w->slot_off.release(); w->scan_sums.release();
     w->cellxy.release(); w->sorted_cell.release();
@@ -952,13 +954,14 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     // a collider lies in at most four tile blocks; plus the outside (large) colliders of each batch: at most kMaxExt per
     // batch, one kept pair each at least
     ALLOC(w, w->bbody, 4 * (size_t)n + 16 + std::min<size_t>((size_t)kMaxExt * w->ntiles, w->max_pairs));
+    ALLOC(w, w->bmass, w->bbody.n);
     HIPCHK(w, hipMemset(w->done.p, 0, sizeof(uint32_t) * max_batches));
     ALLOC(w, w->fpairs, w->fb_cap); ALLOC(w, w->fsorted, w->fb_cap);
     const size_t mc = std::max<size_t>(w->fb_cap, w->m);
     ALLOC(w, w->pcolor, mc); ALLOC(w, w->prop, mc);
     const size_t mp = (size_t)w->max_pairs + w->fb_cap;  // record slots: tile pairs, then the fallback list
-    ALLOC(w, w->c_rec, 4 * mp); ALLOC(w, w->c_lam, mp);
-    HIPCHK(w, hipMemset(w->c_rec.p, 0, sizeof(float4) * 4 * mp));
+    ALLOC(w, w->c_rec, kRecPlanes * mp); ALLOC(w, w->c_lam, mp);
+    HIPCHK(w, hipMemset(w->c_rec.p, 0, sizeof(float4) * kRecPlanes * mp));
     HIPCHK(w, hipMemset(w->zero.p, 0, 2 * w->zero_bytes));
     HIPCHK(w, hipMemset(w->sticky.p, 0, sizeof(uint32_t)));   // every table is new: earlier overflows no longer apply
     w->ovf_host = 0;
@@ -1188,7 +1191,7 @@ int sfx_tick_substep(sfx_world* w) {
     const uint32_t gb = cdiv(std::max(w->nb, 1u), kBlock);   // integration and derive walk the bodies
     const uint32_t njc = (uint32_t)w->joint_color_start.size() - 1;
     { Prof p(w, SFX_K_INTEGRATE, w->nb);
-      hipLaunchKernelGGL(k_integrate, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp, w->vel_prev_epoch); }
+      hipLaunchKernelGGL(k_integrate, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->dpos.p, w->mass.p, sp, w->vel_prev_epoch); }
     // Derive-on-load (sfx_kernels.h): inside sfx_step, with no joint damping between the derive and the velocity solve and
     // no halos read between substeps, the velocity solve derives a body's velocity where it first loads it and the bodies
     // it does not touch are derived by the next integration (or by one k_derive after the last substep): three launches of
@@ -1241,7 +1244,7 @@ int sfx_tick_substep(sfx_world* w) {
         Prof p(w, SFX_K_NARROW, w->ctr_valid ? w->stale.n_kept : 0);
         static const uint32_t ndiv = [] { const char* e = getenv("SFX_NARROW_DIV"); return e ? (uint32_t)std::max(1, atoi(e)) : 1u; }();
         hipLaunchKernelGGL(k_narrow, dim3(std::min(std::max(cdiv(est, kBlock * ndiv), 1u), 16384u)), dim3(kBlock), 0, w->stream, T, w->ctr,
-                           B, C, w->cfg.speculative_margin);
+                           B, C, w->cfg.speculative_margin, sp.vthr);
     }
     if (w->fuse_phases) {
         // all phases in one launch, batches wait for the neighbouring batches of earlier phases
@@ -1255,7 +1258,7 @@ int sfx_tick_substep(sfx_world* w) {
     }
     if (!fuse_derive) {
       Prof p(w, SFX_K_DERIVE_VEL, w->nb);
-      hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp, 0u);
+      hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->dpos.p, w->mass.p, sp, 0u);
     }
     for (uint32_t jc = 0; w->joint_damped && jc < njc; ++jc) {
         const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
@@ -1274,7 +1277,7 @@ int sfx_tick_substep(sfx_world* w) {
     }
     if (fuse_derive && last_substep) {   // the bodies no pair touched in the last substep
       Prof p(w, SFX_K_DERIVE_VEL, w->nb);
-      hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->mass.p, sp, vstamp);
+      hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->dpos.p, w->mass.p, sp, vstamp);
     }
     w->vel_prev_epoch = (fuse_derive && !last_substep) ? vstamp : 0u;
     HIPCHK(w, hipGetLastError());

@@ -154,14 +154,16 @@ __device__ __forceinline__ void integrate_body(float4& p, float4& q, float4& v, 
 __device__ __forceinline__ void derive_body(const float4& p, const float4& q, float4& v, const StepParams& sp);
 
 __global__ __launch_bounds__(kBlock) void k_integrate(uint32_t n, float4* __restrict__ pose, float4* __restrict__ prev,
-                                                      float4* __restrict__ vel, const float2* __restrict__ mass,
-                                                      StepParams sp, uint32_t derive_first) {
+                                                      float4* __restrict__ vel, float4* __restrict__ dpos,
+                                                      const float2* __restrict__ mass, StepParams sp, uint32_t derive_first) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 p = pose[i], q;
     float4 v = vel[i];
     const float2 w = mass[i];
+    // (a body whose velocity nobody derived in the last substep was in no pair's batch: its displacement is zero)
     if (derive_first && (w.x > 0.0f || w.y > 0.0f) && __float_as_uint(v.w) != derive_first) derive_body(p, prev[i], v, sp);
+    dpos[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // the position sweep of this substep starts from the poses integrated here
     integrate_body(p, q, v, w, sp);
     prev[i] = q;
     if (w.x > 0.0f || w.y > 0.0f) vel[i] = v;
@@ -186,8 +188,10 @@ __device__ __forceinline__ void derive_body(const float4& p, const float4& q, fl
 }
 
 // `done` != 0: bodies whose velocity record carries that stamp were derived by the velocity solve already
-__global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, const float4* __restrict__ pose,
+// (and had their displacement applied there); the others' displacement is applied here, before their velocity is derived
+__global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, float4* __restrict__ pose,
                                                     const float4* __restrict__ prev, float4* __restrict__ vel,
+                                                    const float4* __restrict__ dpos,
                                                     const float2* __restrict__ mass, StepParams sp, uint32_t done) {
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
@@ -195,7 +199,10 @@ __global__ __launch_bounds__(kBlock) void k_derive(uint32_t n, const float4* __r
     if (!(w.x > 0.0f || w.y > 0.0f)) return;
     float4 v = vel[i];
     if (done && __float_as_uint(v.w) == done) return;
-    derive_body(pose[i], prev[i], v, sp);
+    float4 p = pose[i];
+    const float4 d = dpos[i];
+    if (d.x != 0.0f || d.y != 0.0f || d.z != 0.0f) { apply_delta(p, d); pose[i] = p; }
+    derive_body(p, prev[i], v, sp);
     vel[i] = v;
 }
 
@@ -990,6 +997,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                                                          const float4* __restrict__ shape, uint4* __restrict__ torder,
                                                          uint32_t* __restrict__ tile_batch,
                                                          uint32_t* __restrict__ bbody, uint32_t bbody_cap,
+                                                         const float2* __restrict__ mass, float2* __restrict__ bmass,
                                                          uint32_t* __restrict__ bruns, uint32_t bruns_cap,
                                                          uint32_t max_pairs, uint32_t rounds, Counters* __restrict__ ctr,
                                                          unsigned long long* __restrict__ dbg) {
@@ -1136,11 +1144,15 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                 if (tid == 0) boff = atomicAdd(&ctr->body_cursor, nbc + next);
                 boff = (uint32_t)__shfl((int)boff, 0, 64);
                 if (tid == 0) { s_boff = boff; s_next = next; }
-                if (tid < next && boff + nbc + tid < bbody_cap) bbody[boff + nbc + tid] = s_ext[tid];
+                if (tid < next && boff + nbc + tid < bbody_cap) { bbody[boff + nbc + tid] = s_ext[tid]; bmass[boff + nbc + tid] = mass[s_ext[tid]]; }
             }
             __syncthreads();
             for (uint32_t l = tid; l < nb; l += kBlock)  // the tile solves load their bodies from this list
-                if (s_mark[l] && s_boff + s_remap[l] < bbody_cap) bbody[s_boff + s_remap[l]] = sorted_id[batch_slot(S, 4u * c, l)];
+                if (s_mark[l] && s_boff + s_remap[l] < bbody_cap) {
+                    const uint32_t id = sorted_id[batch_slot(S, 4u * c, l)];
+                    bbody[s_boff + s_remap[l]] = id;
+                    bmass[s_boff + s_remap[l]] = mass[id];   // the masses in list order: the tile solves fetch them beside the ids, not after them
+                }
             SFX_TT(tc1);
 #define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
             // A thread owns the same (at most MP / threads) edges in every round: their ends, keys, dynamic flags, colour and
@@ -1510,6 +1522,7 @@ struct TileArrays {
     const uint4* torder;          // narrowphase order, per batch grouped by shape-pair class: (body a, body b, position in tpair
                                   // = record slot, -); slot kNoPair: skip.  The ids ride along so that k_narrow has one dependent load less
     const uint32_t* bbody;        // per batch (BatchDesc.boff): body ids in local-index order
+    const float2* bmass;          // ... and their masses, in the same order (written once per frame by k_batch_color)
     const uint32_t* bruns;        // per batch (BatchDesc.roff): 64 colour runs, first | end << 16
     const uint32_t* tile_batch;   // [phase][tile]: 1 + index of the tile's batch on that phase's table (0: none this tick)
     uint32_t* done;               // per batch slot: epoch of the last fused launch that finished it
@@ -1520,34 +1533,46 @@ struct TileArrays {
 };
 
 
+__device__ __forceinline__ uint32_t rec_count(const float4& a) { return __float_as_uint(a.z) & 0xFFu; }
+__device__ __forceinline__ float4* rec_plane(const ContactArrays& C, int pl) { return C.rec + (size_t)pl * C.nslots; }
+
 __device__ __forceinline__ void store_record(const ContactArrays& C, uint32_t slot, const PairRec& r) {
-    float4* line = C.rec + 4u * (size_t)slot;
-    line[3] = make_float4(r.rest, __uint_as_float((uint32_t)r.count), r.vpre[0], r.vpre[1]);
+    rec_plane(C, kPlA)[slot] = make_float4(r.nx, r.ny, __uint_as_float((uint32_t)r.count | (r.block ? 256u : 0u)), r.iK[0]);
     if (r.count == 0) return;
-    line[0] = make_float4(r.nx, r.ny, r.mu_s, r.mu_d);
-    line[1] = make_float4(r.la[0][0], r.la[0][1], r.lb[0][0], r.lb[0][1]);
-    line[2] = make_float4(r.la[1][0], r.la[1][1], r.lb[1][0], r.lb[1][1]);  // zeros for a one-point manifold: the line is written whole
+    rec_plane(C, kPlB)[slot] = make_float4(r.ca[0], r.cb[0], r.d0[0], r.tgt[0]);
+    rec_plane(C, kPlC)[slot] = make_float4(r.cta, r.ctb, r.mu_s, r.mu_d);
+    rec_plane(C, kPlD)[slot] = make_float4(r.At[0], r.invS, r.Att, 0.0f);
+    if (r.count == 2) {
+        rec_plane(C, kPlE)[slot] = make_float4(r.ca[1], r.cb[1], r.d0[1], r.tgt[1]);
+        rec_plane(C, kPlF)[slot] = make_float4(r.i00, r.i01, r.i11, r.K01);
+        rec_plane(C, kPlG)[slot] = make_float4(r.iK[1], r.At[1], r.invS0, r.invS1);
+    }
 }
 
 __device__ __forceinline__ void load_record(const ContactArrays& C, uint32_t slot, PairRec& r) {
-    const float4* line = C.rec + 4u * (size_t)slot;
-    const float4 m = line[3];
-    r.count = (int)__float_as_uint(m.y);
-    r.rest = m.x;
-    r.nx = r.ny = r.mu_s = r.mu_d = 0.0f;
-    r.la[0][0] = r.la[0][1] = r.lb[0][0] = r.lb[0][1] = 0.0f;
-    r.la[1][0] = r.la[1][1] = r.lb[1][0] = r.lb[1][1] = 0.0f;
-    r.vpre[0] = r.vpre[1] = 0.0f; r.l0 = r.l1 = 0.0f;
+    const float4 h0 = rec_plane(C, kPlA)[slot];
+    const uint32_t bits = __float_as_uint(h0.z);
+    r.count = (int)(bits & 0xFFu);
+    r.block = (bits & 256u) != 0u;
+    r.nx = h0.x; r.ny = h0.y; r.iK[0] = h0.w;
+    r.mu_s = r.mu_d = 0.0f;
+    r.ca[0] = r.ca[1] = r.cb[0] = r.cb[1] = r.cta = r.ctb = 0.0f;
+    r.d0[0] = r.d0[1] = r.tgt[0] = r.tgt[1] = 0.0f;
+    r.iK[1] = r.i00 = r.i01 = r.i11 = r.K01 = 0.0f;
+    r.Att = r.At[0] = r.At[1] = r.invS = r.invS0 = r.invS1 = 0.0f;
+    r.l0 = r.l1 = 0.0f;
     if (r.count == 0) return;
     const float2 lam = C.lam[slot];
-    r.l0 = lam.x; r.l1 = lam.y; r.vpre[0] = m.z; r.vpre[1] = m.w;
-    const float4 hdr = line[0];
-    r.nx = hdr.x; r.ny = hdr.y; r.mu_s = hdr.z; r.mu_d = hdr.w;
-    const float4 a0 = line[1];
-    r.la[0][0] = a0.x; r.la[0][1] = a0.y; r.lb[0][0] = a0.z; r.lb[0][1] = a0.w;
+    r.l0 = lam.x; r.l1 = lam.y;
+    const float4 hb = rec_plane(C, kPlB)[slot], hc = rec_plane(C, kPlC)[slot], hd = rec_plane(C, kPlD)[slot];
+    r.ca[0] = hb.x; r.cb[0] = hb.y; r.d0[0] = hb.z; r.tgt[0] = hb.w;
+    r.cta = hc.x; r.ctb = hc.y; r.mu_s = hc.z; r.mu_d = hc.w;
+    r.At[0] = hd.x; r.invS = hd.y; r.Att = hd.z;
     if (r.count == 2) {
-        const float4 a1 = line[2];
-        r.la[1][0] = a1.x; r.la[1][1] = a1.y; r.lb[1][0] = a1.z; r.lb[1][1] = a1.w;
+        const float4 he = rec_plane(C, kPlE)[slot], hf = rec_plane(C, kPlF)[slot], hg = rec_plane(C, kPlG)[slot];
+        r.ca[1] = he.x; r.cb[1] = he.y; r.d0[1] = he.z; r.tgt[1] = he.w;
+        r.i00 = hf.x; r.i01 = hf.y; r.i11 = hf.z; r.K01 = hf.w;
+        r.iK[1] = hg.x; r.At[1] = hg.y; r.invS0 = hg.z; r.invS1 = hg.w;
     }
 }
 
@@ -1559,7 +1584,7 @@ __device__ __forceinline__ void load_record(const ContactArrays& C, uint32_t slo
 #define SFX_NARROW_WAVES 1   // waves per SIMD the register budget of k_narrow must allow (build knob)
 #endif
 __global__ __launch_bounds__(kBlock, SFX_NARROW_WAVES) void k_narrow(TileArrays T, const Counters* __restrict__ ctr, BodyArrays B,
-                                                    ContactArrays C, float sm) {
+                                                    ContactArrays C, float sm, float vthr) {
     const uint32_t ntp = min(ctr->tp_cursor, T.max_pairs);
     const uint32_t nfb = min(ctr->n_fb, T.fb_cap) ? ctr->fb_start[SFX_MAX_COLORS] : 0u;
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < ntp + nfb; j += gridDim.x * kBlock) {
@@ -1575,7 +1600,9 @@ __global__ __launch_bounds__(kBlock, SFX_NARROW_WAVES) void k_narrow(TileArrays 
         }
         PairRec r;
         const float4 pa = B.pose[a], pb = B.pose[b], sa = B.shape[a], sb = B.shape[b];
-        prepare_pair(pa, sa, B.vel[a], pb, sb, B.vel[b], shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, r);
+        // the masses are the BODIES' (a further collider has none of its own; only fallback pairs name one of a dynamic body)
+        const float2 wa = B.mass[j < ntp ? a : body_of(B, a)], wb = B.mass[j < ntp ? b : body_of(B, b)];
+        prepare_pair(pa, sa, B.vel[a], wa, pb, sb, B.vel[b], wb, shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, vthr, r);
         store_record(C, slot, r);
     }
 }
@@ -1595,19 +1622,21 @@ __device__ __forceinline__ void fallback_pos(const TileArrays& T, const Counters
             load_record(C, T.max_pairs + k, r);
             if (r.count == 0) continue;
             ab.x = body_of(B, ab.x); ab.y = body_of(B, ab.y);   // the list names colliders, the solve moves their bodies
-            float4 pa = B.pose[ab.x], pb = B.pose[ab.y];
+            float4 Da = B.dpos[ab.x], Db = B.dpos[ab.y];
             const float2 wa = B.mass[ab.x], wb = B.mass[ab.y];
-            const bool moved = solve_pos_rec(r, pa, wa, pb, wb, max_corr);
+            const bool moved = solve_pos_rec(r, Da, wa, Db, wb, max_corr);
             C.lam[T.max_pairs + k] = make_float2(r.l0, r.l1);
             if (moved) {
-                if (wa.x > 0.0f || wa.y > 0.0f) B.pose[ab.x] = pa;
-                if (wb.x > 0.0f || wb.y > 0.0f) B.pose[ab.y] = pb;
+                if (wa.x > 0.0f || wa.y > 0.0f) B.dpos[ab.x] = Da;
+                if (wb.x > 0.0f || wb.y > 0.0f) B.dpos[ab.y] = Db;
             }
         }
         __syncthreads();
     }
 }
 
+// (the static-friction shifts of a fallback pair are applied to the two poses at once, pair by pair: one workgroup on
+// global memory has nowhere to keep them until the end of the phase)
 __device__ __forceinline__ void fallback_vel(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
                                              const ContactArrays& C, const StepParams& sp, uint32_t vstamp = 0u) {
     const uint32_t nfb = min(ctr->n_fb, T.fb_cap);
@@ -1621,18 +1650,33 @@ __device__ __forceinline__ void fallback_vel(const TileArrays& T, const Counters
             load_record(C, T.max_pairs + k, r);
             if (r.count == 0) continue;
             ab.x = body_of(B, ab.x); ab.y = body_of(B, ab.y);
-            float4 pa = B.pose[ab.x], pb = B.pose[ab.y];
             float4 va = B.vel[ab.x], vb = B.vel[ab.y];
             const float2 wa = B.mass[ab.x], wb = B.mass[ab.y];
+            const bool dyna = wa.x > 0.0f || wa.y > 0.0f, dynb = wb.x > 0.0f || wb.y > 0.0f;
             bool da = false, db = false;   // derive-on-load: this pair is the first to read the body's velocity this substep
             if (vstamp) {
-                if ((wa.x > 0.0f || wa.y > 0.0f) && __float_as_uint(va.w) != vstamp) { derive_body(pa, B.prev[ab.x], va, sp); va.w = __uint_as_float(vstamp); da = true; }
-                if ((wb.x > 0.0f || wb.y > 0.0f) && __float_as_uint(vb.w) != vstamp) { derive_body(pb, B.prev[ab.y], vb, sp); vb.w = __uint_as_float(vstamp); db = true; }
+                if (dyna && __float_as_uint(va.w) != vstamp) {
+                    float4 pa = B.pose[ab.x];
+                    apply_delta(pa, B.dpos[ab.x]);
+                    derive_body(pa, B.prev[ab.x], va, sp); va.w = __uint_as_float(vstamp); da = true;
+                    B.pose[ab.x] = pa;
+                }
+                if (dynb && __float_as_uint(vb.w) != vstamp) {
+                    float4 pb = B.pose[ab.y];
+                    apply_delta(pb, B.dpos[ab.y]);
+                    derive_body(pb, B.prev[ab.y], vb, sp); vb.w = __uint_as_float(vstamp); db = true;
+                    B.pose[ab.y] = pb;
+                }
             }
-            const int ch = solve_vel_rec(r, pa, va, wa, pb, vb, wb, sp);
+            float4 Sa = make_float4(0.0f, 0.0f, 0.0f, 0.0f), Sb = Sa;
+            const int ch = solve_vel_rec(r, va, wa, vb, wb, Sa, Sb, sp);
             if (ch || da || db) {
-                if (wa.x > 0.0f || wa.y > 0.0f) { B.vel[ab.x] = va; if (ch & 2) B.pose[ab.x] = pa; }
-                if (wb.x > 0.0f || wb.y > 0.0f) { B.vel[ab.y] = vb; if (ch & 2) B.pose[ab.y] = pb; }
+                if (dyna) B.vel[ab.x] = va;
+                if (dynb) B.vel[ab.y] = vb;
+            }
+            if (ch & 2) {
+                if (dyna) { float4 pa = B.pose[ab.x]; apply_delta(pa, Sa); B.pose[ab.x] = pa; }
+                if (dynb) { float4 pb = B.pose[ab.y]; apply_delta(pb, Sb); B.pose[ab.y] = pb; }
             }
         }
         __syncthreads();
@@ -1684,11 +1728,11 @@ struct SideSlot {
 // another, nothing branches on loaded data), decoded only when the pair's colour comes up -- so the loads of colour
 // c + 1 are in flight while colour c is solved.  The two lanes of a pair load the same lines (one request).
 struct RawSide {
-    float4 m;        // (restitution, count as bits, vn_pre0, vn_pre1)
-    float2 lam;
     uint4 pr;
-    float4 hdr;
-    float2 a0, a1;   // this side's local anchors
+    float4 ha, hb, he, hf, hg;   // planes A, B and (two points) E, F, G
+    float4 hc;                   // velocity pass: plane C
+    float2 hd;                   // velocity pass: (At0, invS) of plane D
+    float2 lam;
     bool in_range;
 };
 
@@ -1700,14 +1744,19 @@ __device__ __forceinline__ void fetch_side(const TileArrays& T, const ContactArr
     q.in_range = in_range;
     slot = in_range ? slot : 0u;
     q.lam = make_float2(0.0f, 0.0f);
-    const float4* line = C.rec + 4u * (size_t)slot;
-    const float2* half = reinterpret_cast<const float2*>(line);
+    q.hc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    q.hd = make_float2(0.0f, 0.0f);
     q.pr = T.tpair[slot];
-    q.m = line[3];
-    q.hdr = line[0];
-    q.a0 = half[2u + side];   // line[1] = (a's anchor 0, b's anchor 0)
-    q.a1 = half[4u + side];   // line[2] = (a's anchor 1, b's anchor 1)
-    if (VEL) q.lam = C.lam[slot];
+    q.ha = rec_plane(C, kPlA)[slot];
+    q.hb = rec_plane(C, kPlB)[slot];
+    q.he = rec_plane(C, kPlE)[slot];
+    q.hf = rec_plane(C, kPlF)[slot];
+    q.hg = rec_plane(C, kPlG)[slot];
+    if (VEL) {
+        q.hc = rec_plane(C, kPlC)[slot];
+        q.hd = *reinterpret_cast<const float2*>(rec_plane(C, kPlD) + slot);
+        q.lam = C.lam[slot];
+    }
 }
 
 template <bool VEL>
@@ -1715,19 +1764,29 @@ __device__ __forceinline__ void decode_side(const RawSide& q, uint32_t side, Sid
     p.valid = false;
     p.r.count = 0;
     const PairEnds e = pair_ends(q.pr);
-    p.li = side ? e.lb : e.la;
-    const int count = (int)__float_as_uint(q.m.y);
+    p.li = side ? +e.lb : +e.la;
+    const uint32_t bits = __float_as_uint(q.ha.z);
+    const int count = (int)(bits & 0xFFu);
     if (!q.in_range || count == 0) return;
     if (e.la >= nb || e.lb >= nb) return;  // an outside body that found no LDS slot (kOvfExt was reported)
     if (VEL && !(q.lam.x + q.lam.y > 0.0f)) return;  // nothing was pushed: nothing to do in the velocity pass
     SideRec& r = p.r;
-    r.count = count; r.rest = q.m.x;
-    r.l0 = q.lam.x; r.l1 = q.lam.y; r.vpre[0] = q.m.z; r.vpre[1] = q.m.w;
-    r.nx = side ? -q.hdr.x : q.hdr.x; r.ny = side ? -q.hdr.y : q.hdr.y;   // from this body to the other
-    r.mu_s = q.hdr.z; r.mu_d = q.hdr.w;
-    r.l[0][0] = q.a0.x; r.l[0][1] = q.a0.y;
-    const bool two = count == 2;
-    r.l[1][0] = two ? q.a1.x : 0.0f; r.l[1][1] = two ? q.a1.y : 0.0f;
+    const bool two = count == 2;   // (planes E, F, G are only written -- and meaningful -- for two points)
+    r.count = count; r.block = (bits & 256u) != 0u;
+    r.nx = side ? -q.ha.x : q.ha.x; r.ny = side ? -q.ha.y : q.ha.y;   // from this body to the other
+    r.iK[0] = q.ha.w;
+    r.c[0] = side ? +q.hb.y : +q.hb.x;   // (unary plus: a conditional of two lvalues is an lvalue -- an address select that keeps the struct in scratch memory)
+    r.d0[0] = q.hb.z; r.tgt[0] = q.hb.w;
+    r.ct = side ? +q.hc.y : +q.hc.x; r.mu_s = q.hc.z; r.mu_d = q.hc.w;
+    // the second point's fields are only written (and meaningful) for two-point manifolds; the solves never select
+    // anything computed from them otherwise.  Only its lever arm enters sums unconditionally (times a zero multiplier)
+    r.c[1] = two ? (side ? +q.he.y : +q.he.x) : 0.0f;
+    r.d0[1] = q.he.z; r.tgt[1] = q.he.w;
+    r.i00 = q.hf.x; r.i01 = q.hf.y; r.i11 = q.hf.z; r.K01 = q.hf.w;
+    r.iK[1] = q.hg.x;
+    r.At[0] = q.hd.x; r.invS = q.hd.y;
+    r.At[1] = q.hg.y; r.invS0 = q.hg.z; r.invS1 = q.hg.w;
+    r.l0 = q.lam.x; r.l1 = q.lam.y;
     p.valid = true;
 }
 
@@ -1877,24 +1936,54 @@ __device__ __forceinline__ void publish_batch(const TileArrays& T, const GridPar
         __hip_atomic_store(&T.done[ph * g.pstride + it], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Position solve of one phase.  A workgroup takes one batch of tiles at a time: the poses of the
-// batch's blocks go to LDS; the narrowphase of the batch's pairs runs at those poses and leaves
-// one record per pair in the contact arrays; then the colours are solved one after the other with
-// a workgroup barrier in between.  The pairs of a colour are a contiguous run of the
-// colour-sorted list and are taken by consecutive lanes; every lane fetches the record of its
-// next colour's pair while it solves the current one.  Finally the blocks' dynamic bodies are
-// written back.  Batches of one phase have disjoint blocks.
+// The colour loop of a batch as a flat list of STEPS: a step is one colour's run, or -- when a colour has more pairs than
+// the workgroup has lane pairs -- one chunk of NT / 2 pairs of it; steps of one colour need no barrier between them.  With
+// the list in LDS a lane knows the record slot of any later step, so records are fetched kDepth steps ahead: a record
+// comes from HBM / Infinity Cache (written by k_narrow on other XCDs) and takes about a microsecond, a step a few hundred
+// cycles.  entry = first pair of the chunk | end of the colour's run << 16 (both < 65536, as in the run table).
+#ifndef SFX_DEPTH_POS
+#define SFX_DEPTH_POS 1
+#endif
+#ifndef SFX_DEPTH_VEL
+#define SFX_DEPTH_VEL 1
+#endif
+constexpr uint32_t kMaxSteps = SFX_MAX_COLORS + 2u * kBatchP / 128u;   // every colour once + the extra chunks of the smallest workgroup
+
+// wave 0 of the workgroup; `runs` = the batch's 64 colour runs (first | end << 16); returns nothing: s_nsteps is set
+template <int NT>
+__device__ __forceinline__ void build_steps(const uint32_t* __restrict__ runs, uint32_t ncol, uint32_t* s_step, uint32_t* s_nsteps) {
+    if (threadIdx.x >= 64u) return;
+    const uint32_t c = threadIdx.x;
+    const uint32_t v = runs[c];
+    const uint32_t cs = v & 0xFFFFu, ce = v >> 16;
+    const uint32_t len = (c < ncol && ce > cs) ? ce - cs : 0u;
+    const uint32_t nch = (len + (uint32_t)(NT / 2) - 1u) / (uint32_t)(NT / 2);
+    const uint32_t incl = wave_inclusive_scan(nch);
+    const uint32_t off = incl - nch;
+    for (uint32_t i = 0; i < nch; ++i)
+        if (off + i < kMaxSteps) s_step[off + i] = (cs + i * (uint32_t)(NT / 2)) | (ce << 16);
+    if (c == 63u) *s_nsteps = min(incl, kMaxSteps);
+}
+
+// Position solve (DESIGN.md "Contract / frozen rows").  A workgroup takes one batch of tiles at a time: the displacements
+// (dx, dy, dtheta) of the batch's bodies -- zero for the first phase of a substep, what earlier phases accumulated
+// otherwise -- and their masses go to LDS; the colours are solved one after the other with an LDS-only barrier in
+// between.  The pairs of a colour are a contiguous run of the colour-sorted list and are taken by consecutive lanes, two
+// lanes per pair; every lane fetches the record of its next colour's pair while it solves the current one.  Finally the
+// dynamic bodies' displacements are written back.  Poses are not touched: the displacement is applied once per body
+// where its velocity is derived.  Batches of one phase have disjoint bodies.
 template <int NT>
 __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int flags, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   float max_corr) {
-    __shared__ float4 s_pose[kMaxBX];
+    __shared__ float4 s_d[kMaxBX];
     __shared__ float2 s_mass[kMaxBX];
     __shared__ uint32_t s_gid[kMaxBX];
     __shared__ float2 s_lam[kBatchP];  // the batch's multipliers, written out in one coalesced pass after the colours
-    __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
+    __shared__ uint32_t s_step[kMaxSteps], s_nsteps;
+    constexpr int kDepth = SFX_DEPTH_POS;
     const uint32_t tid = threadIdx.x;
-    const __amdgpu_buffer_rsrc_t pose_rs = record_rsrc(B.pose);
+    const __amdgpu_buffer_rsrc_t dpos_rs = record_rsrc(B.dpos);
     const uint32_t nitems = phase_total(ctr, ph0, nph);
     __shared__ uint32_t s_next;
     for (uint32_t item = next_item(ctr, flags); item < nitems; item = s_next) {
@@ -1904,78 +1993,89 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         const BatchDesc d = T.batches[ph * g.pstride + it];
         const uint32_t* tiles = T.active + d.first;   // one tile list for all phases
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol, npb = min(d.np, kBatchP);
-        // everything that no earlier phase of this launch writes is fetched before waiting for them: the records of
-        // the first colour (it starts the batch's list), the body ids, the masses, the colour runs
+        // everything that no earlier phase of this launch writes is fetched before waiting for them: the step list, the
+        // records of the first kDepth steps, the body ids, the masses
         const uint32_t side = tid & 1u, half = tid >> 1;   // two lanes per pair: body a, body b
-        RawSide nxt;
-        fetch_side<false>(T, C, start + half, side, start + half < T.max_pairs, nxt);
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
+        build_steps<NT>(T.bruns + 64u * d.roff, ncol, s_step, &s_nsteps);
         for (uint32_t l = tid; l < nb; l += NT) {  // block bodies, then the large colliders outside the block its pairs touch
             const uint32_t gid = T.bbody[d.boff + l];
             s_gid[l] = gid;
-            s_mass[l] = B.mass[gid];
+            s_mass[l] = T.bmass[d.boff + l];
+            if (ph == 0u) s_d[l] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // nothing has moved yet in this substep
         }
         for (uint32_t k = tid; k < npb; k += NT) s_lam[k] = make_float2(0.0f, 0.0f);
-        if (tid < SFX_MAX_COLORS) {  // the colour runs of the batch's pair list, tabulated by k_batch_color
-            const uint32_t v = T.bruns[64u * d.roff + tid];
-            s_cs[tid] = v & 0xFFFFu; s_ce[tid] = v >> 16;
+        __syncthreads();
+#ifdef SFX_PROBE_NOLOOP   // timing probe: a batch without its colour loop (load, hand-off and write-back only; results are wrong)
+        const uint32_t ns = 0u;
+#else
+        const uint32_t ns = s_nsteps;
+#endif
+        RawSide q[kDepth];
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+            const uint32_t st = s_step[min((uint32_t)u, kMaxSteps - 1u)];
+            const uint32_t k = (st & 0xFFFFu) + half;
+            fetch_side<false>(T, C, start + k, side, (uint32_t)u < ns && k < (st >> 16), q[u]);
         }
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
         SFX_TT(ttw);
         SFX_TT_ADD(6, tt0, ttw);
-        for (uint32_t l = tid; l < nb; l += NT) s_pose[l] = B.pose[s_gid[l]];  // (the lane that stored s_gid[l])
+        if (ph != 0u)
+            for (uint32_t l = tid; l < nb; l += NT) s_d[l] = B.dpos[s_gid[l]];  // (the lane that stored s_gid[l])
         __syncthreads();
-        nxt.in_range = ncol > 0u && half < s_ce[0];
         const uint32_t ahead = take_ahead<NT>(ctr, flags);  // the next batch's ticket, in flight during the colour loop
         SFX_TT(tt1);
         SFX_TT(tt2);
-        auto solve = [&](uint32_t k, SideSlot& p) {  // everything from LDS: no memory wait inside a colour step
-            float4 ps = s_pose[p.li];
+        auto solve = [&](uint32_t k, SideSlot& p) __attribute__((always_inline)) {  // everything from LDS: no memory wait inside a step
+            float4 D = s_d[p.li];
             const float2 w = s_mass[p.li];
 #ifdef SFX_PROBE_NOSOLVE   // timing probe: the colour loop without its arithmetic (results are wrong)
-            ps.x += p.r.l[0][0] * 1e-30f;
-            if (w.x > 0.0f) s_pose[p.li] = ps;
+            D.x += p.r.c[0] * 1e-30f;
+            if (w.x > 0.0f) s_d[p.li] = D;
             return;
 #endif
-            if (solve_pos_side(p.r, ps, w, max_corr)) {
-                if (w.x > 0.0f || w.y > 0.0f) s_pose[p.li] = ps;
+            if (solve_pos_side(p.r, D, w, max_corr)) {
+                if (w.x > 0.0f || w.y > 0.0f) s_d[p.li] = D;
             }
             if (side == 0u) s_lam[k] = make_float2(p.r.l0, p.r.l1);
         };
-        // (fetching two colours ahead, with two register sets, was measured again in round 2: 2 % slower -- a step does
-        // not wait for its record, it is one wave's dependent instruction chain)
-        for (uint32_t c = 0; c < ncol; ++c) {
-            SideSlot cur;
-            decode_side<false>(nxt, side, cur, nb);
-            const uint32_t k0 = s_cs[c] + half, ce = s_ce[c];
-            {   // the next colour's pair, in flight while this one is solved
-                const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
-                fetch_side<false>(T, C, start + s_cs[c1] + half, side, c + 1u < ncol && s_cs[c1] + half < s_ce[c1], nxt);
+        for (uint32_t s0 = 0; s0 < ns; s0 += (uint32_t)kDepth) {
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) {
+                const uint32_t sidx = s0 + (uint32_t)u;
+                if (sidx < ns) {
+                    const uint32_t st = s_step[sidx];
+                    const uint32_t k = (st & 0xFFFFu) + half;
+                    SideSlot cur;
+                    decode_side<false>(q[u], side, cur, nb);
+                    {   // the record of the step kDepth ahead takes this one's registers
+                        const uint32_t nx = sidx + (uint32_t)kDepth;
+                        const uint32_t st2 = s_step[min(nx, kMaxSteps - 1u)];
+                        const uint32_t k2 = (st2 & 0xFFFFu) + half;
+                        fetch_side<false>(T, C, start + k2, side, nx < ns && k2 < (st2 >> 16), q[u]);
+                    }
+                    if (cur.valid) solve(k, cur);
+                    if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) lds_barrier();   // the colour's last chunk
+                }
             }
-            if (cur.valid) solve(k0, cur);
-            for (uint32_t k = k0 + NT / 2; k < ce; k += NT / 2) {  // colour runs longer than half the workgroup
-                SideSlot more;
-                fetch_side_now<false>(T, C, start + k, side, more, nb);
-                if (more.valid) solve(k, more);
-            }
-            lds_barrier();
         }
         __syncthreads();
         if (tid == NT - 64) s_next = ahead;  // read after the barrier that ends the write-back
         for (uint32_t k = tid; k < npb; k += NT) C.lam[start + k] = s_lam[k];
         SFX_TT(tt3);
         SFX_TT_ADD(1, tt1, tt2); SFX_TT_ADD(2, tt2, tt3); SFX_TT_ADD(5, 0ull, (unsigned long long)ncol);
-        if (nph > 1u) {  // fused phases: later batches of this launch read these poses
+        if (nph > 1u) {  // fused phases: later batches of this launch read these displacements
             for (uint32_t l = tid; l < nb; l += NT) {
                 const float2 w = s_mass[l];
-                if (w.x > 0.0f || w.y > 0.0f) store_record16<true>(B.pose, pose_rs, s_gid[l], s_pose[l]);
+                if (w.x > 0.0f || w.y > 0.0f) store_record16<true>(B.dpos, dpos_rs, s_gid[l], s_d[l]);
             }
             if (ph + 1u < ph0 + nph) publish_batch(T, g, ph, it, epoch);
             else __syncthreads();
         } else {
             for (uint32_t l = tid; l < nb; l += NT) {
                 const float2 w = s_mass[l];
-                if (w.x > 0.0f || w.y > 0.0f) B.pose[s_gid[l]] = s_pose[l];
+                if (w.x > 0.0f || w.y > 0.0f) B.dpos[s_gid[l]] = s_d[l];
             }
             __syncthreads();
         }
@@ -1986,16 +2086,22 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
     if ((flags & kTileFallback) && ctr->n_fb != 0u && last_workgroup(ctr)) fallback_pos(T, ctr, B, C, max_corr);
 }
 
+// Velocity pass, same batches.  The bodies' velocities go to LDS; inside sfx_step (vstamp != 0) the first batch of the sweep
+// to load a body applies the displacement the position sweep left for it, derives its velocity and stamps it (DESIGN.md
+// "Velocities derived where they are first read").  The poses stay in the registers of the lanes that loaded them: the
+// colour steps work on velocities and frozen rows only; static friction accumulates a pose shift per body in LDS, which
+// is applied when the batch writes back.
 template <int NT>
 __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph0, uint32_t nph, uint32_t epoch, int flags, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   StepParams sp, uint32_t vstamp) {
-    __shared__ float4 s_pose[kMaxBX];
     __shared__ float4 s_vel[kMaxBX];
+    __shared__ float4 s_sh[kMaxBX];    // static-friction shifts (dx, dy, dtheta, -) of this batch
     __shared__ float2 s_mass[kMaxBX];
     __shared__ uint32_t s_gid[kMaxBX];
-    __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
-    __shared__ uint32_t s_shift;
+    __shared__ uint32_t s_step[kMaxSteps], s_nsteps;
+    constexpr int kDepth = SFX_DEPTH_VEL;
+    constexpr int kRounds = (int)((kMaxBX + NT - 1) / NT);   // bodies a lane loads (and writes back) per batch, at most
     const uint32_t tid = threadIdx.x;
 #ifdef SFX_TILE_TIMING
     if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[48 + 2 * (epoch & 15u)], ~wall_clock64());   // earliest kernel entry
@@ -2011,89 +2117,111 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         SFX_TT(tv0);
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol;
         const uint32_t side = tid & 1u, half = tid >> 1;   // two lanes per pair: body a, body b
-        RawSide nxt;  // as in k_tile_pos: what earlier phases do not write is fetched before waiting for them
-        fetch_side<true>(T, C, start + half, side, start + half < T.max_pairs, nxt);
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
-        if (tid == 0) s_shift = 0u;
-        if (tid < SFX_MAX_COLORS) {
-            const uint32_t v = T.bruns[64u * d.roff + tid];
-            s_cs[tid] = v & 0xFFFFu; s_ce[tid] = v >> 16;
-        }
+        build_steps<NT>(T.bruns + 64u * d.roff, ncol, s_step, &s_nsteps);   // as in k_tile_pos: what earlier phases do not write is fetched before waiting for them
         for (uint32_t l = tid; l < nb; l += NT) {
             const uint32_t gid = T.bbody[d.boff + l];
             s_gid[l] = gid;
-            s_mass[l] = B.mass[gid];
+            s_mass[l] = T.bmass[d.boff + l];
+            s_sh[l] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+        __syncthreads();
+#ifdef SFX_PROBE_NOLOOP   // timing probe: a batch without its colour loop (load, hand-off and write-back only; results are wrong)
+        const uint32_t ns = 0u;
+#else
+        const uint32_t ns = s_nsteps;
+#endif
+        RawSide q[kDepth];
+#pragma unroll
+        for (int u = 0; u < kDepth; ++u) {
+            const uint32_t st = s_step[min((uint32_t)u, kMaxSteps - 1u)];
+            const uint32_t k = (st & 0xFFFFu) + half;
+            fetch_side<true>(T, C, start + k, side, (uint32_t)u < ns && k < (st >> 16), q[u]);
         }
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
         SFX_TT(tvw);
-        for (uint32_t l = tid; l < nb; l += NT) {
-            const uint32_t gid = s_gid[l];
-            const float4 ps = B.pose[gid];
-            float4 vs = B.vel[gid];
-            if (vstamp) {   // derive-on-load: the first batch of the sweep to read a body derives its velocity and stamps it
-                const float4 q = B.prev[gid];   // (fetched beside the others: no load waits for the stamp)
-                const float2 w = s_mass[l];
-                if ((w.x > 0.0f || w.y > 0.0f) && __float_as_uint(vs.w) != vstamp) { derive_body(ps, q, vs, sp); vs.w = __uint_as_float(vstamp); }
+        float4 rp[kRounds];
+#pragma unroll
+        for (int j = 0; j < kRounds; ++j) {
+            const uint32_t l = tid + (uint32_t)j * NT;
+            rp[j] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+            if (l < nb) {
+                const uint32_t gid = s_gid[l];
+                float4 ps = B.pose[gid];
+                float4 vs = B.vel[gid];
+                if (vstamp) {   // derive-on-load: the first batch of the sweep to read a body applies its displacement, derives its velocity and stamps it
+                    const float4 q = B.prev[gid], dd = B.dpos[gid];   // (fetched beside the others: no load waits for the stamp)
+                    const float2 w = s_mass[l];
+                    if ((w.x > 0.0f || w.y > 0.0f) && __float_as_uint(vs.w) != vstamp) {
+                        apply_delta(ps, dd);
+                        derive_body(ps, q, vs, sp);
+                        vs.w = __uint_as_float(vstamp);
+                    }
+                }
+                rp[j] = ps;
+                s_vel[l] = vs;
             }
-            s_pose[l] = ps;
-            s_vel[l] = vs;
         }
         __syncthreads();
-        nxt.in_range = ncol > 0u && half < s_ce[0];
         const uint32_t ahead = take_ahead<NT>(ctr, flags);
         SFX_TT(tv1);
-        auto solve = [&](const SideSlot& p) {
-            float4 ps = s_pose[p.li], vs = s_vel[p.li];
+        auto solve = [&](const SideSlot& p) __attribute__((always_inline)) {
+            float4 vs = s_vel[p.li], S = s_sh[p.li];
             const float2 w = s_mass[p.li];
 #ifdef SFX_PROBE_NOSOLVE
-            vs.x += p.r.l[0][0] * 1e-30f;
+            vs.x += p.r.c[0] * 1e-30f;
             if (w.x > 0.0f) s_vel[p.li] = vs;
             return;
 #endif
-            const int ch = solve_vel_side(p.r, ps, vs, w, sp);
-            if (w.x > 0.0f || w.y > 0.0f) { s_vel[p.li] = vs; if (ch & 2) s_pose[p.li] = ps; }
-            if ((ch & 2) && side == 0u) s_shift = 1u;
+            const int ch = solve_vel_side(p.r, vs, S, w, sp);
+            if (w.x > 0.0f || w.y > 0.0f) { s_vel[p.li] = vs; if (ch & 2) s_sh[p.li] = S; }
         };
-        for (uint32_t c = 0; c < ncol; ++c) {
-            SideSlot cur;
-            decode_side<true>(nxt, side, cur, nb);
-            const uint32_t k0 = s_cs[c] + half, ce = s_ce[c];
-            {
-                const uint32_t c1 = min(c + 1u, (uint32_t)SFX_MAX_COLORS - 1u);
-                fetch_side<true>(T, C, start + s_cs[c1] + half, side, c + 1u < ncol && s_cs[c1] + half < s_ce[c1], nxt);
+        for (uint32_t s0 = 0; s0 < ns; s0 += (uint32_t)kDepth) {
+#pragma unroll
+            for (int u = 0; u < kDepth; ++u) {
+                const uint32_t sidx = s0 + (uint32_t)u;
+                if (sidx < ns) {
+                    const uint32_t st = s_step[sidx];
+                    SideSlot cur;
+                    decode_side<true>(q[u], side, cur, nb);
+                    {
+                        const uint32_t nx = sidx + (uint32_t)kDepth;
+                        const uint32_t st2 = s_step[min(nx, kMaxSteps - 1u)];
+                        const uint32_t k2 = (st2 & 0xFFFFu) + half;
+                        fetch_side<true>(T, C, start + k2, side, nx < ns && k2 < (st2 >> 16), q[u]);
+                    }
+                    if (cur.valid) solve(cur);
+                    if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) lds_barrier();
+                }
             }
-            if (cur.valid) solve(cur);
-            for (uint32_t k = k0 + NT / 2; k < ce; k += NT / 2) {
-                SideSlot more;
-                fetch_side_now<true>(T, C, start + k, side, more, nb);
-                if (more.valid) solve(more);
-            }
-            lds_barrier();
         }
         __syncthreads();
         if (tid == NT - 64) s_next = ahead;
         SFX_TT(tv2);
-        const bool shifted = s_shift != 0u;
-        if (nph > 1u) {  // fused phases: later batches of this launch read these records
-            for (uint32_t l = tid; l < nb; l += NT) {
+        // write-back by the lanes that loaded: velocity, and the pose when it changed here (the displacement applied on load,
+        // a static-friction shift).  Fused phases: later batches of this launch read these records (write-through stores)
+#pragma unroll
+        for (int j = 0; j < kRounds; ++j) {
+            const uint32_t l = tid + (uint32_t)j * NT;
+            if (l < nb) {
                 const float2 w = s_mass[l];
                 if (w.x > 0.0f || w.y > 0.0f) {
-                    store_record16<true>(B.vel, vel_rs, s_gid[l], s_vel[l]);
-                    if (shifted) store_record16<true>(B.pose, pose_rs, s_gid[l], s_pose[l]);
+                    const float4 S = s_sh[l];
+                    const bool shifted = S.x != 0.0f || S.y != 0.0f || S.z != 0.0f;
+                    float4 ps = rp[j];
+                    if (shifted) apply_delta(ps, S);
+                    if (nph > 1u) {
+                        store_record16<true>(B.vel, vel_rs, s_gid[l], s_vel[l]);
+                        if (shifted || vstamp) store_record16<true>(B.pose, pose_rs, s_gid[l], ps);
+                    } else {
+                        B.vel[s_gid[l]] = s_vel[l];
+                        if (shifted || vstamp) B.pose[s_gid[l]] = ps;
+                    }
                 }
             }
-            if (ph + 1u < ph0 + nph) publish_batch(T, g, ph, it, epoch);
-            else __syncthreads();
-        } else {
-            for (uint32_t l = tid; l < nb; l += NT) {
-                const float2 w = s_mass[l];
-                if (w.x > 0.0f || w.y > 0.0f) {
-                    B.vel[s_gid[l]] = s_vel[l];
-                    if (shifted) B.pose[s_gid[l]] = s_pose[l];
-                }
-            }
-            __syncthreads();
         }
+        if (nph > 1u && ph + 1u < ph0 + nph) publish_batch(T, g, ph, it, epoch);
+        else __syncthreads();
         SFX_TT(tv3);
         SFX_TT_ADD(8, tv0, tvw); SFX_TT_ADD(9, tvw, tv1); SFX_TT_ADD(10, tv1, tv2); SFX_TT_ADD(11, tv2, tv3);
         SFX_TT_ADD(12, tv0, tv3); SFX_TT_ADD(13, 0ull, 1ull); SFX_TT_MAX(14, tvw, tv3);
@@ -2120,9 +2248,9 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
 // phases.  Results are bit-identical to the multi-launch path (tests/test_gpu_parity.py).  The manifold records still
 // go through the contact arrays in global memory (written and read by this one workgroup: visible after a barrier).
 // The joint and fallback functions take a BodyArrays view whose state pointers are the LDS arrays (generic pointers).
-constexpr uint32_t kSmallBodies = 2048;    // LDS: 56 bytes of state per body
+constexpr uint32_t kSmallBodies = 2048;    // LDS: 72 bytes of state per body
 constexpr int kSmallThreads = 512;
-constexpr uint32_t kSmallBatches = 64;     // batches of all phases together whose colour runs are tabulated in LDS
+constexpr uint32_t kSmallBatches = 32;     // batches of all phases together whose colour runs are tabulated in LDS
 
 // The batches of one phase do not interact, so the workgroup solves colour c of ALL of them in one step (the launches
 // above give each batch a workgroup of its own).  Per phase and colour the runs of the phase's batches are laid end to
@@ -2146,7 +2274,7 @@ struct SmallJoints {
 // the next colour's record in flight while this one is solved)
 template <bool VEL>
 __device__ __forceinline__ void small_batch(const BatchDesc& d, const TileArrays& T, const ContactArrays& C, const BodyArrays& B,
-                                            float4* s_pose, float4* s_vel, const float2* s_mass, uint32_t* s_cs, uint32_t* s_ce,
+                                            float4* s_d, float4* s_vel, const float2* s_mass, uint32_t* s_cs, uint32_t* s_ce,
                                             const StepParams& sp) {
     constexpr uint32_t NT = kSmallThreads;
     const uint32_t tid = threadIdx.x, side = tid & 1u, half = tid >> 1;
@@ -2160,21 +2288,21 @@ __device__ __forceinline__ void small_batch(const BatchDesc& d, const TileArrays
     }
     __syncthreads();
     nxt.in_range = ncol > 0u && half < s_ce[0];
-    auto solve = [&](uint32_t k, const RawSide& q) {
+    auto solve = [&](uint32_t k, const RawSide& q) __attribute__((always_inline)) {
         SideSlot p;
         decode_side<VEL>(q, side, p, 0xFFFFFFFFu);   // no local-index limit: the state is addressed by body id
         if (!VEL && side == 0u && q.in_range && !p.valid) C.lam[start + k] = make_float2(0.0f, 0.0f);
         if (!p.valid) return;
-        const uint32_t bi = body_of(B, side ? q.pr.y : q.pr.x);
-        float4 ps = s_pose[bi];
+        const uint32_t bi = body_of(B, side ? +q.pr.y : +q.pr.x);
+        float4 D = s_d[bi];   // position pass: the displacement; velocity pass: the static-friction shift of this phase
         const float2 w = s_mass[bi];
         if constexpr (VEL) {
             float4 vs = s_vel[bi];
-            const int ch = solve_vel_side(p.r, ps, vs, w, sp);
-            if (w.x > 0.0f || w.y > 0.0f) { s_vel[bi] = vs; if (ch & 2) s_pose[bi] = ps; }
+            const int ch = solve_vel_side(p.r, vs, D, w, sp);
+            if (w.x > 0.0f || w.y > 0.0f) { s_vel[bi] = vs; if (ch & 2) s_d[bi] = D; }
         } else {
-            if (solve_pos_side(p.r, ps, w, sp.max_corr)) {
-                if (w.x > 0.0f || w.y > 0.0f) s_pose[bi] = ps;
+            if (solve_pos_side(p.r, D, w, sp.max_corr)) {
+                if (w.x > 0.0f || w.y > 0.0f) s_d[bi] = D;
             }
             if (side == 0u) C.lam[start + k] = make_float2(p.r.l0, p.r.l1);
         }
@@ -2200,14 +2328,14 @@ __device__ __forceinline__ void small_batch(const BatchDesc& d, const TileArrays
 // in flight while this one is solved)
 template <bool VEL>
 __device__ __forceinline__ void small_phase(uint32_t ph, const SmallTables& S, const TileArrays& T, const ContactArrays& C,
-                                            const BodyArrays& B, float4* s_pose, float4* s_vel, const float2* s_mass,
+                                            const BodyArrays& B, float4* s_d, float4* s_vel, const float2* s_mass,
                                             const StepParams& sp) {
     constexpr uint32_t NT = kSmallThreads;
     const uint32_t tid = threadIdx.x, side = tid & 1u, half = tid >> 1;
     const uint32_t b0 = S.pb0[ph], nbat = S.pb0[ph + 1] - b0, base = b0 + ph, ncol = S.pncol[ph];
     if (nbat == 0u) return;
     // record slot of the h-th pair of colour c over the phase's batches (false past the end)
-    auto locate = [&](uint32_t c, uint32_t h, uint32_t& slot) -> bool {
+    auto locate = [&](uint32_t c, uint32_t h, uint32_t& slot) __attribute__((always_inline)) -> bool {
         const uint16_t* row = &S.pre[c][base];
         slot = 0u;
         if (h >= row[nbat]) return false;
@@ -2219,21 +2347,21 @@ __device__ __forceinline__ void small_phase(uint32_t ph, const SmallTables& S, c
         slot = S.bstart[b0 + lo] + S.first[c][b0 + lo] + (h - row[lo]);
         return true;
     };
-    auto solve = [&](uint32_t slot, const RawSide& q) {
+    auto solve = [&](uint32_t slot, const RawSide& q) __attribute__((always_inline)) {
         SideSlot p;
         decode_side<VEL>(q, side, p, 0xFFFFFFFFu);   // no local-index limit: the state is addressed by body id
         if (!VEL && side == 0u && q.in_range && !p.valid) C.lam[slot] = make_float2(0.0f, 0.0f);
         if (!p.valid) return;
-        const uint32_t bi = body_of(B, side ? q.pr.y : q.pr.x);
-        float4 ps = s_pose[bi];
+        const uint32_t bi = body_of(B, side ? +q.pr.y : +q.pr.x);
+        float4 D = s_d[bi];   // position pass: the displacement; velocity pass: the static-friction shift of this phase
         const float2 w = s_mass[bi];
         if constexpr (VEL) {
             float4 vs = s_vel[bi];
-            const int ch = solve_vel_side(p.r, ps, vs, w, sp);
-            if (w.x > 0.0f || w.y > 0.0f) { s_vel[bi] = vs; if (ch & 2) s_pose[bi] = ps; }
+            const int ch = solve_vel_side(p.r, vs, D, w, sp);
+            if (w.x > 0.0f || w.y > 0.0f) { s_vel[bi] = vs; if (ch & 2) s_d[bi] = D; }
         } else {
-            if (solve_pos_side(p.r, ps, w, sp.max_corr)) {
-                if (w.x > 0.0f || w.y > 0.0f) s_pose[bi] = ps;
+            if (solve_pos_side(p.r, D, w, sp.max_corr)) {
+                if (w.x > 0.0f || w.y > 0.0f) s_d[bi] = D;
             }
             if (side == 0u) C.lam[slot] = make_float2(p.r.l0, p.r.l1);
         }
@@ -2273,6 +2401,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_substeps(uint32_t nsub,
     __shared__ float4 s_pose[kSmallBodies];
     __shared__ float4 s_prev[kSmallBodies];
     __shared__ float4 s_vel[kSmallBodies];
+    __shared__ float4 s_d[kSmallBodies];    // position pass: displacements since the narrowphase; velocity pass: the phase's static-friction shifts
     __shared__ float2 s_mass[kSmallBodies];
     __shared__ uint32_t s_cs[SFX_MAX_COLORS], s_ce[SFX_MAX_COLORS];
     const uint32_t tid = threadIdx.x;
@@ -2282,7 +2411,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_substeps(uint32_t nsub,
         s_pose[i] = B.pose[i]; s_vel[i] = B.vel[i]; s_mass[i] = B.mass[i];
     }
     BodyArrays L = B;   // the same world with its state in LDS: what solve_joint, damp_joint and the fallback solves take
-    L.pose = s_pose; L.prev = s_prev; L.vel = s_vel; L.mass = s_mass;
+    L.pose = s_pose; L.prev = s_prev; L.vel = s_vel; L.mass = s_mass; L.dpos = s_d;
     const uint32_t ntp = min(ctr->tp_cursor, T.max_pairs);
     const uint32_t nfb = min(ctr->n_fb, T.fb_cap) ? ctr->fb_start[SFX_MAX_COLORS] : 0u;
     if (tid == 0) {
@@ -2326,7 +2455,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_substeps(uint32_t nsub,
         for (uint32_t i = tid; i < nb; i += NT) {
             float4 p = s_pose[i], q, v = s_vel[i];
             integrate_body(p, q, v, s_mass[i], sp);
-            s_pose[i] = p; s_prev[i] = q; s_vel[i] = v;
+            s_pose[i] = p; s_prev[i] = q; s_vel[i] = v; s_d[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         __syncthreads();
         for (uint32_t jc = 0; jc < SJ.ncolors; ++jc) {
@@ -2350,28 +2479,31 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_substeps(uint32_t nsub,
             const uint32_t ba = body_of(B, a), bb = body_of(B, b);
             PairRec r;
             const float4 pa = s_pose[ba], pb = s_pose[bb], sa = B.shape[a], sb = B.shape[b];
-            prepare_pair(pa, sa, s_vel[ba], pb, sb, s_vel[bb], shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, r);
+            prepare_pair(pa, sa, s_vel[ba], s_mass[ba], pb, sb, s_vel[bb], s_mass[bb], shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, sp.vthr, r);
             store_record(C, slot, r);
         }
         __syncthreads();   // (a workgroup barrier orders this workgroup's global stores and loads as well)
         SFX_TT(ts2);
         SFX_TT_ADD(66, ts1, ts2);
         for (uint32_t ph = 0; ph < nph; ++ph) {
-            if (tabled) { small_phase<false>(ph, S, T, C, B, s_pose, s_vel, s_mass, sp); continue; }
+            if (tabled) { small_phase<false>(ph, S, T, C, B, s_d, s_vel, s_mass, sp); continue; }
             const uint32_t nbat = S.pb0[ph + 1] - S.pb0[ph];
             for (uint32_t it = 0; it < nbat; ++it)
-                small_batch<false>(T.batches[ph * g.pstride + it], T, C, B, s_pose, s_vel, s_mass, s_cs, s_ce, sp);
+                small_batch<false>(T.batches[ph * g.pstride + it], T, C, B, s_d, s_vel, s_mass, s_cs, s_ce, sp);
         }
         __syncthreads();
         SFX_TT(ts3);
         SFX_TT_ADD(67, ts2, ts3);
         fallback_pos(T, ctr, L, C, sp.max_corr);
-        for (uint32_t i = tid; i < nb; i += NT) {
+        for (uint32_t i = tid; i < nb; i += NT) {   // the displacements applied, once per body, and the velocities derived
             const float2 w = s_mass[i];
+            const float4 dd = s_d[i];
+            s_d[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // from here on: the static-friction shifts of a velocity phase
             if (!(w.x > 0.0f || w.y > 0.0f)) continue;
-            float4 v = s_vel[i];
-            derive_body(s_pose[i], s_prev[i], v, sp);
-            s_vel[i] = v;
+            float4 v = s_vel[i], p = s_pose[i];
+            apply_delta(p, dd);
+            derive_body(p, s_prev[i], v, sp);
+            s_pose[i] = p; s_vel[i] = v;
         }
         __syncthreads();   // also: the multipliers the position pass stored are visible to the velocity pass
         SFX_TT(ts4);
@@ -2381,10 +2513,24 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_substeps(uint32_t nsub,
             __syncthreads();
         }
         for (uint32_t ph = 0; ph < nph; ++ph) {
-            if (tabled) { small_phase<true>(ph, S, T, C, B, s_pose, s_vel, s_mass, sp); continue; }
-            const uint32_t nbat = S.pb0[ph + 1] - S.pb0[ph];
-            for (uint32_t it = 0; it < nbat; ++it)
-                small_batch<true>(T.batches[ph * g.pstride + it], T, C, B, s_pose, s_vel, s_mass, s_cs, s_ce, sp);
+            if (tabled) small_phase<true>(ph, S, T, C, B, s_d, s_vel, s_mass, sp);
+            else {
+                const uint32_t nbat = S.pb0[ph + 1] - S.pb0[ph];
+                for (uint32_t it = 0; it < nbat; ++it)
+                    small_batch<true>(T.batches[ph * g.pstride + it], T, C, B, s_d, s_vel, s_mass, s_cs, s_ce, sp);
+            }
+            __syncthreads();
+            for (uint32_t i = tid; i < nb; i += NT) {   // end of the phase: its static-friction shifts, once per body
+                const float4 S4 = s_d[i];
+                if (S4.x == 0.0f && S4.y == 0.0f && S4.z == 0.0f) continue;
+                const float2 w = s_mass[i];
+                s_d[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (!(w.x > 0.0f || w.y > 0.0f)) continue;
+                float4 p = s_pose[i];
+                apply_delta(p, S4);
+                s_pose[i] = p;
+            }
+            __syncthreads();
         }
         __syncthreads();
         SFX_TT(ts5);
@@ -2489,7 +2635,7 @@ __global__ __launch_bounds__(kBlock) void k_stats_pairs(const Counters* __restri
         Manifold m;
         manifold(shape_pose(B.pose[a], B.shape[a], B.lpose, a), B.shape[a], shape_pose(B.pose[b], B.shape[b], B.lpose, b), B.shape[b], B.poly, sm, m);
         for (int q = 0; q < m.count; ++q) md = fmaxf(md, m.depth[q]);
-        const uint32_t cnt = __float_as_uint(C.rec[4u * (size_t)slot + 3u].y);
+        const uint32_t cnt = rec_count(rec_plane(C, kPlA)[slot]);
         if (cnt) {
             mf += 1u;
             mf2 += (cnt == 2) ? 1u : 0u;

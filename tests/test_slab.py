@@ -68,7 +68,7 @@ def test_free_fall_is_bit_identical_to_the_undecomposed_world():
     for _ in range(3):
         L.step(DT)
         W.step(DT)
-    assert W.stats().n_manifolds == 0
+    assert W.stats().n_contacts == 0   # (pairs within the speculative margin have manifolds, nothing pushes)
     pos, rot, vel, ang = L.gather()
     assert np.array_equal(pos.view(np.uint32), W.poses()[0].view(np.uint32))
     assert np.array_equal(vel.view(np.uint32), W.velocities()[0].view(np.uint32))
