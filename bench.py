@@ -76,19 +76,21 @@ def penetration_mm(w):
 def kernel_bytes(st, derive_bodies=0):
     """Algorithmic (compulsory) bytes of ONE launch of each contact-sweep kernel (one launch per substep),
     from the tick's measured counts.  DESIGN.md "Kernels": P = solver pairs, M = touching pairs (manifolds),
-    M2 = of which with two points.
-      k_narrow   : P x (16 order (ids + slot) + 2 x (16 pose + 16 shape) read, 8 count written)
-                   + M x (2 x 16 velocity read; 16 normal/friction + 16 anchors + 8 lambda + 8 pre-velocity written) + M2 x 16
-      k_tile_pos : P x (16 pair + 8 count read) + M x (32 record + 2 x (16 pose + 8 mass) read; 8 lambda + 2 x 16 pose written) + M2 x 16
-      k_tile_vel : P x (16 + 8 read) + M x (48 record + 2 x (16 pose + 16 velocity + 8 mass) read; 2 x 16 velocity written) + M2 x 16
-                   + derive_bodies x 16: inside sfx_step the kernel also derives the velocities (DESIGN.md "Velocities derived where
-                   they are first read"): the start-of-substep pose of every dynamic body, read once; pose, mass and the
-                   velocity written are in the pair terms already"""
+    M2 = of which with two points; record planes A..G are 16 bytes each (sfx_device.h ContactArrays).
+      k_narrow   : P x (16 order (ids + slot) + 2 x (16 pose + 16 shape) read, 16 plane A written)
+                   + M x (2 x (16 velocity + 8 mass) read; planes B, C, D = 48 written) + M2 x 48 (planes E, F, G)
+      k_tile_pos : P x (4 pair indices + 16 plane A read) + M x (16 plane B + 2 x (16 displacement + 8 mass) read;
+                   8 lambda + 2 x 16 displacement written) + M2 x 48
+      k_tile_vel : P x (4 + 16 + 8 lambda read) + M x (planes B, C, D = 48 + 2 x (16 velocity + 8 mass) read;
+                   2 x 16 velocity written) + M2 x 48
+                   + derive_bodies x 64: inside sfx_step the kernel also applies the position sweep's displacement and
+                   derives the velocities (DESIGN.md "Velocities derived where they are first read"): pose, start-of-substep
+                   pose and displacement of every dynamic body read once, its pose written once"""
     P, M, M2 = float(st.n_solver_pairs), float(st.n_manifolds), float(st.n_manifolds2)
     return {
-        "narrow": P * 88.0 + M * 80.0 + M2 * 16.0,
-        "solve_pos": P * 24.0 + M * 120.0 + M2 * 16.0,
-        "solve_vel": P * 24.0 + M * 160.0 + M2 * 16.0 + 16.0 * derive_bodies,
+        "narrow": P * 96.0 + M * 96.0 + M2 * 48.0,
+        "solve_pos": P * 20.0 + M * 104.0 + M2 * 48.0,
+        "solve_vel": P * 28.0 + M * 128.0 + M2 * 48.0 + 64.0 * derive_bodies,
     }
 
 
@@ -101,12 +103,43 @@ KERNEL_NAMES = {
 
 def tick_bytes_per_body_substep(st, n_dyn, substeps):
     """SURVEY.md 8d accounting for the whole tick, from measured pair / contact counts."""
-    kb = kernel_bytes(st)
-    integrate = 16 + 16 + 8 + 16 + 16 + 16          # pose, vel, mass read; prev, pose, vel written
-    derive = 16 + 16 + 8 + 16
+    kb = kernel_bytes(st, n_dyn)
+    integrate = 16 + 16 + 8 + 16 + 16 + 16 + 16     # pose, vel, mass read; prev, pose, vel, zero displacement written
+    derive = 0                                      # applied and derived where the velocity solve loads a body: in kernel_bytes
     p = st.n_pairs / n_dyn
     broad = (16 + 16 + 16 + 16 + 4 + 8 + 4 + 4 + 28 + 16 * 5 + p * (8 + 8 + 2 + 16 + 16)) / substeps
     return integrate + derive + sum(kb.values()) / n_dyn + broad
+
+
+def survey_scene_leg(device, bodies, steps, warmup, settle_frames=1500):
+    """SURVEY.md 8d's own lattice for the headline config -- 400 wide (250 rows: a pile twice as deep as the bench scene's,
+    about 55 layers) -- settled and timed the same way, reported beside the headline as config.survey_scene (VERDICT r2
+    item 4).  Deeper piles compress more under XPBD at 4 substeps (DESIGN.md "Deep piles") and need 2-D tiles."""
+    from starframe_amd import scenes
+    from starframe_amd.world import World
+
+    sc = scenes.mixed_pile(n=bodies, width=400)
+    sc = settle(sc, device, frames=settle_frames)
+    w = World.from_scene(sc, device=device)
+    for _ in range(warmup):
+        w.step(DT)
+    w.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        w.step(DT)
+    w.sync()
+    el = time.perf_counter() - t0
+    st = w.stats()
+    pen = penetration_mm(w)
+    vel, _ = w.velocities()
+    dyn = np.asarray(sc.inv_mass) > 0
+    pos, _ = w.poses()
+    w.close()
+    return {"scene": f"lattice 400 wide x {bodies // 400} rows, pitch 0.30 m, settled {settle_frames} damped ticks",
+            "value": sc.n_dynamic() * sc.substeps * steps / el, "unit": "body-substeps/s", "ms_per_step": 1e3 * el / steps,
+            "steps": steps, "warmup": warmup, "pairs": st.n_pairs, "manifolds": st.n_manifolds, "colors": st.n_colors,
+            "tiles": st.n_tiles, "pile_height_m": round(float(pos[dyn, 1].max()), 2),
+            "v_rms": round(float(np.sqrt((vel[dyn] ** 2).sum(1).mean())), 4), "penetration_mm": pen}
 
 
 def cpu_baseline(scene, budget_s=15.0):
@@ -266,6 +299,8 @@ def main():
     ap.add_argument("--no-single-reference", dest="single_reference", action="store_false",
                     help="N > 1: skip rank 0's one-GPU run of its share of the slab (reported as scaling_reference)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-survey-scene", action="store_true",
+                    help="N = 1: skip the second, untimed-for-value leg on SURVEY.md 8d's 400-wide lattice (config.survey_scene)")
     ap.add_argument("--settle-frames", type=int, default=600)
     ap.add_argument("--live-events", default="solve_vel",
                     help="comma-separated kernel classes bracketed with HIP events INSIDE the timed region (the roofline's "
@@ -424,6 +459,10 @@ def main():
     w.set_profiling(False)
     st2 = w.stats()
     pen = penetration_mm(w) if slab is None else None   # after everything timed: it runs a broadphase of its own
+    v_rms = None
+    if slab is None:   # how much the "settled" pile still moves (DESIGN.md "Jitter"): root mean square speed of the dynamic bodies
+        vv, _ = w.velocities()
+        v_rms = round(float(np.sqrt((vv[np.asarray(scene.inv_mass) > 0] ** 2).sum(1).mean())), 4)
     derive_bodies = scene.n_dynamic() if slab is None else 0   # sfx_step derives on load; the slab driver steps substep by substep
     kb = kernel_bytes(st2, derive_bodies)
     per_kernel = {}
@@ -475,6 +514,7 @@ def main():
                          f"{scene.substeps} substeps, dt=1/60 (BASELINE.json configs[4] at {args.slab_bodies} bodies per GPU: 4 M at 8 GPUs)"),
             "scene": scene_note,
             "penetration_mm": pen,
+            "v_rms": v_rms,
             "bodies_per_gpu": n_rank,
             "substeps": scene.substeps,
             "parallelism": parallelism,
@@ -517,6 +557,8 @@ def main():
     if dist is not None:
         dist.barrier()
     w.close()
+    if slab is None and not args.no_survey_scene and args.bodies == 100_000 and args.width != 400:
+        out["config"]["survey_scene"] = survey_scene_leg(device, args.bodies, args.steps, args.warmup)
     if rank == 0 and world == 1 and not args.no_cpu:
         out["cpu_baseline"] = cpu_baseline(scene)
     sys.stdout.flush()

@@ -108,6 +108,14 @@ def run(n, width, settle, frames, name, openmp=True):
     for lo in np.arange(0.0, 1.0, 0.2):
         m = (ymid >= lo * top) & (ymid < (lo + 0.2) * top) & ~stat
         print(f"    {lo:.1f}-{lo + 0.2:.1f}: {pct(dmax[m])}")
+    # force chains: within one height band the contact depths (= loads: a contact carries its load by its depth) of a random
+    # packing are spread like the contact forces of a granular pile -- roughly exponentially about their mean
+    band = (ymid < 0.2 * top) & ~stat
+    if band.sum() > 100:
+        x = dmax[band] / dmax[band].mean()
+        print("  bottom fifth, depth / mean depth: fraction above 1, 2, 3, 4, 6 x mean: "
+              + ", ".join(f"{(x > k).mean():.4f}" for k in (1, 2, 3, 4, 6))
+              + "   (exponential: " + ", ".join(f"{np.exp(-k):.4f}" for k in (1, 2, 3, 4, 6)) + f"); mean {1e3 * dmax[band].mean():.2f} mm")
     sp = np.sqrt((vel ** 2).sum(1))
     print("  speed by body type: " + ", ".join(f"{NAMES[t]} v_rms {np.sqrt((sp[dyn & (types == t)] ** 2).mean()):.4f} "
                                               f"w_rms {np.sqrt((om[dyn & (types == t)] ** 2).mean()):.3f}" for t in (1, 2, 3)))

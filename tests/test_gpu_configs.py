@@ -118,6 +118,13 @@ def test_mixed_pile_100k_one_tick_from_the_settled_state():
     check_one_tick(s, min_pairs=300_000, min_manifolds=200_000)
 
 
+def test_mixed_pile_100k_w400_one_tick_from_the_settled_state():
+    """SURVEY.md 8d's own lattice for configs[2] (400 wide, 250 rows: the pile bench.py reports as config.survey_scene,
+    about 55 layers deep, 2-D tiles with all four pair classes): settled on the GPU, one tick on both sides."""
+    s = settle_on_gpu(scenes.mixed_pile(width=400), 1500)
+    check_one_tick(s, min_pairs=300_000, min_manifolds=200_000)
+
+
 def test_circles_10k_one_tick_lattice_and_settled():
     """configs[1]: 10 k circles in the container."""
     s = scenes.circles_container()

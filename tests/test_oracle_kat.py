@@ -367,6 +367,51 @@ def test_settled_pile_penetration_is_bounded():
     assert pos[:2000, 1].min() > 0.0 and np.isfinite(pos).all()
 
 
+def test_released_pile_stays_quiet_and_its_depth_tail_is_that_of_force_chains():
+    """The bench times an UNDAMPED pile: 3000 mixed bodies (60 lattice rows, about 14 layers) settled
+    with damping, then released for 300 frames.  What the solver's contract promises of such a pile (DESIGN.md "Jitter and
+    the depth tail", measured on 20 k and 100 k piles with scripts/jitter_study.py):
+      - it stays where it is and what motion is left decays: one Gauss-Seidel sweep per substep leaves a residual of a few
+        per cent of the corrections a loaded contact receives (k g h^2 per body above it), so the pile hums at centimetres
+        per second instead of resting, most where the load is highest -- it must not grow;
+      - the contact depths -- a contact carries its load by its depth -- are spread within one height band like the
+        contact forces of a granular packing, about exponentially around their mean (force chains): the p99 is a few
+        times the median and the maximum an order of magnitude above it, without any contact being defective."""
+    from starframe_amd import scenes
+
+    s = scenes.mixed_pile(n=3000, width=50)
+    dyn = s.inv_mass > 0
+    w = OracleWorld.from_scene(s, linear_damping=3.3, angular_damping=1.0)
+    for _ in range(600):
+        w.step(DT, ORDER_COLORED)
+    pos, rot = w.poses()
+    w.close()
+    w = OracleWorld.from_scene(s.with_state(pos, rot))
+    top0, mean0 = pos[dyn, 1].max(), float(pos[dyn, 1].mean())
+    rms = {}
+    for f in range(1, 301):
+        w.step(DT, ORDER_COLORED)
+        if f in (100, 300):
+            v = w.velocities()[0][dyn]
+            rms[f] = float(np.sqrt((v ** 2).sum(1).mean()))
+    pos, _ = w.poses()
+    w.broadphase(DT)
+    c = w.contacts()
+    c = c[c["count"] > 0]
+    deep = np.maximum(c["depth"][:, 0], np.where(c["count"] > 1, c["depth"][:, 1], -1.0))
+    ymid = 0.5 * (pos[c["body_a"], 1] + pos[c["body_b"], 1])
+    d = deep[deep > 0]
+    p50, p99 = np.percentile(d, [50, 99])
+    assert np.isfinite(pos).all() and abs(float(pos[dyn, 1].mean()) - mean0) < 0.02   # the pile stands where it stood (centre of mass)
+    assert rms[300] < 0.08 and rms[300] < 1.2 * rms[100], rms                       # it hums, it does not grow
+    assert p50 < 0.004 and p99 < 0.025 and d.max() < 0.060, (p50, p99, d.max())     # metres; bodies are 60-200 mm across
+    band = (deep > 0) & (ymid < 0.2 * top0)                                          # the bottom fifth: one load level
+    x = deep[band] / deep[band].mean()
+    assert band.sum() > 500
+    for k, lo, hi in ((1.0, 0.25, 0.50), (2.0, 0.07, 0.22), (4.0, 0.0, 0.04)):        # exponential: 0.37, 0.135, 0.018
+        assert lo <= (x > k).mean() <= hi, (k, (x > k).mean())
+
+
 def test_unclamped_drop_does_not_explode():
     """1500 mixed bodies dropped undamped from up to 15 m: they land at 17 m/s, 70 mm per substep -- body-sized
     overlaps that the position solve corrects in one go (no depenetration clamp).  Round 1 clamped the correction
