@@ -416,8 +416,10 @@ def main():
         w = World.from_scene(scene, device=device)
         step = lambda: w.step(DT)
 
+    sync = slab.sync if slab is not None else w.sync   # (slabs: the ranks also agree that none of them has failed)
+
     def barrier():
-        w.sync()
+        sync()
         if dist is not None:
             dist.barrier()
 
@@ -436,7 +438,7 @@ def main():
         elif live and i % every == 1:
             w.set_profiling_classes(["stats"])     # a class no tick kernel belongs to = paused (0 would collect and synchronise)
         step()
-    w.sync()
+    sync()
     elapsed = time.perf_counter() - t0
     kt_live = w.kernel_times(reset=True) if live else {}
     w.set_profiling(False)

@@ -279,6 +279,7 @@ extern "C" {
     pub fn sfx_rccl_unique_id(id: *mut u8) -> c_int;
     pub fn sfx_rccl_comm_create(id: *const u8, rank: c_int, nranks: c_int, device: c_int, out: *mut *mut sfx_rccl_comm) -> c_int;
     pub fn sfx_rccl_comm_destroy(c: *mut sfx_rccl_comm);
+    pub fn sfx_rccl_comm_abort(c: *mut sfx_rccl_comm);
     pub fn sfx_rccl_halo_exchange(c: *mut sfx_rccl_comm, w: *mut sfx_world, left: c_int, right: c_int, n_send_left: u32,
                                   n_send_right: u32, n_recv_left: u32, n_recv_right: u32) -> c_int;
     pub fn sfx_rccl_sendrecv(c: *mut sfx_rccl_comm, hip_stream: *mut c_void, send_dev: *const f32, n_send: usize, to: c_int,

@@ -33,13 +33,21 @@ typedef struct sfx_rccl_comm sfx_rccl_comm;
 int sfx_rccl_unique_id(unsigned char id[SFX_RCCL_ID_BYTES]);
 int sfx_rccl_comm_create(const unsigned char id[SFX_RCCL_ID_BYTES], int rank, int nranks, int device, sfx_rccl_comm** out);
 void sfx_rccl_comm_destroy(sfx_rccl_comm* c); /* NULL is a no-op */
+/* For a rank that has FAILED (a capacity overflow, a stale halo, a device error) while its peers may still be inside
+ * a halo exchange: ends the communicator without waiting for them (ncclCommAbort) and frees it.  The peers' pending
+ * operations then fail instead of waiting for ever; the host ends the run (tools/sfx_slab_run.cpp kills the other
+ * ranks on the first bad exit). */
+void sfx_rccl_comm_abort(sfx_rccl_comm* c);
 
 /* One substep's exchange, enqueued on the world's stream (nothing synchronises, nothing is allocated):
  *   sfx_halo_pack(w); group { send left block -> `left`, send right block -> `right`, recv ghosts from `left`,
  *   recv ghosts from `right` }; sfx_halo_unpack(w).
  * left / right: neighbour ranks, -1 for none.  Counts are bodies (8 floats each) and must add up to what
  * sfx_halo_set was given: n_send_left + n_send_right = n_send, n_recv_left + n_recv_right = n_recv.  A rank may
- * name itself as a neighbour (send to self: used by the single-GPU tests). */
+ * name itself as a neighbour (send to self: used by the single-GPU tests); ANOTHER rank as both neighbours (a ring of
+ * two slabs) is refused with SFX_ERR_UNSUPPORTED: its two blocks would pair up in issue order, the wrong way round.
+ * The world must run on the communicator's device (SFX_ERR_INVALID otherwise).  A failing ncclSend / ncclRecv never
+ * leaves the group open: the first error is returned after ncclGroupEnd. */
 int sfx_rccl_halo_exchange(sfx_rccl_comm* c, sfx_world* w, int left, int right, uint32_t n_send_left,
                            uint32_t n_send_right, uint32_t n_recv_left, uint32_t n_recv_right);
 

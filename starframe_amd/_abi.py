@@ -313,7 +313,7 @@ def load_libsfx(path=None):
 
 # ---- libsfx_rccl.so (include/sfx_rccl.h): the slab halo exchange over plain RCCL
 LIBSFX_RCCL_PATH = os.path.join(HERE, "csrc", "libsfx_rccl.so")
-SFX_RCCL_SYMBOLS = ["sfx_rccl_unique_id", "sfx_rccl_comm_create", "sfx_rccl_comm_destroy", "sfx_rccl_halo_exchange", "sfx_rccl_sendrecv",
+SFX_RCCL_SYMBOLS = ["sfx_rccl_unique_id", "sfx_rccl_comm_create", "sfx_rccl_comm_destroy", "sfx_rccl_comm_abort", "sfx_rccl_halo_exchange", "sfx_rccl_sendrecv",
                     "sfx_rccl_allreduce_stats", "sfx_rccl_last_error"]
 RCCL_ID_BYTES = 128
 _rccl = None
@@ -333,6 +333,8 @@ def load_libsfx_rccl():
     lib.sfx_rccl_comm_create.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     lib.sfx_rccl_comm_destroy.argtypes = [vp]
     lib.sfx_rccl_comm_destroy.restype = None
+    lib.sfx_rccl_comm_abort.argtypes = [vp]
+    lib.sfx_rccl_comm_abort.restype = None
     lib.sfx_rccl_halo_exchange.argtypes = [vp, vp, C.c_int, C.c_int, u32, u32, u32, u32]
     lib.sfx_rccl_sendrecv.argtypes = [vp, vp, vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int]
     lib.sfx_rccl_sendrecv.restype = C.c_int

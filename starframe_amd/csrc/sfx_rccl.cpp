@@ -82,6 +82,14 @@ int sfx_rccl_comm_create(const unsigned char id[SFX_RCCL_ID_BYTES], int rank, in
     return SFX_OK;
 }
 
+void sfx_rccl_comm_abort(sfx_rccl_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm) (void)ncclCommAbort(c->comm);   // does not wait for the peers: outstanding operations are dropped
+    if (c->stage) (void)hipFree(c->stage);
+    delete c;
+}
+
 void sfx_rccl_comm_destroy(sfx_rccl_comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -96,6 +104,10 @@ int sfx_rccl_halo_exchange(sfx_rccl_comm* c, sfx_world* w, int left, int right, 
     if ((left >= c->nranks) || (right >= c->nranks)) return fail(SFX_ERR_INVALID, "neighbour rank out of range");
     if (left < 0 && (n_send_left || n_recv_left)) return fail(SFX_ERR_INVALID, "left halo without a left neighbour");
     if (right < 0 && (n_send_right || n_recv_right)) return fail(SFX_ERR_INVALID, "right halo without a right neighbour");
+    // one peer as BOTH neighbours pairs the blocks up in issue order -- its left block would land where its right block
+    // belongs: only a rank that names ITSELF (the single-GPU self test) may do that
+    if (left >= 0 && left == right && left != c->rank)
+        return fail(SFX_ERR_UNSUPPORTED, "rank %d as both the left and the right neighbour (a ring of two slabs) is not supported", left);
     uint32_t n_send = 0, n_recv = 0;
     int rc = sfx_halo_counts(w, &n_send, &n_recv);
     if (rc) return fail(rc, "%s", sfx_last_error(w));
@@ -110,17 +122,27 @@ int sfx_rccl_halo_exchange(sfx_rccl_comm* c, sfx_world* w, int left, int right, 
     if (rc) return fail(rc, "%s", sfx_last_error(w));
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    {   // RCCL work must go on a stream of the communicator's device
+        hipDevice_t sd = 0;
+        if (st && hipStreamGetDevice(st, &sd) == hipSuccess && (int)sd != c->device)
+            return fail(SFX_ERR_INVALID, "the world runs on device %d, the communicator was made for device %d", (int)sd, c->device);
+    }
     // every message is a run of 8-float body records; the two directions of one neighbour pair are matched by the
     // order of the calls inside the group (sends and receives to / from one peer pair up in issue order)
     const size_t sl = 8 * (size_t)n_send_left, sr = 8 * (size_t)n_send_right, rl = 8 * (size_t)n_recv_left, rr = 8 * (size_t)n_recv_right;
     if (sl + sr + rl + rr) {
+        // an error inside the group must not leave it open (every later call on the communicator would queue into it):
+        // the first error is kept, ncclGroupEnd is always called
+        ncclResult_t first = ncclSuccess;
+        auto keep = [&](ncclResult_t r) { if (first == ncclSuccess && r != ncclSuccess) first = r; };
         NCCLCHK(ncclGroupStart());
-        if (left >= 0 && sl) NCCLCHK(ncclSend(send, sl, ncclFloat, left, c->comm, st));
-        if (right >= 0 && sr) NCCLCHK(ncclSend(send + sl, sr, ncclFloat, right, c->comm, st));
+        if (left >= 0 && sl) keep(ncclSend(send, sl, ncclFloat, left, c->comm, st));
+        if (right >= 0 && sr) keep(ncclSend(send + sl, sr, ncclFloat, right, c->comm, st));
         // what comes from the left neighbour is ITS right block, from the right neighbour its left block
-        if (left >= 0 && rl) NCCLCHK(ncclRecv(recv, rl, ncclFloat, left, c->comm, st));
-        if (right >= 0 && rr) NCCLCHK(ncclRecv(recv + rl, rr, ncclFloat, right, c->comm, st));
-        NCCLCHK(ncclGroupEnd());
+        if (left >= 0 && rl) keep(ncclRecv(recv, rl, ncclFloat, left, c->comm, st));
+        if (right >= 0 && rr) keep(ncclRecv(recv + rl, rr, ncclFloat, right, c->comm, st));
+        keep(ncclGroupEnd());
+        if (first != ncclSuccess) return fail(SFX_ERR_DEVICE, "halo exchange failed: %s", ncclGetErrorString(first));
     }
     rc = sfx_halo_unpack(w);
     if (rc) return fail(rc, "%s", sfx_last_error(w));
@@ -133,10 +155,13 @@ int sfx_rccl_sendrecv(sfx_rccl_comm* c, void* hip_stream, const float* send_dev,
     if (to >= c->nranks || from >= c->nranks) return fail(SFX_ERR_INVALID, "peer rank out of range");
     HIPCHK(hipSetDevice(c->device));
     hipStream_t st = reinterpret_cast<hipStream_t>(hip_stream);
+    ncclResult_t first = ncclSuccess;
+    auto keep = [&](ncclResult_t r) { if (first == ncclSuccess && r != ncclSuccess) first = r; };
     NCCLCHK(ncclGroupStart());
-    if (to >= 0 && n_send) NCCLCHK(ncclSend(send_dev, n_send, ncclFloat, to, c->comm, st));
-    if (from >= 0 && n_recv) NCCLCHK(ncclRecv(recv_dev, n_recv, ncclFloat, from, c->comm, st));
-    NCCLCHK(ncclGroupEnd());
+    if (to >= 0 && n_send) keep(ncclSend(send_dev, n_send, ncclFloat, to, c->comm, st));
+    if (from >= 0 && n_recv) keep(ncclRecv(recv_dev, n_recv, ncclFloat, from, c->comm, st));
+    keep(ncclGroupEnd());   // (always: an open group would swallow every later call)
+    if (first != ncclSuccess) return fail(SFX_ERR_DEVICE, "send / receive failed: %s", ncclGetErrorString(first));
     return SFX_OK;
 }
 

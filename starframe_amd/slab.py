@@ -168,6 +168,12 @@ class StaleHalo(RuntimeError):
     """A body has moved more than a quarter of the halo since the slabs were cut: ghost lists may miss contacts."""
 
 
+class SlabError(RuntimeError):
+    """A rank of a distributed slab run reported a capacity overflow or a stale halo: raised on EVERY rank at the
+    same frame (the ranks agree by all-reduce), so that no rank is left waiting in a halo exchange for a peer that
+    has stopped."""
+
+
 def arm_guard(world, halo):
     """Device-side guard where the engine has one (libsfx: checked by every tick's first kernel, reported as
     SFX_ERR_CAPACITY bit 128 by the next sync or tick); returns False for engines that need the host check."""
@@ -299,16 +305,28 @@ class DistSlab:
     Any other backend ("gloo"): the halo goes through host memory (tests, CPU engines)."""
 
     def __init__(self, scene, engine, dist, halo=None, device_index=None, rebalance_every=0, imbalance_tol=0.10,
-                 transport="auto", **cfg_kw):
+                 transport="auto", check_every=16, **cfg_kw):
         """transport (device path only): "native" = libsfx_rccl.so, plain rccl.h ncclSend / ncclRecv on the world's own
         stream through a communicator of its own (the path a host without torch uses; include/sfx_rccl.h);
         "torch" = torch.distributed batch_isend_irecv on tensors that alias the library's buffers; "auto" = native when it comes up on every rank, else torch (all ranks together, with a warning).
-        The environment variable SFX_SLAB_TRANSPORT overrides the argument."""
+        The environment variable SFX_SLAB_TRANSPORT overrides the argument.
+        check_every: every that many frames (and in sync / rebalance) the ranks all-reduce an error flag; a capacity
+        overflow or a stale halo on ANY rank then raises SlabError on ALL of them at that frame.  Between two checks
+        the rank that saw the condition keeps ticking (its results are void), so that its peers' exchanges complete."""
         import torch
 
         self.torch, self.dist = torch, dist
         self.rank, self.nranks = dist.get_rank(), dist.get_world_size()
+        # the device every tensor of this driver lives on and the native communicator is made for: resolved ONCE, and made
+        # torch's current device, so that no all-reduce lands on cuda:0 of every rank (ADVICE r2)
+        self.on_cuda = dist.get_backend() == "nccl"
+        if self.on_cuda:
+            if device_index is None:
+                device_index = torch.cuda.current_device()
+            torch.cuda.set_device(device_index)
         self.engine, self.device_index = engine, device_index
+        self.check_every = int(check_every)
+        self._local_error = ""
         self.halo = default_halo(scene) if halo is None else float(halo)
         self.rebalance_every, self.imbalance_tol = int(rebalance_every), float(imbalance_tol)
         self.frames = self.replans = 0
@@ -340,8 +358,7 @@ class DistSlab:
             self.native = self._native_comm(required=transport == "native")
         if self.on_device and not self.native:
             try:
-                dev = torch.device("cuda", device_index if device_index is not None else torch.cuda.current_device())
-                torch.cuda.set_device(dev)
+                dev = torch.device("cuda", device_index)
                 # one stream carries the world's kernels and orders the RCCL transfers against them
                 if self.stream is None:
                     self.stream = torch.cuda.Stream(dev)
@@ -357,12 +374,31 @@ class DistSlab:
                 self.on_device = False
                 self.world.set_stream(0)
 
+    def _dev(self):
+        """Where this driver's collective tensors live: its GPU under nccl, the host under gloo."""
+        t = self.torch
+        return t.device("cuda", self.device_index) if self.on_cuda else t.device("cpu")
+
     def _agree(self, ok):
         """True when every rank says so (one all-reduce): the ranks switch transport together or not at all."""
         t = self.torch
-        flag = t.tensor([1 if ok else 0], dtype=t.int32, device=t.device("cuda", t.cuda.current_device()))
+        flag = t.tensor([1 if ok else 0], dtype=t.int32, device=self._dev())
         self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
         return bool(flag.item())
+
+    def check(self):
+        """The collective error decision: one all-reduce (MAX) of "this rank has seen a capacity overflow
+        or a stale halo"; when any rank has, every rank raises SlabError here, together."""
+        t = self.torch
+        flag = t.tensor([1 if self._local_error else 0], dtype=t.int32, device=self._dev())
+        self.dist.all_reduce(flag, op=self.dist.ReduceOp.MAX)
+        if int(flag.item()):
+            raise SlabError(f"rank {self.rank} of {self.nranks}, frame {self.frames}: "
+                            + (self._local_error or "another rank reported an overflow or a stale halo; this rank stops with it"))
+
+    def _note(self, what):
+        if not self._local_error:
+            self._local_error = what
 
     def _native_comm(self, required):
         """A RCCL communicator of the library's own (once per driver; it outlives re-cuts): rank 0 makes the id, the
@@ -398,7 +434,7 @@ class DistSlab:
         box = [bytes(buf)]
         self.dist.broadcast_object_list(box, src=0)
         comm = C.c_void_p()
-        dev = self.device_index if self.device_index is not None else self.torch.cuda.current_device()
+        dev = self.device_index
         rc = self.rccl.sfx_rccl_comm_create((C.c_ubyte * _abi.RCCL_ID_BYTES).from_buffer_copy(box[0]), self.rank, self.nranks, dev,
                                             C.byref(comm))
         if rc != 0:
@@ -418,7 +454,7 @@ class DistSlab:
         t, p = self.torch, self.plan
         x = self.world.poses()[0][:p.n_owned, 0]
         moved = float(np.abs(x - self.scene.pos[p.ids[:p.n_owned], 0]).max()) if p.n_owned else 0.0
-        dev = t.device("cuda", t.cuda.current_device()) if self.on_device else t.device("cpu")
+        dev = self._dev()
         c = t.tensor(slab_counts(x, self.bounds, self.nranks), dtype=t.int64, device=dev)
         m = t.tensor([moved], dtype=t.float64, device=dev)
         self.dist.all_reduce(c, op=self.dist.ReduceOp.SUM)
@@ -431,6 +467,7 @@ class DistSlab:
         at equal counts and rebuild their worlds -- bodies change owner, ghost and send lists are new.  Every
         rank decides on the same all-reduced figures.  The migration goes through host memory (a re-upload):
         it is a per-many-frames event, not on the substep path.  Returns True when the slabs were re-cut."""
+        self.check()
         counts, moved = self.drift()
         need, self.imbalance = needs_replan(counts, moved, self.halo, self.imbalance_tol)
         if not (need or force):
@@ -483,19 +520,52 @@ class DistSlab:
                 w.wait()
         self.world.halo_put(recv.numpy().reshape(-1, 8))
 
+    def _local(self, call, *a):
+        """An engine call whose capacity / halo errors are rank-local: noted, not raised -- this rank goes on ticking
+        (the library refuses a tick only until sync has reported the condition once), so that the peers' exchanges
+        complete; the next collective check stops all ranks together."""
+        from .world import SfxError
+        from ._abi import SFX_ERR_CAPACITY
+        try:
+            return call(*a)
+        except SfxError as e:
+            if e.code != SFX_ERR_CAPACITY:
+                raise
+            self._note(str(e))
+        try:
+            self.world.sync()      # reports the sticky condition (again) and clears it
+        except SfxError as e:
+            if e.code != SFX_ERR_CAPACITY:
+                raise
+        return call(*a)
+
     def step(self, dt):
-        self.world.tick_begin(dt)
+        if self.check_every and self.frames % self.check_every == 0:
+            self.check()
+        self._local(self.world.tick_begin, dt)
         for _ in range(self.scene.substeps):
-            self.world.tick_substep()
+            self._local(self.world.tick_substep)
             self.exchange()
         self.frames += 1
         if self.rebalance_every and self.frames % self.rebalance_every == 0:
             self.rebalance()
         elif not self.device_guard:
-            host_guard(self.world, self.plan, self.scene, self.halo)
+            try:
+                host_guard(self.world, self.plan, self.scene, self.halo)
+            except StaleHalo as e:
+                self._note(str(e))
 
     def sync(self):
-        self.world.sync()
+        """Waits for this rank's work; then the ranks agree on whether any of them failed (SlabError on all)."""
+        from .world import SfxError
+        from ._abi import SFX_ERR_CAPACITY
+        try:
+            self.world.sync()
+        except SfxError as e:
+            if e.code != SFX_ERR_CAPACITY:
+                raise
+            self._note(str(e))
+        self.check()
 
     def owned_state(self):
         p = self.plan
@@ -526,7 +596,7 @@ class DistSlab:
         inertia = np.where(ii > 0, 1.0 / np.where(ii > 0, ii, 1.0), 0.0)
         ke = float((0.5 * m * (lv.astype(np.float64) ** 2).sum(1)).sum() + (0.5 * inertia * la.astype(np.float64) ** 2).sum())
         st = self.world.stats()
-        dev = t.device("cuda", t.cuda.current_device()) if self.on_device else t.device("cpu")
+        dev = self._dev()
         sums = t.tensor([ke, float(st.n_pairs), float(st.n_manifolds), float(st.n_contacts), float(len(ids))],
                         dtype=t.float64, device=dev)
         mx = t.tensor([float(st.max_depth), float(st.n_colors)], dtype=t.float64, device=dev)

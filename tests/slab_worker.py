@@ -26,6 +26,30 @@ def main():
         vel = np.zeros_like(s.pos)
         vel[dyn, 0] = 2.0
         s = s.with_state(s.pos, s.rot, vel, s.angvel)
+    if len(sys.argv) > 3 and sys.argv[3] == "trip":
+        # one body of the LEFT slab shoots off at 30 m/s: rank 0's halo guard trips in the first frames, rank 1 sees nothing.
+        # Both ranks must stop, together, at the next collective check -- and neither may hang in an exchange
+        from starframe_amd.slab import SlabError
+
+        dyn = np.nonzero((s.inv_mass > 0) | (s.inv_inertia > 0))[0]
+        left = dyn[np.argmin(s.pos[dyn, 0])]
+        vel = np.zeros_like(s.pos)
+        vel[left] = (0.0, 30.0)
+        vel[left, 0] = 30.0
+        s = s.with_state(s.pos, s.rot, vel, s.angvel)
+        slab = DistSlab(s, OracleWorld, dist, halo=1.5, check_every=4)
+        msg = "no error"
+        try:
+            for _ in range(ticks):
+                slab.step(1.0 / 60.0)
+            slab.sync()
+        except SlabError as e:
+            msg = str(e)
+        with open(f"{out}.rank{dist.get_rank()}", "w") as f:
+            f.write(f"{slab.frames}\n{msg}\n")
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     slab = DistSlab(s, OracleWorld, dist, halo=1.5, rebalance_every=2)
     for _ in range(ticks):
         slab.step(1.0 / 60.0)

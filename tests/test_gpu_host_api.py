@@ -75,8 +75,9 @@ def test_native_rccl_slab_driver_send_to_self(tmp_path):
     scene_file = str(tmp_path / "circles_settled.bin")
     dump(s, scene_file)
     exe = os.path.join(ROOT, "tools", "sfx_slab_run")
-    if not os.path.exists(exe):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "sfx_slab_run"])
+    # always through make (a no-op when the binary is newer than its sources, the headers and the two libraries): a binary
+    # left over from before an ABI change must not run against the new library (it also checks sfx_abi_version itself)
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "sfx_slab_run"])
     out = subprocess.run([exe, scene_file, "30", "--self"], capture_output=True, text=True, timeout=200)
     sys.stdout.write(out.stdout)
     assert out.returncode == 0, out.stdout + out.stderr

@@ -136,6 +136,25 @@ def test_two_ranks_over_gloo_equal_logical_slabs(tmp_path):
     assert float(z["max_depth"]) == pytest.approx(max(w.stats().max_depth for w in L.worlds), rel=1e-6)
 
 
+def test_an_error_on_one_rank_stops_all_ranks_together(tmp_path):
+    """the halo guard / capacity errors are rank-local.  Two ranks over gloo; a body of rank 0's slab shoots
+    off and trips rank 0's guard in the first frames.  Rank 0 must not stop alone (rank 1 would wait for its halo for
+    ever): both ranks raise SlabError at the same frame, the next collective check."""
+    out = str(tmp_path / "trip")
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "slab_worker.py"), out, "20", "trip"], env=env))
+    for p in procs:
+        assert p.wait(timeout=240) == 0     # (a hang ends the test by this timeout)
+    r0 = open(out + ".rank0").read().splitlines()
+    r1 = open(out + ".rank1").read().splitlines()
+    assert r0[0] == r1[0] == "4", (r0, r1)               # the first check after the guard tripped, on both ranks
+    assert "moved more than halo / 4" in r0[1]            # the rank that saw it says what it saw
+    assert "another rank" in r1[1]                        # the other one stops with it
+
+
 def drifting_scene():
     """The small pile with 2 m/s to the right: it slides against the right wall, bodies cross the cuts."""
     s = small_scene()

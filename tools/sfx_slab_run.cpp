@@ -10,6 +10,7 @@
 //
 // scene.bin: scripts/dump_scene.py (circles and static rects only: the planner below knows no other shape, like
 // starframe_amd/slab.py it cuts the x axis at equal body counts and ghosts the neighbours' bodies within the halo).
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -272,13 +273,20 @@ static int run_rank(const Scene& s, int ticks, int rank, int nranks, const std::
         }
         return 0;
     };
-    for (int t = 0; t < 10; ++t) if (tick()) return 1;
+    // a rank that fails (capacity overflow, stale halo, device error) must not leave its peers waiting in an exchange:
+    // it aborts its communicator and exits non-zero; the parent then ends the other ranks (main)
+    auto failed = [&]() -> int {
+        sfx_rccl_comm_abort(comm);
+        sfx_destroy(w);
+        return 1;
+    };
+    for (int t = 0; t < 10; ++t) if (tick()) return failed();
     CHECK(w, sfx_sync(w));
     double zero = 0.0, tmax = 0.0;
     CHECK(w, sfx_rccl_allreduce_stats(comm, &zero, 1, &tmax, 1));   // a barrier before the clock starts
     const auto t0 = std::chrono::steady_clock::now();
-    for (int t = 0; t < ticks; ++t) if (tick()) return 1;
-    CHECK(w, sfx_sync(w));
+    for (int t = 0; t < ticks; ++t) if (tick()) return failed();
+    if (sfx_sync(w)) { fprintf(stderr, "rank %d: %s\n", rank, sfx_last_error(w)); return failed(); }
     double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     sfx_frame_stats st;
     CHECK(w, sfx_stats(w, &st));
@@ -302,7 +310,10 @@ int main(int argc, char** argv) {
     Scene s;
     if (!load(argv[1], s)) { fprintf(stderr, "cannot read %s (circles and static rects only)\n", argv[1]); return 2; }
     if (self) return run_self(s, ticks);
+    if (sfx_abi_version() != SFX_ABI_VERSION) { fprintf(stderr, "libsfx.so has ABI %u, this program was built for %u: rebuild\n", sfx_abi_version(), SFX_ABI_VERSION); return 2; }
     const std::string idfile = "/tmp/sfx_slab_run." + std::to_string((long)getpid()) + ".id";
+    remove(idfile.c_str());   // (a killed run with the same process id may have left one: ranks > 0 would read a stale id)
+    remove((idfile + ".tmp").c_str());
     if (nranks == 1) { const int rc = run_rank(s, ticks, 0, 1, idfile); remove(idfile.c_str()); return rc; }
     std::vector<pid_t> kids;
     for (int r = 0; r < nranks; ++r) {   // fork BEFORE anything touches the GPU: every rank initialises HIP itself
@@ -311,8 +322,18 @@ int main(int argc, char** argv) {
         if (pid == 0) _exit(run_rank(s, ticks, r, nranks, idfile));
         kids.push_back(pid);
     }
+    // the first rank that ends badly ends the run: the others (by their process ids) are not waited for in order --
+    // they may be inside a collective that will never complete
     int bad = 0;
-    for (pid_t k : kids) { int st = 0; waitpid(k, &st, 0); if (!WIFEXITED(st) || WEXITSTATUS(st)) bad = 1; }
+    for (size_t left_kids = kids.size(); left_kids; --left_kids) {
+        int st = 0;
+        const pid_t k = waitpid(-1, &st, 0);
+        if (k < 0) break;
+        if (!WIFEXITED(st) || WEXITSTATUS(st)) {
+            if (!bad) for (pid_t o : kids) if (o != k) kill(o, SIGKILL);
+            bad = 1;
+        }
+    }
     remove(idfile.c_str());
     return bad;
 }
