@@ -340,6 +340,7 @@ def main():
     device = local_rank
     dist = None
     slab = None
+    setup = None
     if world > 1 or args.force_slab:
         import torch
         import torch.distributed as dist
@@ -359,23 +360,36 @@ def main():
         from starframe_amd.slab import DistSlab
 
         # BASELINE.json configs[4] in its weak-scaling form: a granular slab of `slab_bodies` circles per
-        # GPU (500 k: 4 M at N = 8), 100 lattice rows, `world` times as wide; settled as slabs with damping (untimed; the
-        # halo guard is off while the circles roll into place, re-cuts every 50 frames), then cut again on the settled state
+        # GPU (500 k: 4 M at N = 8), 100 lattice rows, `world` times as wide; settled as slabs with damping (untimed, one
+        # cut with a wide halo), relaxed without damping, then cut again on the state at rest
         per_gpu = args.slab_bodies
         scene = scenes.granular_slab(n=world * per_gpu, width=world * (per_gpu // 100))
         scene_note = f"granular_slab: lattice {world * (per_gpu // 100)} wide x 100 rows of circles r ~ U[0.05, 0.10], pitch 0.22 m"
-        def untimed(sc, frames, **kw):   # slabs that re-cut every 50 frames, halo guard off (bodies are on their way)
-            pre = DistSlab(sc, World, dist, device_index=device, rebalance_every=50, **kw)
-            for k in range(frames):
-                if k % 50 == 0:
-                    pre.world.halo_guard(0.0)
+        setup = {}
+        t_setup = time.perf_counter()
+
+        def untimed(sc, frames, what, **kw):
+            # ONE cut with a 12 m halo and no re-cut (a re-cut gathers every body on every rank and rebuilds the worlds:
+            # at 4 M bodies ~5 s of host work each, and re-cutting every 50 frames made the untimed part the longest
+            # thing in an N = 8 run); the halo guard is off while the circles roll into place, and what it would have
+            # checked is checked once at the end: no body may have travelled more than halo / 4 in x
+            t = time.perf_counter()
+            pre = DistSlab(sc, World, dist, device_index=device, halo=12.0, **kw)
+            pre.world.halo_guard(0.0)
+            for _ in range(frames):
                 pre.step(DT)
+            pre.sync()
+            _, moved = pre.drift()
+            if moved > pre.halo / 4:
+                raise SystemExit(f"bench: a body travelled {moved:.2f} m in x while the pile {what} (limit {pre.halo / 4:.1f} m): "
+                                 f"the halo of the untimed set-up is too narrow for this scene")
             pos, rot, _, _ = pre.gather()
             pre.close()
+            setup[what] = round(time.perf_counter() - t, 2)
             return sc.with_state(pos, rot, name=scene.name + "_settled")
 
-        scene = untimed(scene, args.settle_frames, linear_damping=3.3, angular_damping=1.0)
-        scene = untimed(scene, 120)    # ... and relaxed without damping, so that the cut below is made on a pile at rest
+        scene = untimed(scene, args.settle_frames, "settled", linear_damping=3.3, angular_damping=1.0)
+        scene = untimed(scene, 120, "relaxed")    # ... without damping, so that the cut below is made on a pile at rest
         single = None
         if args.single_reference:   # rank 0's share of the same workload on one GPU alone: the denominator of a scaling figure
             if rank == 0:
@@ -397,7 +411,11 @@ def main():
             dist.barrier()
         # an 8 m halo (0.7 % more bodies per slab): surface circles roll, and the halo guard stops the run -- loudly --
         # when a body has moved halo / 4 = 2 m since this cut; no re-cut inside the timed region (it rebuilds the worlds)
+        t = time.perf_counter()
         slab = DistSlab(scene, World, dist, device_index=device, halo=8.0)
+        setup["final_cut"] = round(time.perf_counter() - t, 2)
+        setup["total"] = round(time.perf_counter() - t_setup, 2)
+        print(f"bench: rank {rank} set-up {setup}", file=sys.stderr, flush=True)
         w = slab.world
         n_dyn = scene.n_dynamic()            # all ranks together
         n_local = slab.plan.n_owned
@@ -520,6 +538,7 @@ def main():
             "bodies_per_gpu": n_rank,
             "substeps": scene.substeps,
             "parallelism": parallelism,
+            **({"setup_s": setup} if setup else {}),     # untimed: cut, settle, gather, relax, final cut (wall seconds on rank 0)
             "pairs": st.n_pairs,
             "manifolds": st.n_manifolds,
             "colors": st.n_colors,

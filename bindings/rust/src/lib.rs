@@ -1,5 +1,5 @@
 //! sfx-sys: the thin `extern "C"` FFI crate BASELINE.json:5 asks for, mirroring include/sfx.h and
-//! include/sfx_rccl.h declaration by declaration (ABI 9).
+//! include/sfx_rccl.h declaration by declaration (ABI 10).
 //! UNCOMPILED: no rustc/cargo in the build image and no upstream source to test against; the C and C++
 //! harnesses (tools/sfx_c_tick.c, starframe_amd/cpp, tools/sfx_slab_run.cpp) and ctypes exercise the identical
 //! ABI, and tests/test_abi.py::test_rust_mirror_declares_every_symbol_and_size checks this file's text against
@@ -7,7 +7,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const SFX_ABI_VERSION: u32 = 9;
+pub const SFX_ABI_VERSION: u32 = 10;
 
 // sfx_status
 pub const SFX_OK: c_int = 0;
@@ -215,6 +215,7 @@ extern "C" {
     pub fn sfx_create(cfg: *const sfx_config, out: *mut *mut sfx_world) -> c_int;
     pub fn sfx_destroy(w: *mut sfx_world);
     pub fn sfx_abi_version() -> u32;
+    pub fn sfx_build_id() -> *const c_char;
     pub fn sfx_default_config(cfg: *mut sfx_config);
     // scene upload
     pub fn sfx_upload_bodies(w: *mut sfx_world, n: u32, pos: *const f32, rot: *const f32, vel: *const f32,
@@ -255,6 +256,11 @@ extern "C" {
     /// Device pointers in and out; allocates nothing, does not synchronise (include/sfx.h).
     pub fn sfx_query_points_static(w: *mut sfx_world, n: u32, points_dev: *const f32, mask: u32, body_dev: *mut u32,
                                    count_dev: *mut u32) -> c_int;
+    /// Device pointers in and out, enqueued on the world's stream, no synchronisation (include/sfx.h).
+    pub fn sfx_query_aabbs_device(w: *mut sfx_world, n: u32, boxes_dev: *const f32, mask: u32, hits_dev: *mut u64, cap: u32,
+                                  n_hits_dev: *mut u32) -> c_int;
+    pub fn sfx_query_rays_device(w: *mut sfx_world, n: u32, rays_dev: *const f32, max_t_dev: *const f32, mask: u32,
+                                 hits_dev: *mut sfx_ray_hit) -> c_int;
     // parity hooks
     pub fn sfx_debug_aabbs(w: *mut sfx_world, out: *mut f32) -> c_int;
     pub fn sfx_debug_pairs(w: *mut sfx_world, keys: *mut u64, cap: usize, n: *mut usize) -> c_int;

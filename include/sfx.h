@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 9u
+#define SFX_ABI_VERSION 10u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -243,6 +243,9 @@ typedef struct sfx_world sfx_world;
 int sfx_create(const sfx_config* cfg, sfx_world** out);
 void sfx_destroy(sfx_world* w); /* NULL is a no-op */
 uint32_t sfx_abi_version(void);
+/* the first 16 hex digits of the SHA-256 of the sources the library was compiled from (starframe_amd/build.py): what
+ * tells a shipped libsfx.so from one that lags behind its tree */
+const char* sfx_build_id(void);
 void sfx_default_config(sfx_config* cfg);
 
 /* ---- scene upload (BASELINE.json:5 "body/collider/material components") --- */
@@ -357,12 +360,24 @@ int sfx_query_rays(sfx_world* w, uint32_t n, const float* rays /* [n][4] */, con
  *  - points, body and count are DEVICE pointers ([n][2] floats, [n], [n] or NULL); nothing is copied;
  *  - everything is enqueued on the world's stream and the call returns without synchronising; it calls no
  *    hipMalloc / hipFree / allocating routine.
- * Limits: worlds of at most 131072 bodies on a grid of at most 2^18 cells (the automatic grid of <= 131072
- * bodies), else SFX_ERR_UNSUPPORTED; profiling must be off (event pools allocate), else SFX_ERR_INVALID.
+ * Limits: worlds of at most 131072 bodies + further colliders (one index entry per collider) on a grid of at most
+ * 2^18 cells (the automatic grid of that many entries), else SFX_ERR_UNSUPPORTED; profiling must be off (event pools allocate), else SFX_ERR_INVALID.
  * The index is rebuilt by every call.  All worlds on a GPU share that GPU's array: calls that overlap on one
  * GPU (two streams, two threads) race; serialise them. */
 int sfx_query_points_static(sfx_world* w, uint32_t n, const float* points_dev /* [n][2], device */, uint32_t mask,
                             uint32_t* body_dev /* [n], device */, uint32_t* count_dev /* [n] or NULL, device */);
+
+/* ---- box and ray queries on device memory (no counterpart in the reference; SURVEY.md section 8f rank 1 for hosts
+ * that keep their data on the GPU): boxes / rays / max_t / hits are DEVICE pointers, everything is enqueued on the
+ * world's stream and the calls return without copying or synchronising (the query index is built on that stream too;
+ * its buffers are allocated by a world's first query).
+ * sfx_query_aabbs_device: hits_dev receives up to cap keys (query << 32 | BODY) in no particular order -- a body with
+ * several colliders in the box appears once per collider; *n_hits_dev = the full count (compare with cap).
+ * sfx_query_rays_device: as sfx_query_rays. */
+int sfx_query_aabbs_device(sfx_world* w, uint32_t n, const float* boxes_dev /* [n][4] */, uint32_t mask,
+                           uint64_t* hits_dev, uint32_t cap, uint32_t* n_hits_dev);
+int sfx_query_rays_device(sfx_world* w, uint32_t n, const float* rays_dev /* [n][4] */, const float* max_t_dev /* [n] */,
+                          uint32_t mask, sfx_ray_hit* hits_dev /* [n] */);
 
 /* ---- parity hooks (slow paths, used by tests) ----------------------------- */
 /* world AABBs [n][4] = (lo.x, lo.y, hi.x, hi.y) of the last tick's broadphase */

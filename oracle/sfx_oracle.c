@@ -218,7 +218,7 @@ static int is_dynamic(const sfo_world* w, uint32_t i) {
 /* of an entry: is the body it belongs to dynamic (an entry beyond the bodies has no mass of its own) */
 static int owner_dynamic(const sfo_world* w, uint32_t e) { return is_dynamic(w, w->cbody[e]); }
 
-/* a further collider of a DYNAMIC body: its pairs go to the fallback list (solved on the body, not on the entry) */
+/* a further collider of a DYNAMIC body: its pairs are solved on the body, not on the entry (build_order: tile_end_ok) */
 static int dynamic_secondary(const sfo_world* w, uint32_t e) { return e >= w->nb && owner_dynamic(w, e); }
 
 /* [DESIGN] bounding diameter of a shape, used only for the automatic cell size */
@@ -970,6 +970,22 @@ static uint32_t wrapped_tile(const sfo_world* w, int32_t tx, int32_t ty) {
 
 static int32_t tile_coord(int32_t c, uint32_t tl) { return c >= 0 ? (int32_t)((uint32_t)c >> tl) : -(int32_t)(((uint32_t)(-(c + 1)) >> tl) + 1u); }
 
+/* [DESIGN] May the end `e` of a candidate pair stand in a tile's pair list?  Always, unless it is a further collider of
+ * a dynamic body: the tile solves keep one state per BODY, at the place of its first collider (entry = body id), so
+ * the further collider must be small and lie in the home tile of that first collider, which must be small too; and where
+ * the pair crosses a tile border in x (ddx) / in y (ddy) the two must share the cell column / row -- the body then takes
+ * part in exactly the seam units its first collider alone could take part in, and the units of one class still share
+ * no body (see "tile order" above).  Everything else of such a body goes to the fallback list. */
+static int tile_end_ok(const sfo_world* w, uint32_t e, int ddx, int ddy) {
+    if (!dynamic_secondary(w, e)) return 1;
+    const uint32_t b = w->cbody[e];
+    if (!w->is_small[e] || !w->is_small[b]) return 0;
+    if (tile_coord(w->ccx[e], w->tlx) != tile_coord(w->ccx[b], w->tlx) || tile_coord(w->ccy[e], w->tly) != tile_coord(w->ccy[b], w->tly)) return 0;
+    if (ddx && w->ccx[e] != w->ccx[b]) return 0;
+    if (ddy && w->ccy[e] != w->ccy[b]) return 0;
+    return 1;
+}
+
 static void build_order(sfo_world* w, float frame_dt) {
     uint32_t np = w->n_pairs < w->max_pairs ? w->n_pairs : w->max_pairs;
     uint32_t lx = w->gxl - w->tlx, ly = w->gyl - w->tly, ntiles = 1u << (lx + ly);
@@ -985,18 +1001,18 @@ static void build_order(sfo_world* w, float frame_dt) {
         uint32_t a = w->pa[e], b = w->pb[e], own = SFO_FALLBACK;
         int32_t txa = tile_coord(w->ccx[a], w->tlx), tya = tile_coord(w->ccy[a], w->tly);
         int32_t txb = tile_coord(w->ccx[b], w->tlx), tyb = tile_coord(w->ccy[b], w->tly);
-        if (dynamic_secondary(w, a) || dynamic_secondary(w, b)) own = SFO_FALLBACK;
+        int ddx = 0, ddy = 0;
+        if (w->is_small[a] && w->is_small[b]) {
+            /* (wrapped tile coordinates: with one tile column / row every home tile is the same one) */
+            ddx = (((uint32_t)txa ^ (uint32_t)txb) & ((1u << lx) - 1u)) != 0;
+            ddy = (((uint32_t)tya ^ (uint32_t)tyb) & ((1u << ly) - 1u)) != 0;
+        }
+        if (!tile_end_ok(w, a, ddx, ddy) || !tile_end_ok(w, b, ddx, ddy)) own = SFO_FALLBACK;
         else if (w->is_small[a] && w->is_small[b]) own = wrapped_tile(w, txa < txb ? txa : txb, tya < tyb ? tya : tyb);
         else if (w->is_small[a] && !dyn[b]) own = wrapped_tile(w, txa, tya);
         else if (w->is_small[b] && !dyn[a]) own = wrapped_tile(w, txb, tyb);
         w->owner[e] = own;
-        w->pclass[e] = 0;
-        if (own != SFO_FALLBACK && w->is_small[a] && w->is_small[b]) {
-            /* (wrapped tile coordinates: with one tile column / row every home tile is the same one) */
-            int ddx = (((uint32_t)txa ^ (uint32_t)txb) & ((1u << lx) - 1u)) != 0;
-            int ddy = (((uint32_t)tya ^ (uint32_t)tyb) & ((1u << ly) - 1u)) != 0;
-            w->pclass[e] = (uint8_t)(ddx ? (ddy ? 3 : 1) : (ddy ? 2 : 0));
-        }
+        w->pclass[e] = (uint8_t)(own == SFO_FALLBACK ? 0 : ddx ? (ddy ? 3 : 1) : (ddy ? 2 : 0));
         if (own != SFO_FALLBACK) tcnt[own]++;
     }
     w->max_tile_pairs = 0; w->max_tile_bodies = 0; w->n_tiles = 0;

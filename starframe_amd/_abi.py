@@ -198,7 +198,8 @@ def vptr(a):
 
 # every symbol include/sfx.h declares; tests check the built library exports all of them
 SFX_SYMBOLS = [
-    "sfx_create", "sfx_destroy", "sfx_abi_version", "sfx_default_config",
+    "sfx_create", "sfx_destroy", "sfx_abi_version", "sfx_build_id", "sfx_default_config",
+    "sfx_query_aabbs_device", "sfx_query_rays_device",
     "sfx_upload_bodies", "sfx_upload_colliders", "sfx_upload_materials", "sfx_upload_constraints",
     "sfx_upload_angle_constraints",
     "sfx_step", "sfx_sync", "sfx_download_poses", "sfx_download_velocities",
@@ -252,6 +253,7 @@ def load_libsfx(path=None):
     lib.sfx_destroy.argtypes = [vp]
     lib.sfx_destroy.restype = None
     lib.sfx_abi_version.restype = C.c_uint32
+    lib.sfx_build_id.restype = C.c_char_p
     lib.sfx_default_config.argtypes = [P(SfxConfig)]
     lib.sfx_default_config.restype = None
     bind_world_api(lib, "sfx_")
@@ -286,7 +288,10 @@ def load_libsfx(path=None):
     lib.sfx_query_aabbs.argtypes = [vp, C.c_uint32, P(C.c_float), C.c_uint32, vp, C.c_size_t, P(C.c_size_t)]
     lib.sfx_query_rays.argtypes = [vp, C.c_uint32, P(C.c_float), P(C.c_float), C.c_uint32, vp]
     lib.sfx_query_points_static.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, vp]
-    for n in ("sfx_query_points", "sfx_query_aabbs", "sfx_query_rays", "sfx_query_points_static"):
+    lib.sfx_query_aabbs_device.argtypes = [vp, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp]
+    lib.sfx_query_rays_device.argtypes = [vp, C.c_uint32, vp, vp, C.c_uint32, vp]
+    for n in ("sfx_query_points", "sfx_query_aabbs", "sfx_query_rays", "sfx_query_points_static", "sfx_query_aabbs_device",
+              "sfx_query_rays_device"):
         getattr(lib, n).restype = C.c_int
     lib.sfx_debug_aabbs.argtypes = [vp, P(C.c_float)]
     lib.sfx_debug_pairs.argtypes = [vp, vp, C.c_size_t, P(C.c_size_t)]

@@ -36,24 +36,72 @@ def build_rccl(force=False, verbose=False):
     return RCCL_OUT
 
 
+def source_hash():
+    """First 16 hex digits of the SHA-256 over the library's sources (contents, in a fixed order): compiled into the
+    library as SFX_BUILD_ID, returned by sfx_build_id()."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def built_id(path=None):
+    """sfx_build_id() of a built library (None when it is missing, or older than the build id)."""
+    import ctypes
+
+    path = path or OUT
+    if not os.path.exists(path):
+        return None
+    try:
+        lib = ctypes.CDLL(path)
+        lib.sfx_build_id.restype = ctypes.c_char_p
+        return lib.sfx_build_id().decode()
+    except (OSError, AttributeError):
+        return None
+
+
 def needs_build():
-    if not os.path.exists(OUT):
-        return True
-    t = os.path.getmtime(OUT)
-    return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+    """The shipped library must BE the tree's: not "newer than its sources" (timestamps do not survive a copy) but built
+    from exactly these sources."""
+    return built_id() != source_hash()
 
 
-def build(force=False, verbose=False, extra=()):
-    if not force and not needs_build():
-        build_rccl(verbose=verbose)
-        return OUT
+RACES_OUT = os.path.join(CSRC, "libsfx_races.so")
+
+
+def build_races(force=False, verbose=False):
+    """libsfx_races.so: the same library with -DSFX_DEBUG_RACES (sfx_kernels.h "race detector"): every write of a body's
+    record inside a colour step is checked on the device against a second writer of that colour.  Loaded by
+    tests/test_gpu_races.py only (SFX_LIBRARY); never by the product path."""
+    if not force and built_id(RACES_OUT) == source_hash():
+        return RACES_OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra) + ["-o", OUT] + [os.path.join(CSRC, s) for s in SOURCES]
+    cmd = [hipcc] + FLAGS + ['-DSFX_BUILD_ID="%s"' % source_hash(), "-DSFX_DEBUG_RACES", "-o", RACES_OUT] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    build_rccl(force=True, verbose=verbose)
-    return OUT
+    return RACES_OUT
+
+
+def build(force=False, verbose=False, extra=(), out=None):
+    """Compiles libsfx.so (+ libsfx_rccl.so next to it when out is the in-tree path).  force: compile whatever is there."""
+    target = out or OUT
+    if not force and out is None and not needs_build():
+        build_rccl(verbose=verbose)
+        build_races(verbose=verbose)
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ['-DSFX_BUILD_ID="%s"' % source_hash()] + list(extra) + ["-o", target] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    if out is None:
+        build_rccl(force=True, verbose=verbose)
+        build_races(force=force, verbose=verbose)
+    return target
 
 
 if __name__ == "__main__":

@@ -92,6 +92,8 @@ struct sfx_world {
     uint32_t vel_prev_epoch = 0;   // stamp of the previous substep of this tick when it left bodies underived, else 0
     bool in_step = false;          // sfx_step is driving the substeps (it sees the whole tick)
     DevBuf<uint4> filt, sorted_filt;   // filter words by entry id / in slot order (written by k_finalize_slots)
+    DevBuf<uint32_t> slot_of;          // slot of every entry; only worlds in which a dynamic body has further colliders
+    bool dyn_compounds = false;        // ... (rebuild_filt): k_pairs then looks up where a further collider's body sits
     // broadphase.  `zero` is one allocation cleared by a single memset per tick:
     // [Counters][cell_start: ncell + 1 + pad][tile_cnt: ntiles + 1 + pad][tile_fill: ntiles][tile_flag: ntiles][tile_batch: ntiles]
     DevBuf<uint32_t> zero;
@@ -516,11 +518,14 @@ int broadphase(sfx_world* w, float dt) {
     if (rc) return rc;
     { Prof p(w, SFX_K_SCATTER, n);
       hipLaunchKernelGGL(k_scatter, dim3(gb), dim3(kBlock), 0, w->stream, n, w->bucket.p, w->cell_fill.p, w->tmp_id.p); }
+    uint32_t* const slot_of = (w->dyn_compounds && w->slot_of.n >= n) ? w->slot_of.p : nullptr;
+    if (slot_of) HIPCHK(w, hipMemsetAsync(slot_of, 0xFF, sizeof(uint32_t) * n, w->stream));   // kNoSlot: entries without a shape get none
     { Prof p(w, SFX_K_SCATTER, n);
       hipLaunchKernelGGL(k_finalize_slots, dim3(gb), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->tmp_id.p,
                          w->bucket.p, w->aabb.p, w->cellxy.p, w->large_tmp.p, w->large_cap, w->sorted_id.p,
-                         w->sorted_aabb.p, w->sorted_cell.p, w->ctr, w->filt.p, w->sorted_filt.p); }
+                         w->sorted_aabb.p, w->sorted_cell.p, w->ctr, w->filt.p, w->sorted_filt.p, slot_of); }
     PairArrays P;
+    P.slot_of = slot_of;
     P.slot_cnt = w->slot_cnt.p; P.slot_off = w->slot_off.p; P.tile_cnt = w->tile_cnt; P.tile_fill = w->tile_fill; P.tile_flag = w->tile_flag;
     P.rawp = w->rawp.p; P.fpairs = w->fpairs.p; P.hit_tmp = w->hit_tmp.p; P.max_pairs = w->max_pairs; P.fb_cap = w->fb_cap;
     // one 8-lane group per slot: 32 slots per block
@@ -666,6 +671,11 @@ extern "C" {
 
 uint32_t sfx_abi_version(void) { return SFX_ABI_VERSION; }
 
+#ifndef SFX_BUILD_ID
+#define SFX_BUILD_ID "unknown"
+#endif
+const char* sfx_build_id(void) { return SFX_BUILD_ID; }
+
 void sfx_default_config(sfx_config* cfg) {
     if (!cfg) return;
     memset(cfg, 0, sizeof(*cfg));
@@ -772,7 +782,7 @@ void sfx_destroy(sfx_world* w) {
     for (auto& e : w->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : w->ev_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     w->pose.release(); w->prev.release(); w->vel.release(); w->dpos.release(); w->shape.release(); w->lpose.release(); w->poly.release();
-    w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release(); w->sorted_filt.release();
+    w->mats.release(); w->aabb.release(); w->sorted_aabb.release(); w->mass.release(); w->filt.release(); w->sorted_filt.release(); w->slot_of.release();
     w->bucket.release(); w->zero.release(); w->cell_fill.release(); w->tmp_id.release();
     w->active.release(); w->batches.release(); w->torder.release(); w->done.release(); w->bbody.release(); w->bmass.release(); w->bruns.release(); w->rawp.release(); w->tpair.release();
     w->fpairs.release(); w->fsorted.release(); w->hit_tmp.release();
@@ -807,12 +817,15 @@ const char* sfx_last_error(sfx_world* w) { return w ? w->err.c_str() : g_create_
 static int rebuild_filt(sfx_world* w) {
     if (!w->have_bodies) return SFX_OK;
     std::vector<uint4> f(std::max(w->n, 1u));
+    w->dyn_compounds = false;
     for (uint32_t i = 0; i < w->n; ++i) {
         const bool dyn = is_dynamic(w, i);
         uint4 v = make_uint4(0, 0, 0, (dyn ? kFiltDynamic : 0u) | ((dyn && i >= w->nb) ? kFiltFurther : 0u) | (owner(w, i) << 8));
         if (w->have_colliders) { v.x = w->h_col[i].category; v.y = w->h_col[i].mask; v.z = w->h_col[i].group; }
         f[i] = v;
+        if (dyn && i >= w->nb) w->dyn_compounds = true;
     }
+    if (w->dyn_compounds && w->slot_of.n < w->n) ALLOC(w, w->slot_of, w->n);
     HIPCHK(w, hipMemcpyAsync(w->filt.p, f.data(), sizeof(uint4) * w->n, hipMemcpyHostToDevice, w->stream));
     HIPCHK(w, hipStreamSynchronize(w->stream));
     return SFX_OK;
@@ -1223,7 +1236,8 @@ int sfx_tick_substep(sfx_world* w) {
     // Fused launches: workgroup b may start with batch b (no ticket round trip) while this world is the only one
     // on its device -- the grid is then resident as a whole.  With other worlds on the device (logical slabs, several
     // ranks per GPU: SFX_SHARED_DEVICE=1 says so for other processes) every batch is handed out by ticket.
-    const int first = (w->counted && g_live_worlds[w->device].load() == 1 && !g_shared_device) ? kTileStaticFirst : 0;
+    static const int race_selftest = [] { const char* e = getenv("SFX_RACE_SELFTEST"); return (e && e[0] == '1') ? kTileRaceSelfTest : 0; }();   // libsfx_races.so only
+    const int first = ((w->counted && g_live_worlds[w->device].load() == 1 && !g_shared_device) ? kTileStaticFirst : 0) | race_selftest;
     auto launch_pos = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
         fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;
         const uint32_t nt = tvp == 0 ? 512u : tvp == 1 ? 256u : 128u;
@@ -1482,7 +1496,7 @@ int build_query_index(sfx_world* w, const QueryBuffers& Q) {
     { Prof p(w, SFX_K_QUERY, n);
       hipLaunchKernelGGL(k_finalize_slots, dim3(gb), dim3(kBlock), 0, w->stream, n, g, qcs, Q.tmp_id, Q.bucket,
                          Q.aabb, Q.cellxy, Q.large_tmp, w->large_cap, Q.sorted_id, Q.sorted_aabb,
-                         Q.sorted_cell, qctr, (const uint4*)nullptr, (uint4*)nullptr); }
+                         Q.sorted_cell, qctr, (const uint4*)nullptr, (uint4*)nullptr, (uint32_t*)nullptr); }
     { Prof p(w, SFX_K_QUERY, n);
       hipLaunchKernelGGL(k_query_bounds, dim3(std::min(gb, 1024u)), dim3(kBlock), 0, w->stream, qcs, w->ncell,
                          Q.sorted_aabb, Q.bounds); }
@@ -1581,7 +1595,7 @@ int sfx_query_aabbs(sfx_world* w, uint32_t n, const float* boxes, uint32_t mask,
     HIPCHK(w, hipMemsetAsync(w->q_nhits.p, 0, sizeof(uint32_t), w->stream));
     { Prof p(w, SFX_K_QUERY, n);
       hipLaunchKernelGGL(k_query_aabbs, dim3(std::min(cdiv(n, kBlock / 64), 4096u)), dim3(kBlock), 0, w->stream, n, d_box, mask,
-                         query_index(w), body_arrays(w), d_hits, dcap, w->q_nhits.p); }
+                         query_index(w), body_arrays(w), d_hits, dcap, w->q_nhits.p, 0); }
     uint32_t total = 0;
     hipError_t e = hipMemcpyAsync(&total, w->q_nhits.p, sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
@@ -1620,6 +1634,37 @@ int sfx_query_rays(sfx_world* w, uint32_t n, const float* rays, const float* max
     if (e == hipSuccess) e = hipStreamSynchronize(w->stream);
     if (e != hipSuccess) return fail(w, SFX_ERR_DEVICE, "ray query failed: %s", hipGetErrorString(e));
     return w->profiling ? collect_profile(w) : SFX_OK;
+}
+
+// Box and ray queries for callers that keep their data on the device: device pointers in and out,
+// everything enqueued on the world's stream, no copy and no synchronisation.  The query index is the library's own (built
+// by the first query after the poses changed; its buffers are allocated by the first query of a world, like the host
+// variants'), so only sfx_query_points_static is the entry point that allocates nothing.
+int sfx_query_aabbs_device(sfx_world* w, uint32_t n, const float* boxes_dev, uint32_t mask, uint64_t* hits_dev, uint32_t cap,
+                           uint32_t* n_hits_dev) {
+    if (!w || (n && !boxes_dev) || !n_hits_dev || (cap && !hits_dev)) return fail(w, SFX_ERR_INVALID, "null argument");
+    int rc = ensure_query_index(w);
+    if (rc) return rc;
+    HIPCHK(w, hipMemsetAsync(n_hits_dev, 0, sizeof(uint32_t), w->stream));
+    if (n == 0) return SFX_OK;
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_query_aabbs, dim3(std::min(cdiv(n, kBlock / 64), 4096u)), dim3(kBlock), 0, w->stream, n,
+                         reinterpret_cast<const float4*>(boxes_dev), mask, query_index(w), body_arrays(w),
+                         reinterpret_cast<unsigned long long*>(hits_dev), cap, n_hits_dev, 1); }
+    HIPCHK(w, hipGetLastError());
+    return SFX_OK;
+}
+
+int sfx_query_rays_device(sfx_world* w, uint32_t n, const float* rays_dev, const float* max_t_dev, uint32_t mask,
+                          sfx_ray_hit* hits_dev) {
+    if (!w || (n && (!rays_dev || !max_t_dev || !hits_dev))) return fail(w, SFX_ERR_INVALID, "null argument");
+    int rc = ensure_query_index(w);
+    if (rc || n == 0) return rc;
+    { Prof p(w, SFX_K_QUERY, n);
+      hipLaunchKernelGGL(k_query_rays, dim3(cdiv(n, kBlock)), dim3(kBlock), 0, w->stream, n, reinterpret_cast<const float4*>(rays_dev),
+                         max_t_dev, mask, query_index(w), body_arrays(w), hits_dev); }
+    HIPCHK(w, hipGetLastError());
+    return SFX_OK;
 }
 
 // The point query without any allocation: same kernels as sfx_query_points, the query index in the static device
@@ -1688,7 +1733,7 @@ int sfx_sync(sfx_world* w) {
         w->ovf_host = 0;
         HIPCHK(w, hipMemset(w->sticky.p, 0, sizeof(uint32_t)));
         if (w->ticked && w->have_colliders && !w->tick_open) { HIPCHK(w, hipMemset(&w->ctr->overflow, 0, sizeof(uint32_t))); w->stale.overflow = 0; }
-        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in a tick since the last sfx_sync (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list, 32 a fused solve launch gave up waiting, 64 more than 64 large colliders over one batch of tiles, 128 a body moved beyond the halo guard: cut the slabs again)",
+        return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in a tick since the last sfx_sync (bits %u: 1 pairs, 2 colours, 4 serial colouring, 8 large list, 16 fallback list, 32 a fused solve launch gave up waiting, 64 more than 64 large colliders over one batch of tiles, 128 a body moved beyond the halo guard: cut the slabs again, 256 two pairs of one colour wrote the same body [libsfx_races.so only])",
                     bits);
     }
     return SFX_OK;

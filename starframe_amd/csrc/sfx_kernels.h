@@ -37,7 +37,7 @@ constexpr uint32_t kMaxBX = kMaxB + kMaxExt;        // LDS body slots of a tile 
 constexpr int kScanItems = 16;                      // items per thread in the block scan
 constexpr int kScanTile = kBlock * kScanItems;      // 4096 items per block
 constexpr uint32_t kLeftCap = 4096;                 // leftover edges the serial finish takes
-constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u, kOvfFallback = 16u, kOvfStall = 32u, kOvfExt = 64u, kOvfHalo = 128u;
+constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge = 8u, kOvfFallback = 16u, kOvfStall = 32u, kOvfExt = 64u, kOvfHalo = 128u, kOvfRace = 256u;
 
 // stage timing of the tile kernels and the colouring (development builds with -DSFX_TILE_TIMING; `T.dbg` or `dbg` in scope)
 #ifdef SFX_TILE_TIMING
@@ -414,9 +414,11 @@ __global__ __launch_bounds__(kBlock) void k_finalize_slots(uint32_t n, GridParam
                                                             const uint32_t* __restrict__ large_tmp, uint32_t large_cap,
                                                             uint32_t* __restrict__ sorted_id, float4* __restrict__ sorted_aabb,
                                                             int2* __restrict__ sorted_cell, Counters* __restrict__ ctr,
-                                                            const uint4* __restrict__ filt, uint4* __restrict__ sorted_filt) {
+                                                            const uint4* __restrict__ filt, uint4* __restrict__ sorted_filt,
+                                                            uint32_t* __restrict__ slot_of) {
     // (sorted_filt, may be null: the filter words in slot order too, so that the pair passes read a candidate's box,
-    // cell, id and filter side by side instead of its filter through its id)
+    // cell, id and filter side by side instead of its filter through its id.  slot_of, may be null: the slot of every
+    // entry -- worlds with dynamic compound bodies: k_pairs looks up where a further collider's body sits)
     const uint32_t p = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t ns = cell_start[g.ncell_all];   // grid-sorted slots: the small colliders, then the medium ones
     const uint32_t nl = min(ctr->n_large, large_cap);
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize_slots(uint32_t n, GridParam
         sorted_aabb[dst] = aabb[i];
         sorted_cell[dst] = cellxy[i];
         if (sorted_filt) sorted_filt[dst] = filt[i];
+        if (slot_of) slot_of[i] = dst;
     } else if (p - ns < nl) {
         const uint32_t i = large_tmp[p - ns];
         uint32_t rank = 0;
@@ -441,6 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_finalize_slots(uint32_t n, GridParam
         sorted_aabb[dst] = aabb[i];
         sorted_cell[dst] = make_int2(0, 0);
         if (sorted_filt) sorted_filt[dst] = filt[i];
+        if (slot_of) slot_of[i] = dst;
     }
 }
 
@@ -453,7 +457,8 @@ __global__ __launch_bounds__(kBlock) void k_finalize_slots(uint32_t n, GridParam
 // Every pair goes to one of three streams (DESIGN.md "Contract / tiles"):
 //   0  owned by the slot's own tile T      (both small, or small + large non-dynamic)
 //   1  owned by the tile left of T         (the neighbour cell (-1, +1) lies in that tile)
-//   2  the fallback list                   (a large dynamic collider is involved)
+//   2  the fallback list                   (a large dynamic collider is involved, or a further collider of a dynamic
+//                                           body that does not sit beside its body's first collider: tile_end)
 // The count pass adds the per-slot stream sizes to the tiles' pair counts; after
 // k_tile_list + a scan of those counts the fill pass reserves room per slot and stream with
 // one atomic each and writes (id a, id b, slot a, slot b).  Pairs of tiles flagged as over
@@ -476,8 +481,10 @@ struct PairArrays {
     uint2* fpairs;           // fallback list (id a, id b)
     uint2* hit_tmp;          // [kHitTmp * (n + 1)] per slot: the count pass's hits (id, slot) of stream 0 from the front
                              // and of stream 1 from the back, so that the fill pass copies instead of testing again
+    const uint32_t* slot_of; // [n] slot of every entry (kNoSlot: none), or null: no dynamic body of this world has a further collider
     uint32_t max_pairs, fb_cap;
 };
+constexpr uint32_t kNoSlot = 0xFFFFFFFFu;
 constexpr uint32_t kClassShift = 30u, kSlotMask = (1u << kClassShift) - 1u;  // slots < 2^24: the class of a tile pair sits above
 constexpr uint32_t kHitTmp = 16;  // a slot with more tile pairs (or any fallback pair) is tested again by the fill pass
 
@@ -509,6 +516,34 @@ __device__ __forceinline__ uint32_t wave_group_add(uint32_t* __restrict__ arr, u
     return rb + pre;
 }
 
+// One end of a candidate pair that is a further collider of a DYNAMIC body (kFiltFurther).  The tile solves keep one
+// state per body, at the slot of its first collider (entry = body id), so the pair may stand in a tile's list only when
+// the further collider is small and lies in the home tile of that first collider, which must be small too -- and where
+// the pair crosses a tile border in x (ddx) / y (ddy), in its cell column / row: the body then takes part in exactly
+// the seam units its first collider alone could take part in, and the units of one class still share no body.  The
+// slot word of the pair then names the BODY's slot (k_batch_color gives it the body's local index; the pair's ids
+// stay the colliders': k_narrow and the reach test measure the shapes).  oracle/sfx_oracle.c tile_end_ok.
+struct TileEnd { uint32_t slot; int2 cell; bool ok; };
+
+__device__ __forceinline__ TileEnd tile_end(uint32_t slot, int2 c, uint4 f, uint32_t ns, const GridParams& g,
+                                            const uint32_t* __restrict__ slot_of, const int2* __restrict__ sorted_cell) {
+    TileEnd e;
+    e.slot = slot; e.cell = c; e.ok = true;
+    if (!(f.w & kFiltFurther)) return e;
+    e.ok = false;
+    if (!slot_of || slot >= ns) return e;
+    const uint32_t ps = slot_of[f.w >> 8];
+    if (ps >= ns) return e;   // (kNoSlot: the body's first collider has no shape)
+    const int2 cp = sorted_cell[ps];
+    e.ok = (cp.x >> g.tlx) == (c.x >> g.tlx) && (cp.y >> g.tly) == (c.y >> g.tly);
+    e.slot = ps; e.cell = cp;
+    return e;
+}
+
+__device__ __forceinline__ bool tile_end_ok(const TileEnd& e, int2 c, bool ddx, bool ddy) {
+    return e.ok && (!ddx || e.cell.x == c.x) && (!ddy || e.cell.y == c.y);
+}
+
 template <bool FILL>
 __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, const uint32_t* __restrict__ cell_start,
                                                    const uint32_t* __restrict__ sorted_id,
@@ -535,6 +570,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
         if (live) { i = sorted_id[p]; Ai = sorted_aabb[p]; fi = sorted_filt[p]; c = sorted_cell[p]; }
         const int32_t txp = c.x >> g.tlx, typ = c.y >> g.tly;
         const uint32_t T0 = tile_of(txp, typ, g), T1 = tile_of(txp - 1, typ, g);
+        const TileEnd Ei = tile_end(p, c, fi, ns, g, P.slot_of, sorted_cell);   // (p itself unless a further collider of a dynamic body)
         // stream bases (fill pass): lane 0 of the group reserves, the group reads them by shuffle
         uint32_t base[3] = {0u, 0u, 0u};
         bool to_fb[3] = {false, false, true};
@@ -615,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                     if (to_fb[s3]) {
                         if (dst < P.fb_cap) P.fpairs[dst] = make_uint2(swap ? j : i, swap ? i : j);
                     } else if (dst < P.max_pairs) {
-                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, (swap ? p : q) | (cls << kClassShift));
+                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : Ei.slot, (swap ? Ei.slot : q) | (cls << kClassShift));
                     }
                 }
                 cnt[s3] += (uint32_t)__popcll(bal);
@@ -637,12 +673,14 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
             // class of a tile pair (DESIGN.md "Contract / tiles"): 0 interior, 1 x seam, 2 y seam, 3 corner -- where the two
             // home tiles lie; it rides in the two top bits of the pair's second slot word
             uint32_t cls = 0u;
+            bool ddx = false, ddy = false;
             if (small_slot && r >= 1 && r < 5) {
                 // (wrapped tile coordinates: with one tile column / row every home tile is the same one)
-                const bool ddx = ((uint32_t)((ncx >> g.tlx) ^ txp) & ((1u << (g.gxl - g.tlx)) - 1u)) != 0u;
-                const bool ddy = ((uint32_t)((ncy >> g.tly) ^ typ) & ((1u << (g.gyl - g.tly)) - 1u)) != 0u;
+                ddx = ((uint32_t)((ncx >> g.tlx) ^ txp) & ((1u << (g.gxl - g.tlx)) - 1u)) != 0u;
+                ddy = ((uint32_t)((ncy >> g.tly) ^ typ) & ((1u << (g.gyl - g.tly)) - 1u)) != 0u;
                 cls = ddx ? (ddy ? 3u : 1u) : (ddy ? 2u : 0u);
             }
+            uint32_t qw = q;   // the candidate's slot word: its body's slot when it is a further collider of a dynamic body
             if (x < L) {
                 // the candidate's cell, box, id and filter words: four loads side by side (the slot order makes them
                 // sequential), nothing waits for another
@@ -655,10 +693,15 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                     j = jq;
                     hit = pair_filter(fi, fj);
                     if (r == 5 && small_slot && (fj.w & kFiltDynamic)) st = 2;  // small against a large dynamic collider
-                    if ((fi.w | fj.w) & kFiltFurther) st = 2;  // a further collider of a dynamic body: solved on the body
+                    if (hit && ((fi.w | fj.w) & kFiltFurther)) {   // a further collider of a dynamic body: in the tiles when it sits beside its body
+                        const TileEnd Ej = tile_end(q, cq, fj, ns, g, P.slot_of, sorted_cell);
+                        if (!tile_end_ok(Ei, c, ddx, ddy) || !tile_end_ok(Ej, cq, ddx, ddy)) st = 2;
+                        qw = Ej.slot;
+                    }
                 }
             }
-            emit(hit, j, q, st, cls);
+            if (st == 2) cls = 0u;
+            emit(hit, j, qw, st, cls);
         }
         // Second level: a small slot against the medium colliders homed in the level-1 cells [c1(lo) - 1, c1(hi)] on both
         // axes (an overlapping medium collider's home cell lies there: its box is under 1.9 such cells wide).  Up to nine
@@ -693,6 +736,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                 bool hit = false;
                 uint32_t j = 0;
                 int st = 0;   // small + medium: the small collider's tile, unless the medium one is dynamic
+                uint32_t qw = q;
                 if (x < L1) {
                     const int2 cq = sorted_cell[q];
                     const float4 Aq = sorted_aabb[q];
@@ -702,10 +746,14 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                         j = jq;
                         hit = pair_filter(fi, fj);
                         if (fj.w & kFiltDynamic) st = 2;
-                        if ((fi.w | fj.w) & kFiltFurther) st = 2;
+                        if (hit && ((fi.w | fj.w) & kFiltFurther)) {
+                            const TileEnd Ej = tile_end(q, cq, fj, ns, g, P.slot_of, sorted_cell);   // (a medium slot: never ok)
+                            if (!tile_end_ok(Ei, c, false, false) || !tile_end_ok(Ej, cq, false, false)) st = 2;
+                            qw = Ej.slot;
+                        }
                     }
                 }
-                emit(hit, j, q, st, 0u);
+                emit(hit, j, qw, st, 0u);
             }
         }
         if (FILL && copy) {
@@ -719,7 +767,7 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                     if (to_fb[s3]) {
                         if (dst < P.fb_cap) P.fpairs[dst] = make_uint2(swap ? j : i, swap ? i : j);
                     } else if (dst < P.max_pairs) {
-                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : p, (swap ? p : q) | (cls << kClassShift));
+                        P.rawp[dst] = make_uint4(swap ? j : i, swap ? i : j, swap ? q : Ei.slot, (swap ? Ei.slot : q) | (cls << kClassShift));
                     }
                 }
             }
@@ -1600,8 +1648,8 @@ __global__ __launch_bounds__(kBlock, SFX_NARROW_WAVES) void k_narrow(TileArrays 
         }
         PairRec r;
         const float4 pa = B.pose[a], pb = B.pose[b], sa = B.shape[a], sb = B.shape[b];
-        // the masses are the BODIES' (a further collider has none of its own; only fallback pairs name one of a dynamic body)
-        const float2 wa = B.mass[j < ntp ? a : body_of(B, a)], wb = B.mass[j < ntp ? b : body_of(B, b)];
+        // the masses are the BODIES' (a further collider has none of its own)
+        const float2 wa = B.mass[body_of(B, a)], wb = B.mass[body_of(B, b)];
         prepare_pair(pa, sa, B.vel[a], wa, pb, sb, B.vel[b], wb, shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, vthr, r);
         store_record(C, slot, r);
     }
@@ -1843,7 +1891,7 @@ __device__ __forceinline__ uint32_t phase_total(const Counters* __restrict__ ctr
 // then the argument above needs every workgroup of the grid on the device, which the host can promise only while
 // no other world runs fused launches on the same device (sfx_host.hip: live worlds per device, SFX_SHARED_DEVICE).
 // kTileSlot: which of the two ticket counters this launch uses.
-constexpr int kTileFallback = 1, kTileStaticFirst = 2, kTileSlot = 4;
+constexpr int kTileFallback = 1, kTileStaticFirst = 2, kTileSlot = 4, kTileRaceSelfTest = 8;
 
 __device__ __forceinline__ uint32_t* ticket_of(Counters* __restrict__ ctr, int flags) {
     return &ctr->item_ticket[(flags & kTileSlot) ? 1 : 0];
@@ -1936,6 +1984,27 @@ __device__ __forceinline__ void publish_batch(const TileArrays& T, const GridPar
         __hip_atomic_store(&T.done[ph * g.pstride + it], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Device-side race detector ("a debug kernel that asserts no body index is touched twice per colour";
+// builds with -DSFX_DEBUG_RACES: libsfx_races.so).  The colouring is what makes the solves race-free: within one colour no
+// two pairs write the same body.  Here every write of a body's LDS record inside a colour step first stamps the body's
+// slot with (colour + 1) by an atomic exchange; finding the same stamp already there means a second writer in that colour
+// and sets overflow bit 256, which the next sfx_sync reports.  Statics are read, never written: not stamped.  The stamps
+// of a batch start at zero.  kTileRaceSelfTest (host: SFX_RACE_SELFTEST=1) stamps every write twice: the report path itself.
+#ifdef SFX_DEBUG_RACES
+#define SFX_RACE_DECL __shared__ uint32_t s_stamp[kMaxBX];
+#define SFX_RACE_CLEAR(nb) for (uint32_t l_ = threadIdx.x; l_ < (nb); l_ += blockDim.x) s_stamp[l_] = 0u;
+#define SFX_RACE_WRITE(li, colour)                                                                     \
+    do {                                                                                               \
+        const uint32_t tag_ = (colour) + 1u;                                                           \
+        if (atomicExch(&s_stamp[(li)], tag_) == tag_) atomicOr(&ctr->overflow, kOvfRace);              \
+        if ((flags & kTileRaceSelfTest) && atomicExch(&s_stamp[(li)], tag_) == tag_) atomicOr(&ctr->overflow, kOvfRace); \
+    } while (0)
+#else
+#define SFX_RACE_DECL
+#define SFX_RACE_CLEAR(nb)
+#define SFX_RACE_WRITE(li, colour)
+#endif
+
 // The colour loop of a batch as a flat list of STEPS: a step is one colour's run, or -- when a colour has more pairs than
 // the workgroup has lane pairs -- one chunk of NT / 2 pairs of it; steps of one colour need no barrier between them.  With
 // the list in LDS a lane knows the record slot of any later step, so records are fetched kDepth steps ahead: a record
@@ -1981,6 +2050,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
     __shared__ uint32_t s_gid[kMaxBX];
     __shared__ float2 s_lam[kBatchP];  // the batch's multipliers, written out in one coalesced pass after the colours
     __shared__ uint32_t s_step[kMaxSteps], s_nsteps;
+    SFX_RACE_DECL
     constexpr int kDepth = SFX_DEPTH_POS;
     const uint32_t tid = threadIdx.x;
     const __amdgpu_buffer_rsrc_t dpos_rs = record_rsrc(B.dpos);
@@ -2005,6 +2075,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
             if (ph == 0u) s_d[l] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);   // nothing has moved yet in this substep
         }
         for (uint32_t k = tid; k < npb; k += NT) s_lam[k] = make_float2(0.0f, 0.0f);
+        SFX_RACE_CLEAR(nb)
         __syncthreads();
 #ifdef SFX_PROBE_NOLOOP   // timing probe: a batch without its colour loop (load, hand-off and write-back only; results are wrong)
         const uint32_t ns = 0u;
@@ -2027,6 +2098,8 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         const uint32_t ahead = take_ahead<NT>(ctr, flags);  // the next batch's ticket, in flight during the colour loop
         SFX_TT(tt1);
         SFX_TT(tt2);
+        uint32_t colour = 0u;   // (counts the barriers of the loop: the race detector's stamp)
+        (void)colour;
         auto solve = [&](uint32_t k, SideSlot& p) __attribute__((always_inline)) {  // everything from LDS: no memory wait inside a step
             float4 D = s_d[p.li];
             const float2 w = s_mass[p.li];
@@ -2036,7 +2109,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
             return;
 #endif
             if (solve_pos_side(p.r, D, w, max_corr)) {
-                if (w.x > 0.0f || w.y > 0.0f) s_d[p.li] = D;
+                if (w.x > 0.0f || w.y > 0.0f) { SFX_RACE_WRITE(p.li, colour); s_d[p.li] = D; }
             }
             if (side == 0u) s_lam[k] = make_float2(p.r.l0, p.r.l1);
         };
@@ -2056,7 +2129,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
                         fetch_side<false>(T, C, start + k2, side, nx < ns && k2 < (st2 >> 16), q[u]);
                     }
                     if (cur.valid) solve(k, cur);
-                    if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) lds_barrier();   // the colour's last chunk
+                    if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) { lds_barrier(); ++colour; }   // the colour's last chunk
                 }
             }
         }
@@ -2100,6 +2173,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
     __shared__ float2 s_mass[kMaxBX];
     __shared__ uint32_t s_gid[kMaxBX];
     __shared__ uint32_t s_step[kMaxSteps], s_nsteps;
+    SFX_RACE_DECL
     constexpr int kDepth = SFX_DEPTH_VEL;
     constexpr int kRounds = (int)((kMaxBX + NT - 1) / NT);   // bodies a lane loads (and writes back) per batch, at most
     const uint32_t tid = threadIdx.x;
@@ -2125,6 +2199,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
             s_mass[l] = T.bmass[d.boff + l];
             s_sh[l] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
+        SFX_RACE_CLEAR(nb)
         __syncthreads();
 #ifdef SFX_PROBE_NOLOOP   // timing probe: a batch without its colour loop (load, hand-off and write-back only; results are wrong)
         const uint32_t ns = 0u;
@@ -2165,6 +2240,8 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         __syncthreads();
         const uint32_t ahead = take_ahead<NT>(ctr, flags);
         SFX_TT(tv1);
+        uint32_t colour = 0u;
+        (void)colour;
         auto solve = [&](const SideSlot& p) __attribute__((always_inline)) {
             float4 vs = s_vel[p.li], S = s_sh[p.li];
             const float2 w = s_mass[p.li];
@@ -2174,7 +2251,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
             return;
 #endif
             const int ch = solve_vel_side(p.r, vs, S, w, sp);
-            if (w.x > 0.0f || w.y > 0.0f) { s_vel[p.li] = vs; if (ch & 2) s_sh[p.li] = S; }
+            if (w.x > 0.0f || w.y > 0.0f) { SFX_RACE_WRITE(p.li, colour); s_vel[p.li] = vs; if (ch & 2) s_sh[p.li] = S; }
         };
         for (uint32_t s0 = 0; s0 < ns; s0 += (uint32_t)kDepth) {
 #pragma unroll
@@ -2191,7 +2268,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
                         fetch_side<true>(T, C, start + k2, side, nx < ns && k2 < (st2 >> 16), q[u]);
                     }
                     if (cur.valid) solve(cur);
-                    if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) lds_barrier();
+                    if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) { lds_barrier(); ++colour; }
                 }
             }
         }
@@ -2766,7 +2843,7 @@ __global__ __launch_bounds__(kBlock) void k_query_points(uint32_t nq, const floa
 // appended (query << 32 | body) in no particular order, n_hits counts all of them
 __global__ __launch_bounds__(kBlock) void k_query_aabbs(uint32_t nq, const float4* __restrict__ boxes, uint32_t mask,
                                                          QueryIndex Q, BodyArrays B, unsigned long long* __restrict__ hits,
-                                                         uint32_t cap, uint32_t* __restrict__ n_hits) {
+                                                         uint32_t cap, uint32_t* __restrict__ n_hits, int name_bodies) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * kBlock + threadIdx.x) >> 6, nwaves = (gridDim.x * kBlock) >> 6;
     const uint32_t ns = Q.cell_start[Q.ncell], nl = min(Q.ctr->n_large, Q.large_cap);
@@ -2778,7 +2855,7 @@ __global__ __launch_bounds__(kBlock) void k_query_aabbs(uint32_t nq, const float
             if (!(B.filt[i].x & mask)) return;
             if (!aabb_overlap(Bx, Q.sorted_aabb[slot])) return;
             const uint32_t idx = atomicAdd(n_hits, 1u);
-            if (idx < cap) hits[idx] = ((unsigned long long)k << 32) | i;
+            if (idx < cap) hits[idx] = ((unsigned long long)k << 32) | (name_bodies ? body_of(B, i) : i);
         };
         if (ns && Bx.x <= Bx.z && Bx.y <= Bx.w) {
             const float lox = fkey_inv(~Q.bounds[0]) * Q.inv_cell, hix = fkey_inv(Q.bounds[2]) * Q.inv_cell;

@@ -90,8 +90,10 @@ def default_halo(scene):
     return 4.0 * rmax + 4.0 * (scene.aabb_margin + 0.03)
 
 
-def plan_slabs(scene, nranks, halo=None):
-    """Cuts `scene` into `nranks` slabs.  Returns (plans, boundaries)."""
+def plan_slabs(scene, nranks, halo=None, only_rank=None):
+    """Cuts `scene` into `nranks` slabs.  Returns (plans, boundaries).  only_rank: build that rank's plan alone (the
+    others are None): what a rank of a distributed run needs -- the cuts are global, the lists are its own (at 4 M
+    bodies and 8 ranks all plans take 4 s of numpy per rank, one takes 0.6 s)."""
     if (scene.constraints is not None and len(scene.constraints)) or len(getattr(scene, "angle_constraints", ())):
         raise ValueError("scenes with constraints are not decomposed (chains stay on one GPU)")
     halo = default_halo(scene) if halo is None else float(halo)
@@ -114,7 +116,11 @@ def plan_slabs(scene, nranks, halo=None):
     owner = np.clip(owner, 0, nranks - 1)
     gid = np.arange(scene.n)
     plans = []
+    wanted = range(nranks) if only_rank is None else (only_rank,)
     for r in range(nranks):
+        if r not in wanted:
+            plans.append(None)
+            continue
         lo, hi = bounds[r], bounds[r + 1]
         owned = gid[dyn & (owner == r)]
         ghost_l = gid[dyn & (owner == r - 1) & (x + rad > lo - halo)] if r > 0 else gid[:0]
@@ -127,23 +133,21 @@ def plan_slabs(scene, nranks, halo=None):
         ids = np.concatenate([owned, ghost_l, ghost_r, fixed])
         plans.append(SlabPlan(r, nranks, float(lo), float(hi), ids, len(owned)))
     # send lists mirror the neighbours' ghost lists (ascending global id on both sides)
-    for r in range(nranks):
+    for r in wanted:
         p = plans[r]
-        local = {int(g): k for k, g in enumerate(p.ids[:p.n_owned])}
+        owned = p.ids[:p.n_owned]                       # ascending global ids: local index = position in this list
         no, nl = p.n_owned, 0
         if r > 0:
             gl = dyn & (owner == r - 1) & (x + rad > p.lo - halo)
             nl = int(gl.sum())
             p.recv_left = np.arange(no, no + nl, dtype=np.uint32)
-            q = plans[r - 1]
-            want = gid[dyn & (owner == r) & (x - rad < q.hi + halo)]          # what r-1 ghosts from r
-            p.send_left = np.array([local[int(g)] for g in want], np.uint32)
+            want = gid[dyn & (owner == r) & (x - rad < bounds[r] + halo)]     # what r-1 ghosts from r (its hi = this lo)
+            p.send_left = np.searchsorted(owned, want).astype(np.uint32)
         if r + 1 < nranks:
             gr = dyn & (owner == r + 1) & (x - rad < p.hi + halo)
             p.recv_right = np.arange(no + nl, no + nl + int(gr.sum()), dtype=np.uint32)
-            q = plans[r + 1]
-            want = gid[dyn & (owner == r) & (x + rad > q.lo - halo)]          # what r+1 ghosts from r
-            p.send_right = np.array([local[int(g)] for g in want], np.uint32)
+            want = gid[dyn & (owner == r) & (x + rad > bounds[r + 1] - halo)] # what r+1 ghosts from r (its lo = this hi)
+            p.send_right = np.searchsorted(owned, want).astype(np.uint32)
     return plans, bounds
 
 
@@ -342,9 +346,8 @@ class DistSlab:
     def _build(self, scene):
         torch, dist, device_index = self.torch, self.dist, self.device_index
         self.scene = scene
-        plans, self.bounds = plan_slabs(scene, self.nranks, self.halo)
+        plans, self.bounds = plan_slabs(scene, self.nranks, self.halo, only_rank=self.rank)
         self.plan = plans[self.rank]
-        self.all_plans = plans
         self.world = self.engine.from_scene(local_scene(scene, self.plan), **self.cfg_kw)
         self.world.halo_set(self.plan.send_idx, self.plan.recv_idx)
         self.device_guard = arm_guard(self.world, self.halo)

@@ -217,6 +217,17 @@ class World(WorldBase):
         self._check(self.lib.sfx_query_points_static(self.handle, n, C.c_void_p(points_dev), mask, C.c_void_p(body_dev),
                                                      C.c_void_p(count_dev or None)))
 
+    def query_aabbs_device(self, boxes_dev, n, hits_dev, cap, n_hits_dev, mask=0xFFFFFFFF):
+        """sfx_query_aabbs_device: device addresses (ints) of [n][4] float boxes, `cap` uint64 hit keys (query << 32 | body,
+        unordered) and one uint32 for the full hit count; enqueues on the world's stream, does not synchronise."""
+        self._check(self.lib.sfx_query_aabbs_device(self.handle, n, C.c_void_p(boxes_dev), mask, C.c_void_p(hits_dev or None), cap,
+                                                    C.c_void_p(n_hits_dev)))
+
+    def query_rays_device(self, rays_dev, max_t_dev, n, hits_dev, mask=0xFFFFFFFF):
+        """sfx_query_rays_device: device addresses of [n][4] float rays, [n] float max_t and [n] sfx_ray_hit records."""
+        self._check(self.lib.sfx_query_rays_device(self.handle, n, C.c_void_p(rays_dev), C.c_void_p(max_t_dev), mask,
+                                                   C.c_void_p(hits_dev)))
+
     # ---- parity hooks
     def broadphase(self, dt):
         self._check(self.lib.sfx_debug_broadphase(self.handle, dt))

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(libsfx):
     assert sorted(_abi.SFX_SYMBOLS) == syms, "starframe_amd/_abi.py symbol list out of date"
     for s in syms:
         assert hasattr(libsfx, s), f"libsfx.so does not export {s}"
-    assert libsfx.sfx_abi_version() == 9
+    assert libsfx.sfx_abi_version() == 10
 
 
 def test_rccl_library_exports_its_header():
@@ -156,3 +156,25 @@ def test_product_package_does_not_touch_the_oracle():
                 assert "libsfx_oracle" not in text and "dlopen" not in text, f
     out = subprocess.check_output(["ldd", _abi.LIBSFX_PATH]).decode()
     assert "oracle" not in out
+
+
+def test_shipped_library_is_built_from_the_tree_s_sources(libsfx):
+    """what was compiled must be unambiguous.  The library carries the hash of the sources it was
+    compiled from (sfx_build_id); it equals the hash of the tree's sources, so build() has nothing to do."""
+    from starframe_amd import build
+
+    assert build.built_id() == build.source_hash(), "starframe_amd/csrc/libsfx.so was not built from this tree: run __graft_entry__.build()"
+    assert not build.needs_build()
+
+
+def test_forced_rebuild_compiles_the_tree(tmp_path):
+    """build(force=True) compiles whatever is there (hipcc cross-compiles gfx950 without a GPU): the fresh library carries
+    this tree's build id and exports the whole header."""
+    from starframe_amd import build
+
+    out = str(tmp_path / "libsfx_forced.so")
+    assert build.build(force=True, out=out) == out
+    assert build.built_id(out) == build.source_hash()
+    lib = C.CDLL(out)
+    for s in declared_symbols():
+        assert hasattr(lib, s), s

@@ -120,3 +120,48 @@ def test_empty_and_degenerate_queries():
     assert np.array_equal(gh["body"], oh["body"]) and np.array_equal(gh["t"], oh["t"])
     assert gh["body"].tolist() == [0, NO_BODY, 0, 0] and gh["t"][0] == 9.0 and gh["t"][3] == 0.0
     assert np.array_equal(g2.query_points([[0, 0], [0, 5]])[0], o2.query_points([[0, 0], [0, 5]])[0])
+
+
+def test_device_pointer_box_and_ray_queries_equal_the_host_ones():
+    """sfx_query_aabbs_device / sfx_query_rays_device: inputs and outputs in device memory (plain
+    hipMalloc buffers here), enqueued on the world's stream without a synchronisation; the answers are those of the
+    host-array calls -- box hits as a set (the device call neither sorts nor merges a body's colliders), ray hits record
+    for record.  Includes a soup with compound bodies (hits name bodies, not colliders)."""
+    from starframe_amd._abi import ray_hit_dtype
+    from starframe_amd.world import World
+    from tests.hipmem import Hip
+
+    hip = Hip()
+    for kw in (dict(), dict(compounds=0.3)):
+        s = scenes.random_soup(1500, seed=21, extent=8.0, **kw)
+        w = World.from_scene(s)
+        w.step(DT)
+        pts, boxes, rays, max_t = query_inputs(21, 8.0, n=700, near=w.poses()[0])
+        d_boxes = hip.to_device(np.ascontiguousarray(boxes, np.float32))
+        d_rays = hip.to_device(np.ascontiguousarray(rays, np.float32))
+        d_mt = hip.to_device(np.ascontiguousarray(np.broadcast_to(np.asarray(max_t, np.float32), (len(rays),))))
+        d_n = hip.malloc(4)
+        for mask in (0xFFFFFFFF, 2):
+            ref_hits = w.query_aabbs(boxes, mask)
+            ref_rays = w.query_rays(rays, max_t, mask)
+            cap = max(2 * len(ref_hits), 64)
+            d_hits = hip.malloc(8 * cap)
+            d_out = hip.malloc(len(rays) * ray_hit_dtype.itemsize)
+            hip.fill(d_n, 0x5A, 4)
+            w.query_aabbs_device(d_boxes, len(boxes), d_hits, cap, d_n, mask)
+            w.query_rays_device(d_rays, d_mt, len(rays), d_out, mask)
+            w.sync()   # the calls only enqueue
+            n = int(hip.to_host(d_n, np.uint32, 1)[0])
+            assert n <= cap and n >= len(ref_hits)
+            got = np.unique(hip.to_host(d_hits, np.uint64, cap)[:n])
+            assert np.array_equal(got, ref_hits)
+            out = hip.to_host(d_out, np.uint8, len(rays) * ray_hit_dtype.itemsize).view(ray_hit_dtype)
+            assert np.array_equal(out["body"], ref_rays["body"])
+            assert np.array_equal(out["t"], ref_rays["t"]) and np.array_equal(out["normal"], ref_rays["normal"])
+        # capacity: the full count comes back, the buffer holds `cap` of the hits
+        small = hip.malloc(8 * 4)
+        w.query_aabbs_device(d_boxes, len(boxes), small, 4, d_n)
+        w.sync()
+        assert int(hip.to_host(d_n, np.uint32, 1)[0]) > 4
+        w.close()
+        hip.free_all()

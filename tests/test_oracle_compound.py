@@ -142,9 +142,10 @@ def test_queries_name_the_body_of_the_collider_hit():
     w.close()
 
 
-@pytest.mark.parametrize("seed", [3, 4])
-def test_soup_of_compounds_three_pair_enumerations_agree_and_it_runs(seed):
-    s = random_soup(250, seed=seed, offsets=0.3, compounds=0.3)
+@pytest.mark.parametrize("seed,n,extent", [(3, 250, None), (4, 250, None), (37, 2000, 9.0)])
+def test_soup_of_compounds_three_pair_enumerations_agree_and_it_runs(seed, n, extent):
+    """(250 bodies: the whole grid is one tile; 2000: many tiles, seams and corners)"""
+    s = random_soup(n, seed=seed, offsets=0.3, compounds=0.3, **({} if extent is None else {"extent": extent}))
     assert s.n_colliders > s.n + 40
     w = OracleWorld.from_scene(s)
     w.broadphase(DT)
@@ -158,8 +159,22 @@ def test_soup_of_compounds_three_pair_enumerations_agree_and_it_runs(seed):
     ka, kb = (keys >> np.uint64(32)).astype(np.int64), (keys & np.uint64(0xFFFFFFFF)).astype(np.int64)
     dyn = (s.inv_mass > 0) | (s.inv_inertia > 0)
     further_dyn = lambda e: (e >= s.n) & dyn[body[e]]
-    must_fb = further_dyn(ka) | further_dyn(kb)
-    assert must_fb.sum() > 20 and np.all(tiles[must_fb] == FALLBACK)
+    # pairs of a further collider of a dynamic body: in a tile's list when the collider sits beside its body's first one
+    # (oracle/sfx_oracle.c tile_end_ok), else on the fallback list -- both happen in a soup
+    cmp_ = further_dyn(ka) | further_dyn(kb)
+    in_tiles = cmp_ & (tiles != FALLBACK)
+    assert cmp_.sum() > 20 and in_tiles.sum() > 10
+    if n >= 2000:
+        assert (cmp_ & (tiles == FALLBACK)).sum() > 50 and in_tiles.sum() > 8 * (cmp_ & (tiles == FALLBACK)).sum()
+        assert len(np.unique(tiles[tiles != FALLBACK] >> 28)) >= 2   # (strips here: interior and x seam)
+    # what the rule is for: the units (tile, class) of ONE class share no dynamic body -- they are solved side by side
+    for cls in range(4):
+        owner = {}
+        sel = (tiles != FALLBACK) & ((tiles >> 28) == cls) & (colors < 0xFE)
+        for x, y, u in zip(body[ka[sel]], body[kb[sel]], tiles[sel]):
+            for v in (x, y):
+                if dyn[v]:
+                    assert owner.setdefault(int(v), int(u)) == int(u), (cls, v, u, owner[int(v)])
     # colours: two pairs of one unit that share a dynamic BODY never share a colour
     PRUNED = 0xFE
     for unit in np.unique(tiles):
@@ -170,8 +185,7 @@ def test_soup_of_compounds_three_pair_enumerations_agree_and_it_runs(seed):
                 if dyn[v]:
                     assert (v, c) not in seen, (unit, v, c)
                     seen.add((v, c))
-    e0 = None
-    for _ in range(60):
+    for _ in range(60 if n < 2000 else 10):
         w.step(DT)
     pos, rot = w.poses()
     assert np.isfinite(pos).all() and np.isfinite(rot).all() and pos.shape[0] == s.n

@@ -4,54 +4,17 @@ world with fewer points, so that anything the first call left in the static scra
 
 Device memory for the inputs and outputs comes from the HIP runtime directly (ctypes on libamdhip64): the
 entry point takes device pointers and must not see an allocation of its own."""
-import ctypes as C
-
 import numpy as np
 import pytest
 
 from starframe_amd import scenes
 from starframe_amd._abi import SFX_ERR_INVALID, SFX_ERR_UNSUPPORTED
+from tests.hipmem import Hip
 from tests.test_oracle_queries import query_inputs
 
 pytestmark = pytest.mark.gpu
 
 DT = 1.0 / 60.0
-H2D, D2H = 1, 2
-
-
-class Hip:
-    def __init__(self):
-        self.lib = C.CDLL("libamdhip64.so")
-        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
-        self.lib.hipFree.argtypes = [C.c_void_p]
-        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-        self.lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
-        self.bufs = []
-
-    def malloc(self, nbytes):
-        p = C.c_void_p()
-        assert self.lib.hipMalloc(C.byref(p), max(nbytes, 16)) == 0
-        self.bufs.append(p)
-        return p.value
-
-    def to_device(self, arr):
-        a = np.ascontiguousarray(arr)
-        p = self.malloc(a.nbytes)
-        assert self.lib.hipMemcpy(p, a.ctypes.data, a.nbytes, H2D) == 0
-        return p
-
-    def to_host(self, p, dtype, count):
-        out = np.empty(count, dtype)
-        assert self.lib.hipMemcpy(out.ctypes.data, p, out.nbytes, D2H) == 0   # blocking: ordered after the null stream only
-        return out
-
-    def fill(self, p, byte, nbytes):
-        assert self.lib.hipMemset(p, byte, nbytes) == 0
-
-    def free_all(self):
-        for p in self.bufs:
-            self.lib.hipFree(p)
-        self.bufs = []
 
 
 def static_query(hip, w, pts, mask=0xFFFFFFFF, with_count=True):
@@ -60,7 +23,11 @@ def static_query(hip, w, pts, mask=0xFFFFFFFF, with_count=True):
     d_body, d_count = hip.malloc(4 * n), hip.malloc(4 * n)
     hip.fill(d_body, 0xEE, 4 * n)
     hip.fill(d_count, 0xEE, 4 * n)
+    # the property the entry point exists for: the call allocates nothing -- the device's free memory is the
+    # same before and after it (a lazily allocated buffer on this path would show here)
+    before = hip.free_bytes()
     w.query_points_static(d_pts, n, d_body, d_count if with_count else 0, mask)
+    assert hip.free_bytes() == before, "sfx_query_points_static changed the device's free memory: it allocated"
     w.sync()   # the call only enqueues on the world's stream
     return hip.to_host(d_body, np.uint32, n), hip.to_host(d_count, np.uint32, n)
 
