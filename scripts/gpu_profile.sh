@@ -13,7 +13,7 @@ timeout -k 10 300 python bench.py > $OUT/bench.json 2> $OUT/bench.err || { tail 
 cat $OUT/bench.json
 step rocprof-same
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_same -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || { tail -20 $OUT/bench_under_rocprof.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_same -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-survey-scene > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err || { tail -20 $OUT/bench_under_rocprof.err; exit 1; }
 cd $GRAFT_REPO_ROOT
 python scripts/trace_window.py $(find $OUT/prof_same -name 'bench_kernel_trace.csv' | head -1) 200 70 > $OUT/bench_kernel_trace_settled.txt 2>&1 || true
 cp $(find $OUT/prof_same -name 'bench_kernel_stats.csv' | head -1) $OUT/bench_kernel_stats.csv 2>/dev/null || true

@@ -19,7 +19,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p
 cat $OUT/bench_rocprof.json
 step rocprof-same
 # the default bench command itself under the kernel trace (CPU leg off): scripts/trace_window.py reads its settled ticks
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_same -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu > $OUT/bench_rocprof_same.json 2> $OUT/bench_rocprof_same.err || { tail -20 $OUT/bench_rocprof_same.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_same -o bench -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu --no-survey-scene > $OUT/bench_rocprof_same.json 2> $OUT/bench_rocprof_same.err || { tail -20 $OUT/bench_rocprof_same.err; exit 1; }
 step native
 cd $GRAFT_REPO_ROOT
 timeout -k 10 120 tools/sfx_run data/pile100k.bin 200 400 > $OUT/sfx_run.log 2>&1 || { tail $OUT/sfx_run.log; exit 1; }

@@ -16,7 +16,7 @@ import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     n = r["Name"].split("(")[0].replace("void sfx::", "")[:40]
-    if any(k in n for k in ("k_tile", "k_narrow", "k_integrate", "k_batch_color", "k_derive")):
+    if "k_" in n:
         print(f"   {n:40s} calls {r['Calls']:>6s} avg {float(r['AverageNs'])/1e3:8.2f} us  min {float(r['MinNs'])/1e3:8.2f}  max {float(r['MaxNs'])/1e3:8.2f}")
 PY
 done

@@ -49,18 +49,20 @@ def source_hash():
 
 
 def built_id(path=None):
-    """sfx_build_id() of a built library (None when it is missing, or older than the build id)."""
-    import ctypes
-
+    """The build id of a built library -- what its sfx_build_id() returns -- read from the file (None when it is missing or
+    older than the build id).  Not by loading it: a process that asks, rebuilds and then loads the library would get the
+    copy it loaded first."""
     path = path or OUT
     if not os.path.exists(path):
         return None
-    try:
-        lib = ctypes.CDLL(path)
-        lib.sfx_build_id.restype = ctypes.c_char_p
-        return lib.sfx_build_id().decode()
-    except (OSError, AttributeError):
+    marker = b"sfx-build-id:"
+    with open(path, "rb") as fh:
+        data = fh.read()
+    at = data.find(marker)
+    if at < 0:
         return None
+    end = data.find(b"\0", at)
+    return data[at + len(marker):end].decode(errors="replace")
 
 
 def needs_build():

@@ -494,6 +494,10 @@ void color_global(sfx_world* w, const uint2* edges, const uint32_t* n_edges, uin
     hipLaunchKernelGGL(k_color_global, dim3(1), dim3(kGlobalColorBlock), 0, w->stream, A);
 }
 
+#ifndef SFX_COLOR_Z   // workgroups that colour the batches of one group of tiles side by side (build knob for probes)
+#define SFX_COLOR_Z(group) ((group) > 1u ? 2u : 1u)
+#endif
+
 int broadphase(sfx_world* w, float dt) {
     const uint32_t n = w->n;
     const GridParams g = grid_params(w);
@@ -531,8 +535,10 @@ int broadphase(sfx_world* w, float dt) {
     // one 8-lane group per slot: 32 slots per block
     const uint32_t gp = std::min(std::max(cdiv(n + 1, kBlock / kGroup), 1u), 8192u);
     { Prof p(w, SFX_K_PAIR_COUNT, n);
-      hipLaunchKernelGGL(k_pairs<false>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
-                         w->sorted_aabb.p, w->sorted_cell.p, w->sorted_filt.p, P, w->ctr, w->large_cap); }
+      if (slot_of) hipLaunchKernelGGL((k_pairs<false, true>), dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
+                                      w->sorted_aabb.p, w->sorted_cell.p, w->sorted_filt.p, P, w->ctr, w->large_cap);
+      else hipLaunchKernelGGL((k_pairs<false, false>), dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
+                              w->sorted_aabb.p, w->sorted_cell.p, w->sorted_filt.p, P, w->ctr, w->large_cap); }
     { Prof p(w, SFX_K_TILE_LIST, w->ntiles);
       if (n / std::max(w->ntiles, 1u) >= 32u)
           hipLaunchKernelGGL(k_tile_count<64>, dim3(cdiv(w->ntiles, kBlock / 64)), dim3(kBlock), 0, w->stream, g, w->cell_start,
@@ -552,8 +558,10 @@ int broadphase(sfx_world* w, float dt) {
       if (rc) return rc;
     }
     { Prof p(w, SFX_K_PAIR_FILL, n);
-      hipLaunchKernelGGL(k_pairs<true>, dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
-                         w->sorted_aabb.p, w->sorted_cell.p, w->sorted_filt.p, P, w->ctr, w->large_cap); }
+      if (slot_of) hipLaunchKernelGGL((k_pairs<true, true>), dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
+                                      w->sorted_aabb.p, w->sorted_cell.p, w->sorted_filt.p, P, w->ctr, w->large_cap);
+      else hipLaunchKernelGGL((k_pairs<true, false>), dim3(gp), dim3(kBlock), 0, w->stream, n, g, w->cell_start, w->sorted_id.p,
+                              w->sorted_aabb.p, w->sorted_cell.p, w->sorted_filt.p, P, w->ctr, w->large_cap); }
     ReachParams RP;
     RP.pose = w->pose.p; RP.vel = w->vel.p; RP.lpose = w->lpose.p; RP.poly = w->poly.p;
     RP.margin = w->cfg.aabb_margin; RP.vel_pad_max = w->cfg.vel_pad_max; RP.dt = dt; RP.sm = w->cfg.speculative_margin;
@@ -562,7 +570,7 @@ int broadphase(sfx_world* w, float dt) {
       hipLaunchKernelGGL(k_reach, dim3(cdiv(std::min(est, w->max_pairs), kBlock)), dim3(kBlock), 0, w->stream, w->tile_cnt,
                          w->ntiles, w->max_pairs, w->rawp.p, w->shape.p, RP); }
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
-      hipLaunchKernelGGL(k_batch_color<kBatchP>, dim3(w->color_grid, (w->tly == w->gyl) ? 2u : 4u, w->group > 1u ? 2u : 1u), dim3(kColorThreads), 0, w->stream, g, w->group,
+      hipLaunchKernelGGL(k_batch_color<kBatchP>, dim3(w->color_grid, (w->tly == w->gyl) ? 2u : 4u, SFX_COLOR_Z(w->group)), dim3(kColorThreads), 0, w->stream, g, w->group,
                          w->cell_start, w->sorted_id.p, w->sorted_filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
                          w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->bbody.p, (uint32_t)w->bbody.n, w->mass.p, w->bmass.p, w->bruns.p, (uint32_t)(w->bruns.n / 64), w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
@@ -674,7 +682,10 @@ uint32_t sfx_abi_version(void) { return SFX_ABI_VERSION; }
 #ifndef SFX_BUILD_ID
 #define SFX_BUILD_ID "unknown"
 #endif
-const char* sfx_build_id(void) { return SFX_BUILD_ID; }
+// (the id sits behind a marker so that starframe_amd/build.py can read it from the FILE: loading the library to ask it
+// would pin the old copy in a process that then rebuilds it)
+static const char g_build_marker[] = "sfx-build-id:" SFX_BUILD_ID;
+const char* sfx_build_id(void) { return g_build_marker + 13; }
 
 void sfx_default_config(sfx_config* cfg) {
     if (!cfg) return;

@@ -544,7 +544,9 @@ __device__ __forceinline__ bool tile_end_ok(const TileEnd& e, int2 c, bool ddx, 
     return e.ok && (!ddx || e.cell.x == c.x) && (!ddy || e.cell.y == c.y);
 }
 
-template <bool FILL>
+// CMP: the world has dynamic bodies with further colliders (P.slot_of is there); without them no filter word carries
+// kFiltFurther and the candidate loop is compiled without the lookups (they cost the count pass 4.6 us of 29 on the pile)
+template <bool FILL, bool CMP>
 __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, const uint32_t* __restrict__ cell_start,
                                                    const uint32_t* __restrict__ sorted_id,
                                                    const float4* __restrict__ sorted_aabb,
@@ -570,7 +572,9 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
         if (live) { i = sorted_id[p]; Ai = sorted_aabb[p]; fi = sorted_filt[p]; c = sorted_cell[p]; }
         const int32_t txp = c.x >> g.tlx, typ = c.y >> g.tly;
         const uint32_t T0 = tile_of(txp, typ, g), T1 = tile_of(txp - 1, typ, g);
-        const TileEnd Ei = tile_end(p, c, fi, ns, g, P.slot_of, sorted_cell);   // (p itself unless a further collider of a dynamic body)
+        TileEnd Ei;   // (p itself unless a further collider of a dynamic body)
+        Ei.slot = p; Ei.cell = c; Ei.ok = true;
+        if constexpr (CMP) Ei = tile_end(p, c, fi, ns, g, P.slot_of, sorted_cell);
         // stream bases (fill pass): lane 0 of the group reserves, the group reads them by shuffle
         uint32_t base[3] = {0u, 0u, 0u};
         bool to_fb[3] = {false, false, true};
@@ -693,14 +697,15 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                     j = jq;
                     hit = pair_filter(fi, fj);
                     if (r == 5 && small_slot && (fj.w & kFiltDynamic)) st = 2;  // small against a large dynamic collider
-                    if (hit && ((fi.w | fj.w) & kFiltFurther)) {   // a further collider of a dynamic body: in the tiles when it sits beside its body
-                        const TileEnd Ej = tile_end(q, cq, fj, ns, g, P.slot_of, sorted_cell);
-                        if (!tile_end_ok(Ei, c, ddx, ddy) || !tile_end_ok(Ej, cq, ddx, ddy)) st = 2;
-                        qw = Ej.slot;
+                    if constexpr (CMP) {
+                        if (hit && ((fi.w | fj.w) & kFiltFurther)) {   // a further collider of a dynamic body: in the tiles when it sits beside its body
+                            const TileEnd Ej = tile_end(q, cq, fj, ns, g, P.slot_of, sorted_cell);
+                            if (!tile_end_ok(Ei, c, ddx, ddy) || !tile_end_ok(Ej, cq, ddx, ddy)) st = 2;
+                            qw = Ej.slot;
+                        }
                     }
                 }
             }
-            if (st == 2) cls = 0u;
             emit(hit, j, qw, st, cls);
         }
         // Second level: a small slot against the medium colliders homed in the level-1 cells [c1(lo) - 1, c1(hi)] on both
@@ -746,10 +751,12 @@ __global__ __launch_bounds__(kBlock) void k_pairs(uint32_t n, GridParams g, cons
                         j = jq;
                         hit = pair_filter(fi, fj);
                         if (fj.w & kFiltDynamic) st = 2;
-                        if (hit && ((fi.w | fj.w) & kFiltFurther)) {
-                            const TileEnd Ej = tile_end(q, cq, fj, ns, g, P.slot_of, sorted_cell);   // (a medium slot: never ok)
-                            if (!tile_end_ok(Ei, c, false, false) || !tile_end_ok(Ej, cq, false, false)) st = 2;
-                            qw = Ej.slot;
+                        if constexpr (CMP) {
+                            if (hit && ((fi.w | fj.w) & kFiltFurther)) {
+                                const TileEnd Ej = tile_end(q, cq, fj, ns, g, P.slot_of, sorted_cell);   // (a medium slot: never ok)
+                                if (!tile_end_ok(Ei, c, false, false) || !tile_end_ok(Ej, cq, false, false)) st = 2;
+                                qw = Ej.slot;
+                            }
                         }
                     }
                 }
@@ -1009,6 +1016,9 @@ struct ReachParams {
 // Reach test of every tile-owned pair (DESIGN.md "Contract / solver pairs"), one pair per lane:
 // a pair that cannot touch in this tick gets bit 31 of its first slot word set.
 constexpr uint32_t kOutOfReach = 0x80000000u;
+// ... and its shape-pair class (circle-circle 2, circle-core 1, core-core 0, anything with a POLY 3: the narrowphase order
+// of k_batch_color) in bits 28..29 of the same word: k_reach has the shapes in hand, the colouring would gather them again
+constexpr uint32_t kShapeClassShift = 28u, kSlotWordMask = (1u << 24) - 1u;
 constexpr uint32_t kNoPair = 0xFFFFFFFFu;  // torder entry of a pair that is not solved this tick
 
 __global__ __launch_bounds__(kBlock) void k_reach(const uint32_t* __restrict__ tile_start, uint32_t ntiles, uint32_t max_pairs,
@@ -1022,7 +1032,10 @@ __global__ __launch_bounds__(kBlock) void k_reach(const uint32_t* __restrict__ t
         motion_pads(RP.vel[rp.y], sb, RP.lpose, rp.y, RP.margin, RP.vel_pad_max, RP.dt, pbx, pby);
         const bool keep = pair_in_reach(shape_pose(RP.pose[rp.x], sa, RP.lpose, rp.x), sa, sqrtf(pax * pax + pay * pay),
                                         shape_pose(RP.pose[rp.y], sb, RP.lpose, rp.y), sb, sqrtf(pbx * pbx + pby * pby), RP.poly, RP.sm);
-        if (!keep) rawp[k].z = rp.z | kOutOfReach;
+        const uint32_t ta = __float_as_uint(sa.x) & 0xFFu, tb = __float_as_uint(sb.x) & 0xFFu;
+        const uint32_t ncirc = (ta == SFX_SHAPE_CIRCLE ? 1u : 0u) + (tb == SFX_SHAPE_CIRCLE ? 1u : 0u);
+        const uint32_t scl = (ta == SFX_SHAPE_POLY || tb == SFX_SHAPE_POLY) ? 3u : 2u - ncirc;
+        rawp[k].z = rp.z | (keep ? 0u : kOutOfReach) | (scl << kShapeClassShift);
     }
 }
 
@@ -1063,7 +1076,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
     static_assert(2 * MP * sizeof(uint16_t) <= MB * kClaim * sizeof(unsigned long long), "leftover lists alias s_claim");
     uint16_t* const s_left = reinterpret_cast<uint16_t*>(s_claim);
     uint16_t* const s_srt = s_left + MP;
-    __shared__ uint8_t s_col[MP], s_prop[MP], s_tj[MP];
+    __shared__ uint8_t s_col[MP], s_scl[MP], s_tj[MP];   // colour, shape-pair class (from k_reach), tile of the batch
     __shared__ uint32_t s_hist[SFX_MAX_COLORS], s_base[SFX_MAX_COLORS];
     __shared__ uint32_t s_nleft, s_ovf, s_bstart, s_nbat, s_npruned, s_ptail, s_ptail_first;
     __shared__ uint32_t s_cls[4];
@@ -1139,7 +1152,8 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                 if ((rp.w >> kClassShift) != cls) continue;
                 const uint32_t e = atomicAdd(&s_np, 1u);
                 s_a[e] = rp.x; s_b[e] = rp.y;
-                s_la[e] = (uint16_t)batch_local(S, j, rp.z & ~kOutOfReach);
+                s_la[e] = (uint16_t)batch_local(S, j, rp.z & kSlotWordMask);
+                s_scl[e] = (uint8_t)((rp.z >> kShapeClassShift) & 3u);
                 s_lb[e] = (uint16_t)batch_local(S, j, rp.w & kSlotMask);
                 s_tj[e] = (uint8_t)j;
                 const bool keep = !(rp.z & kOutOfReach);
@@ -1202,6 +1216,9 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                     bmass[s_boff + s_remap[l]] = mass[id];   // the masses in list order: the tile solves fetch them beside the ids, not after them
                 }
             SFX_TT(tc1);
+#if defined(SFX_PROBE_COLOR_STAGE) && SFX_PROBE_COLOR_STAGE == 1   // timing probe: a batch ends after its set-up (results are wrong)
+            continue;
+#endif
 #define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
             // A thread owns the same (at most MP / threads) edges in every round: their ends, keys, dynamic flags, colour and
             // proposal stay in registers, so a round is one LDS read (the ends' used colours / the claims) and one LDS
@@ -1261,6 +1278,9 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                 any_open = __syncthreads_or(open_edges);
             }
             SFX_TT(tc2);
+#if defined(SFX_PROBE_COLOR_STAGE) && SFX_PROBE_COLOR_STAGE == 2   // ... after the colouring rounds
+            continue;
+#endif
             // serial first-fit finish over the leftovers, ascending key
             for (uint32_t e = tid; e < np; e += kBlock)
                 if (s_col[e] == SFX_NO_COLOR) s_left[atomicAdd(&s_nleft, 1u)] = (uint16_t)e;
@@ -1295,6 +1315,19 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
             }
 #undef TDYN
             SFX_TT(tc3);
+#if defined(SFX_PROBE_COLOR_STAGE) && SFX_PROBE_COLOR_STAGE == 3   // ... after the serial finish
+            continue;
+#endif
+            // the batch's places in the colour-run table, the pair list and the phase's batch table: the three returning
+            // atomics leave together and come back while the histogram below is made (one after the other, each behind its
+            // own wait, they were three round trips on the batch's chain; reserved at the START of a batch they made every
+            // workgroup queue for its body-list offset: + 9 us, measured)
+            uint32_t r_roff = 0u, r_bstart = 0u, r_bidx = 0u;
+            if (tid == 0) {
+                r_roff = atomicAdd(&ctr->run_cursor, 1u);
+                r_bstart = atomicAdd(&ctr->tp_cursor, np);
+                r_bidx = atomicAdd(&ctr->n_batches[cls], 1u);
+            }
             // colour-major order inside the batch (uncoloured pairs last)
             for (uint32_t e = tid; e < np; e += kBlock) {
                 const uint32_t cc = s_col[e];
@@ -1309,9 +1342,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                 const uint64_t usedc = __ballot(hc != 0u);
                 const uint32_t nc = usedc ? 64u - (uint32_t)__builtin_clzll(usedc) : 0u;
                 const uint32_t run = (uint32_t)__shfl((int)inc, 63, 64);
-                uint32_t roff = 0u;
-                if (tid == 0) roff = atomicAdd(&ctr->run_cursor, 1u);
-                roff = (uint32_t)__shfl((int)roff, 0, 64);
+                const uint32_t roff = (uint32_t)__shfl((int)r_roff, 0, 64);
                 if (roff < bruns_cap) bruns[64u * roff + tid] = (inc - hc) | (inc << 16);  // what the tile solves loop over
               if (tid == 0) {
                 s_nleft = run;  // reused: cursor of the uncoloured tail
@@ -1319,13 +1350,13 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                 s_ptail = kept;  // cursor of the pruned pairs behind them
                 s_ptail_first = kept;
                 atomicAdd(&ctr->n_kept, kept);
-                const uint32_t bstart = atomicAdd(&ctr->tp_cursor, np);
+                const uint32_t bstart = r_bstart;
                 s_bstart = bstart;
                 const uint32_t ph = cls;
                 BatchDesc d;
                 d.first = e0 + f;
                 d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nbc + s_next; d.boff = s_boff; d.roff = roff;
-                const uint32_t bidx = atomicAdd(&ctr->n_batches[ph], 1u);
+                const uint32_t bidx = r_bidx;
                 batches[ph * g.pstride + bidx] = d;
                 s_bidx = bidx;
                 atomicMax(&ctr->n_colors, nc);
@@ -1340,14 +1371,10 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
             if (tid < c) tile_batch[cls * g.ntiles + s_tile[f + tid]] = s_bidx + 1u;
             // narrowphase order: the batch's pairs grouped by shape-pair class (circle-circle, circle-
             // polygon core, core-core, anything with a POLY), so that the lanes of a wave take the
-            // same branch of the narrowphase.  s_prop is free now: it keeps the class.
+            // same branch of the narrowphase.  (The class came with the pair: k_reach wrote it.)
             for (uint32_t e = tid; e < np; e += kBlock) {
                 if (s_col[e] == SFX_PRUNED_COLOR) continue;
-                const uint32_t ta = __float_as_uint(shape[s_a[e]].x) & 0xFFu, tb = __float_as_uint(shape[s_b[e]].x) & 0xFFu;
-                const uint32_t nc = (ta == SFX_SHAPE_CIRCLE ? 1u : 0u) + (tb == SFX_SHAPE_CIRCLE ? 1u : 0u);
-                const uint32_t cls = (ta == SFX_SHAPE_POLY || tb == SFX_SHAPE_POLY) ? 3u : 2u - nc;
-                s_prop[e] = (uint8_t)cls;
-                atomicAdd(&s_cls[cls], 1u);
+                atomicAdd(&s_cls[s_scl[e]], 1u);
             }
             __syncthreads();
             if (tid == 0) {
@@ -1374,7 +1401,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                     if (a_out) la = lx; else lb = lx;
                 }
                 tpair[bstart + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), cc | (((cls << 22) | s_tile[f + s_tj[e]]) << 8));
-                if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_prop[e]], 1u)] = make_uint4(s_a[e], s_b[e], bstart + dst, 0u);
+                if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_scl[e]], 1u)] = make_uint4(s_a[e], s_b[e], bstart + dst, 0u);
             }
             for (uint32_t e = s_ptail_first + tid; e < np; e += kBlock) torder[bstart + e] = make_uint4(0u, 0u, kNoPair, 0u);  // pruned pairs: no narrowphase
             __syncthreads();
