@@ -7,7 +7,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const SFX_ABI_VERSION: u32 = 10;
+pub const SFX_ABI_VERSION: u32 = 11;
 
 // sfx_status
 pub const SFX_OK: c_int = 0;
@@ -242,6 +242,8 @@ extern "C" {
     pub fn sfx_halo_download(w: *mut sfx_world, send_host: *mut f32) -> c_int;
     pub fn sfx_halo_upload(w: *mut sfx_world, recv_host: *const f32) -> c_int;
     pub fn sfx_halo_copy(dst: *mut sfx_world, dst_first: u32, src: *mut sfx_world, src_first: u32, count: u32) -> c_int;
+    pub fn sfx_halo_overlap(w: *mut sfx_world, on: c_int) -> c_int;
+    pub fn sfx_halo_stream(w: *mut sfx_world, hip_stream: *mut *mut c_void) -> c_int;
     // state read-back
     pub fn sfx_download_poses(w: *mut sfx_world, pos: *mut f32, rot: *mut f32) -> c_int;
     pub fn sfx_download_velocities(w: *mut sfx_world, vel: *mut f32, angvel: *mut f32) -> c_int;
@@ -269,6 +271,7 @@ extern "C" {
     pub fn sfx_debug_broadphase(w: *mut sfx_world, frame_dt: f32) -> c_int;
     pub fn sfx_debug_contacts(w: *mut sfx_world, out: *mut sfx_contact, cap: usize, n: *mut usize) -> c_int;
     pub fn sfx_debug_joint_order(w: *mut sfx_world, perm: *mut u32, colors: *mut u8, cap: usize, n: *mut usize) -> c_int;
+    pub fn sfx_debug_near_batches(w: *mut sfx_world, n_near: *mut u32, n_batches: *mut u32) -> c_int;
     // reporting
     pub fn sfx_stats(w: *mut sfx_world, out: *mut sfx_frame_stats) -> c_int;
     pub fn sfx_set_profiling(w: *mut sfx_world, on: c_int) -> c_int;

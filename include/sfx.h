@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 10u
+#define SFX_ABI_VERSION 11u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -310,6 +310,19 @@ int sfx_halo_buffers(sfx_world* w, float** send_dev, float** recv_dev);
 int sfx_halo_download(sfx_world* w, float* send_host /* [n_send][8] */);   /* pack + copy, synchronises */
 int sfx_halo_upload(sfx_world* w, const float* recv_host /* [n_recv][8] */); /* copy + unpack */
 int sfx_halo_copy(sfx_world* dst, uint32_t dst_first, sfx_world* src, uint32_t src_first, uint32_t count);
+/* Exchange / compute overlap (SURVEY.md section 5 "overlap it with interior-constraint solving"; DESIGN.md "Multi-GPU /
+ * overlap"; ABI 11).  sfx_halo_overlap(w, 1): every later sfx_tick_substep runs its last kernel, the velocity sweep, as two
+ * launches side by side -- the batches the halo bodies depend on, on a second stream of the library's (the halo stream),
+ * and all the others on the world's stream -- and sfx_halo_pack, the transfer (sfx_halo_copy, sfx_rccl_halo_exchange, or
+ * the caller's own RCCL calls on the stream sfx_halo_stream returns) and sfx_halo_download / _upload go on the halo stream
+ * behind the first, so the halo travels while the second runs; sfx_halo_unpack makes the world's stream wait for it.
+ * The caller's sequence stays substep, pack, transfer, unpack.  Same results, bit for bit, as with overlap off.  A tick
+ * with pairs on the fallback list is not split.  Call it after sfx_halo_set, outside a tick; 0 switches it off.  Off by
+ * default: the three stream hand-offs per substep cost about 35 us on an MI355X -- worth it only where the transfer takes
+ * longer than that (measured: DESIGN.md).
+ * sfx_halo_stream: the hipStream_t the halo's pack and transfer are enqueued on -- the world's stream with overlap off. */
+int sfx_halo_overlap(sfx_world* w, int on);
+int sfx_halo_stream(sfx_world* w, void** hip_stream);
 
 int sfx_download_poses(sfx_world* w, float* pos, float* rot);
 int sfx_download_velocities(sfx_world* w, float* vel, float* angvel);
@@ -394,6 +407,9 @@ int sfx_debug_contacts(sfx_world* w, sfx_contact* out, size_t cap, size_t* n);
 /* joint order after colouring: perm[k] = index into the joint list (distance constraints, then
  * angle constraints) */
 int sfx_debug_joint_order(sfx_world* w, uint32_t* perm, uint8_t* colors, size_t cap, size_t* n);
+/* the last tick's split of the velocity sweep (sfx_halo_overlap): batches on the near list (0xFFFFFFFF: that tick was
+ * not split -- it had a fallback list; 0 with overlap off) and the tick's batches in all; synchronises */
+int sfx_debug_near_batches(sfx_world* w, uint32_t* n_near, uint32_t* n_batches);
 
 /* ---- reporting ------------------------------------------------------------ */
 int sfx_stats(sfx_world* w, sfx_frame_stats* out); /* synchronises */

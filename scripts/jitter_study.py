@@ -32,6 +32,7 @@ VARIANTS = {
     "clamp1": dict(max_depenetration_velocity=1.0),
     "clamp05": dict(max_depenetration_velocity=0.5),
     "pad10": dict(vel_pad_max=0.10),
+    "spec5": dict(speculative_margin=0.005),
     "spec10": dict(speculative_margin=0.010),
     "spec20": dict(speculative_margin=0.020),
     "damp01": dict(_release_damping=0.1),

@@ -206,9 +206,10 @@ SFX_SYMBOLS = [
     "sfx_readback_begin", "sfx_readback_wait",
     "sfx_tick_begin", "sfx_tick_substep", "sfx_set_stream", "sfx_halo_set", "sfx_halo_pack", "sfx_halo_unpack",
     "sfx_halo_buffers", "sfx_halo_download", "sfx_halo_upload", "sfx_halo_copy", "sfx_halo_guard", "sfx_get_stream", "sfx_halo_counts",
+    "sfx_halo_overlap", "sfx_halo_stream",
     "sfx_query_points", "sfx_query_aabbs", "sfx_query_rays", "sfx_query_points_static",
     "sfx_debug_aabbs", "sfx_debug_pairs", "sfx_debug_pair_colors", "sfx_debug_broadphase",
-    "sfx_debug_contacts", "sfx_debug_joint_order",
+    "sfx_debug_contacts", "sfx_debug_joint_order", "sfx_debug_near_batches",
     "sfx_stats", "sfx_set_profiling", "sfx_kernel_times", "sfx_kernel_class_name",
     "sfx_timer_begin", "sfx_timer_end", "sfx_last_error",
 ]
@@ -269,6 +270,10 @@ def load_libsfx(path=None):
     lib.sfx_halo_guard.argtypes = [vp, C.c_float]
     lib.sfx_get_stream.argtypes = [vp, P(vp)]
     lib.sfx_get_stream.restype = C.c_int
+    lib.sfx_halo_overlap.argtypes = [vp, C.c_int]
+    lib.sfx_halo_overlap.restype = C.c_int
+    lib.sfx_halo_stream.argtypes = [vp, P(vp)]
+    lib.sfx_halo_stream.restype = C.c_int
     lib.sfx_halo_counts.argtypes = [vp, P(C.c_uint32), P(C.c_uint32)]
     lib.sfx_halo_counts.restype = C.c_int
     lib.sfx_halo_guard.restype = C.c_int
@@ -299,6 +304,8 @@ def load_libsfx(path=None):
     lib.sfx_debug_broadphase.argtypes = [vp, C.c_float]
     lib.sfx_debug_contacts.argtypes = [vp, vp, C.c_size_t, P(C.c_size_t)]
     lib.sfx_debug_joint_order.argtypes = [vp, vp, vp, C.c_size_t, P(C.c_size_t)]
+    lib.sfx_debug_near_batches.argtypes = [vp, P(C.c_uint32), P(C.c_uint32)]
+    lib.sfx_debug_near_batches.restype = C.c_int
     lib.sfx_set_profiling.argtypes = [vp, C.c_int]
     lib.sfx_kernel_times.argtypes = [vp, P(SfxKernelTime), C.c_int]
     lib.sfx_kernel_class_name.argtypes = [C.c_int]

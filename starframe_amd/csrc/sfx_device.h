@@ -53,7 +53,7 @@ __device__ __forceinline__ uint32_t body_of(const BodyArrays& B, uint32_t e) { r
 
 // filt.w: bit 0 the entry's body is dynamic; bit 1 a further collider of a dynamic body (its pairs go to the fallback
 // list: they are solved on the body, through body_of); bits 8.. the body id (colliders of one body never pair)
-constexpr uint32_t kFiltDynamic = 1u, kFiltFurther = 2u;
+constexpr uint32_t kFiltDynamic = 1u, kFiltFurther = 2u, kFiltHalo = 4u;   // kFiltHalo: the body is on a slab halo list (sent or received)
 
 // shape.x bits: type (8) | material (23) << 8 | has a local pose << 31
 __device__ __forceinline__ uint32_t shape_type(const float4& s) { return __float_as_uint(s.x) & 0xFFu; }

@@ -132,6 +132,14 @@ struct sfx_world {
     uint32_t n_halo_send = 0, n_halo_recv = 0;
     DevBuf<float> halo_x0;         // x of every body when the halo lists were set
     float halo_guard = 0.0f;       // > 0: k_aabb_count flags a body further than this from halo_x0 (kOvfHalo)
+    // exchange / compute overlap (sfx_halo_overlap; sfx_kernels.h k_near_closure): the velocity sweep as two launches, the
+    // pack and the transfer on a stream of their own behind the first
+    bool halo_overlap = false;
+    hipStream_t halo_stream = nullptr;
+    hipEvent_t ev_pre = nullptr, ev_near = nullptr, ev_xchg = nullptr;
+    bool near_open = false;        // the halo stream holds this substep's near launch: a pack goes right behind it
+    DevBuf<uint32_t> near_list;
+    std::vector<uint8_t> h_halo;   // per body: on a halo list (kFiltHalo of its entries)
     // spatial query index (allocated at the first query; DESIGN.md "Contract / spatial queries")
     DevBuf<uint32_t> q_zero, q_bucket, q_cell_fill, q_tmp_id, q_sorted_id, q_large_tmp, q_bounds, q_nhits;
     DevBuf<unsigned char> q_in, q_out;   // query transfer buffers, grown on demand and kept
@@ -475,6 +483,7 @@ TileArrays tile_arrays(sfx_world* w) {
     T.cell_start = w->cell_start; T.sorted_id = w->sorted_id.p; T.tile_start = w->tile_cnt;
     T.active = w->active.p; T.batches = w->batches.p; T.tpair = w->tpair.p; T.torder = w->torder.p; T.bbody = w->bbody.p; T.bmass = w->bmass.p; T.bruns = w->bruns.p; T.tile_batch = w->tile_batch; T.done = w->done.p; T.fsorted = w->fsorted.p;
     T.max_pairs = w->max_pairs; T.fb_cap = w->fb_cap;
+    T.near_list = w->near_list.p; T.near_cap = (uint32_t)w->near_list.n;
     T.dbg = w->dbg.p;
     return T;
 }
@@ -497,6 +506,11 @@ void color_global(sfx_world* w, const uint2* edges, const uint32_t* n_edges, uin
 #ifndef SFX_COLOR_Z   // workgroups that colour the batches of one group of tiles side by side (build knob for probes)
 #define SFX_COLOR_Z(group) ((group) > 1u ? 2u : 1u)
 #endif
+
+// the velocity sweep runs as a near and a far launch (k_near_closure)
+bool split_sweep(const sfx_world* w) {
+    return w->halo_overlap && w->fuse_phases && w->near_list.n >= 4u * (size_t)w->ntiles && (w->n_halo_send || w->n_halo_recv);
+}
 
 int broadphase(sfx_world* w, float dt) {
     const uint32_t n = w->n;
@@ -574,6 +588,11 @@ int broadphase(sfx_world* w, float dt) {
                          w->cell_start, w->sorted_id.p, w->sorted_filt.p, w->tile_cnt, w->active.p, w->rawp.p, w->tpair.p,
                          w->batches.p, w->shape.p, w->torder.p, w->tile_batch, w->bbody.p, (uint32_t)w->bbody.n, w->mass.p, w->bmass.p, w->bruns.p, (uint32_t)(w->bruns.n / 64), w->max_pairs, w->cfg.color_rounds, w->ctr, w->dbg.p); }
     color_global(w, w->fpairs.p, &w->ctr->n_fb, w->fb_cap, 0, w->fsorted.p, w->ctr->fb_start, &w->ctr->n_fb_colors, w->ctr, 1);
+    if (split_sweep(w)) {   // slab world with the exchange overlapped: which batches the halo waits for
+      Prof p(w, SFX_K_COLOR, w->ntiles);
+      hipLaunchKernelGGL(k_near_closure, dim3(1), dim3(1024), 0, w->stream, g, (w->tly == w->gyl) ? 2u : 4u, w->batches.p, w->active.p,
+                         w->tile_batch, w->near_list.p, (uint32_t)w->near_list.n, w->ctr);
+    }
     HIPCHK(w, hipGetLastError());
     return SFX_OK;
 }
@@ -629,6 +648,7 @@ int alloc_entries(sfx_world* w, uint32_t n_entries) {
     w->n = n;
     w->n_halo_send = w->n_halo_recv = 0;   // the halo lists and the guard's snapshot index the old entries
     w->halo_guard = 0.0f;
+    w->h_halo.clear();
     const size_t c = std::max(n, 1u);
     ALLOC(w, w->pose, c); ALLOC(w, w->prev, c); ALLOC(w, w->vel, c); ALLOC(w, w->dpos, c); ALLOC(w, w->mass, c);
     HIPCHK(w, hipMemset(w->dpos.p, 0, sizeof(float4) * c));   // entries that are never integrated (further colliders) keep a zero displacement
@@ -819,6 +839,11 @@ void sfx_destroy(sfx_world* w) {
     if (w->ev_ctr) (void)hipEventDestroy(w->ev_ctr);
     if (w->t_begin) (void)hipEventDestroy(w->t_begin);
     if (w->t_end) (void)hipEventDestroy(w->t_end);
+    if (w->halo_stream) { (void)hipStreamSynchronize(w->halo_stream); (void)hipStreamDestroy(w->halo_stream); }
+    if (w->ev_pre) (void)hipEventDestroy(w->ev_pre);
+    if (w->ev_near) (void)hipEventDestroy(w->ev_near);
+    if (w->ev_xchg) (void)hipEventDestroy(w->ev_xchg);
+    w->near_list.release();
     if (w->own_stream_handle) (void)hipStreamDestroy(w->own_stream_handle);
     delete w;
 }
@@ -831,7 +856,9 @@ static int rebuild_filt(sfx_world* w) {
     w->dyn_compounds = false;
     for (uint32_t i = 0; i < w->n; ++i) {
         const bool dyn = is_dynamic(w, i);
-        uint4 v = make_uint4(0, 0, 0, (dyn ? kFiltDynamic : 0u) | ((dyn && i >= w->nb) ? kFiltFurther : 0u) | (owner(w, i) << 8));
+        const uint32_t ob = owner(w, i);
+        const bool halo = ob < w->h_halo.size() && w->h_halo[ob];
+        uint4 v = make_uint4(0, 0, 0, (dyn ? kFiltDynamic : 0u) | ((dyn && i >= w->nb) ? kFiltFurther : 0u) | (halo ? kFiltHalo : 0u) | (ob << 8));
         if (w->have_colliders) { v.x = w->h_col[i].category; v.y = w->h_col[i].mask; v.z = w->h_col[i].group; }
         f[i] = v;
         if (dyn && i >= w->nb) w->dyn_compounds = true;
@@ -1256,12 +1283,13 @@ int sfx_tick_substep(sfx_world* w) {
         else if (tvp == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
         else hipLaunchKernelGGL(k_tile_pos<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
     };
-    auto launch_vel = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
-        fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;
+    auto launch_vel = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb, hipStream_t st = nullptr) {
+        if (!(fb & kTileOnlyNear)) fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;   // (the near launch takes no tickets)
+        if (!st) st = w->stream;
         const uint32_t nt = tvv == 0 ? 512u : tvv == 1 ? 256u : 128u;
-        if (tvv == 2) hipLaunchKernelGGL(k_tile_vel<128>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp, vstamp);
-        else if (tvv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp, vstamp);
-        else hipLaunchKernelGGL(k_tile_vel<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp, vstamp);
+        if (tvv == 2) hipLaunchKernelGGL(k_tile_vel<128>, dim3(grid), dim3(nt), 0, st, ph0, np, ep, fb, g, T, w->ctr, B, C, sp, vstamp);
+        else if (tvv == 0) hipLaunchKernelGGL(k_tile_vel<512>, dim3(grid), dim3(nt), 0, st, ph0, np, ep, fb, g, T, w->ctr, B, C, sp, vstamp);
+        else hipLaunchKernelGGL(k_tile_vel<256>, dim3(grid), dim3(nt), 0, st, ph0, np, ep, fb, g, T, w->ctr, B, C, sp, vstamp);
     };
     mirror_entries(w);   // the narrowphase reads colliders (entries), the solves write bodies
     {   // manifolds of all solver pairs at the poses integration and joints left (one pair per lane)
@@ -1291,7 +1319,25 @@ int sfx_tick_substep(sfx_world* w) {
         Prof p(w, SFX_K_SOLVE_JOINTS, cnt);
         hipLaunchKernelGGL(k_damp_joints, dim3(cdiv(cnt, kBlock)), dim3(kBlock), 0, w->stream, start, cnt, B, J, sp.h);
     }
-    if (w->fuse_phases) {
+    // The split is taken when the last counters read back say the tick can be split (no fallback list: k_near_closure) --
+    // a tick that turns out otherwise runs its whole sweep in the near launch, on that launch's few workgroups: slow,
+    // right, and over when the next counters arrive.
+    if (w->fuse_phases && split_sweep(w) && w->ctr_valid && w->stale.n_near != kNoSplit && res_vel >= 64u) {
+        // the batches the halo waits for on the halo stream -- the pack and the transfer follow them there -- and all the
+        // others beside them on the world's stream, under the same epoch (k_near_closure).  Both launches fit on the
+        // device together: the far batches that wait for a near batch always find it running or done.
+        const uint32_t ep = ++w->epoch;
+        const uint32_t grid_near = std::min(std::max(w->stale.n_near + w->stale.n_near / 4u + 4u, 8u), res_vel / 4u);
+        const uint32_t grid_far = std::min(total_grid, res_vel - grid_near);
+        HIPCHK(w, hipEventRecord(w->ev_pre, w->stream));
+        HIPCHK(w, hipStreamWaitEvent(w->halo_stream, w->ev_pre, 0));
+        launch_vel(grid_near, 0u, nph, ep, kTileFallback | kTileOnlyNear | race_selftest, w->halo_stream);
+        HIPCHK(w, hipEventRecord(w->ev_near, w->halo_stream));
+        { Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_kept : 0);
+          launch_vel(grid_far, 0u, nph, ep, kTileFallback | kTileOnlyFar | first); }
+        HIPCHK(w, hipStreamWaitEvent(w->stream, w->ev_near, 0));   // whatever follows on the world's stream follows both launches
+        w->near_open = true;
+    } else if (w->fuse_phases) {
         Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_kept : 0);
         launch_vel(std::min(total_grid, res_vel), 0u, nph, ++w->epoch, kTileFallback | first);
     } else {
@@ -1375,6 +1421,14 @@ int sfx_halo_set(sfx_world* w, const uint32_t* send_idx, uint32_t n_send, const 
     if (n_send) HIPCHK(w, hipMemcpy(w->halo_send_idx.p, send_idx, sizeof(uint32_t) * n_send, hipMemcpyHostToDevice));
     if (n_recv) HIPCHK(w, hipMemcpy(w->halo_recv_idx.p, recv_idx, sizeof(uint32_t) * n_recv, hipMemcpyHostToDevice));
     w->n_halo_send = n_send; w->n_halo_recv = n_recv;
+    if (w->halo_overlap && w->near_list.n < 4u * (size_t)w->ntiles) ALLOC(w, w->near_list, 4u * (size_t)std::max(w->ntiles, 1u));
+    {   // the halo bodies' mark in the filter words (kFiltHalo): the colouring finds the batches that touch them
+        w->h_halo.assign(w->nb, 0);
+        for (uint32_t k = 0; k < n_send; ++k) w->h_halo[send_idx[k]] = 1;
+        for (uint32_t k = 0; k < n_recv; ++k) w->h_halo[recv_idx[k]] = 1;
+        const int rc = rebuild_filt(w);
+        if (rc) return rc;
+    }
     // the guard's reference: where every body is now, when the lists are cut
     ALLOC(w, w->halo_x0, std::max(w->n, 1u));
     hipLaunchKernelGGL(k_halo_snapshot, dim3(cdiv(std::max(w->n, 1u), kBlock)), dim3(kBlock), 0, w->stream, w->n, w->pose.p, w->halo_x0.p);
@@ -1394,9 +1448,45 @@ int sfx_halo_pack(sfx_world* w) {
     if (!w) return SFX_ERR_INVALID;
     if (!w->n_halo_send) return SFX_OK;
     HIPCHK(w, hipSetDevice(w->device));
+    hipStream_t st = w->stream;
+    if (w->halo_overlap) {   // on the halo stream, behind the near launch of this substep (or behind whatever the world's stream holds)
+        st = w->halo_stream;
+        if (!w->near_open) {   // no split launch before it: behind whatever the world's stream holds
+            HIPCHK(w, hipEventRecord(w->ev_pre, w->stream));
+            HIPCHK(w, hipStreamWaitEvent(st, w->ev_pre, 0));
+        }
+        w->near_open = false;
+    }
     Prof p(w, SFX_K_HALO, w->n_halo_send);
-    hipLaunchKernelGGL(k_halo_pack, dim3(cdiv(w->n_halo_send, kBlock)), dim3(kBlock), 0, w->stream, w->n_halo_send,
+    hipLaunchKernelGGL(k_halo_pack, dim3(cdiv(w->n_halo_send, kBlock)), dim3(kBlock), 0, st, w->n_halo_send,
                        w->halo_send_idx.p, w->pose.p, w->vel.p, w->halo_send.p);
+    return SFX_OK;
+}
+
+// the stream the halo's pack and transfer are enqueued on
+static hipStream_t xfer_stream(const sfx_world* w) { return w->halo_overlap ? w->halo_stream : w->stream; }
+
+int sfx_halo_stream(sfx_world* w, void** hip_stream) {
+    if (!w || !hip_stream) return SFX_ERR_INVALID;
+    *hip_stream = reinterpret_cast<void*>(xfer_stream(w));
+    return SFX_OK;
+}
+
+int sfx_halo_overlap(sfx_world* w, int on) {
+    if (!w) return SFX_ERR_INVALID;
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    if (w->halo_stream) HIPCHK(w, hipStreamSynchronize(w->halo_stream));
+    if (w->tick_open) return fail(w, SFX_ERR_INVALID, "sfx_halo_overlap inside a tick");
+    if (on && !w->halo_stream) {
+        HIPCHK(w, hipStreamCreateWithFlags(&w->halo_stream, hipStreamNonBlocking));
+        HIPCHK(w, hipEventCreateWithFlags(&w->ev_pre, hipEventDisableTiming));
+        HIPCHK(w, hipEventCreateWithFlags(&w->ev_near, hipEventDisableTiming));
+        HIPCHK(w, hipEventCreateWithFlags(&w->ev_xchg, hipEventDisableTiming));
+    }
+    if (on && w->near_list.n < 4u * (size_t)w->ntiles) ALLOC(w, w->near_list, 4u * (size_t)std::max(w->ntiles, 1u));
+    w->halo_overlap = on != 0;
+    w->near_open = false;
     return SFX_OK;
 }
 
@@ -1405,6 +1495,10 @@ int sfx_halo_unpack(sfx_world* w) {
     if (!w->n_halo_recv) return SFX_OK;
     HIPCHK(w, hipSetDevice(w->device));
     w->q_valid = false;
+    if (w->halo_overlap) {   // the world's stream goes on when the transfer on the halo stream has arrived
+        HIPCHK(w, hipEventRecord(w->ev_xchg, w->halo_stream));
+        HIPCHK(w, hipStreamWaitEvent(w->stream, w->ev_xchg, 0));
+    }
     Prof p(w, SFX_K_HALO, w->n_halo_recv);
     hipLaunchKernelGGL(k_halo_unpack, dim3(cdiv(w->n_halo_recv, kBlock)), dim3(kBlock), 0, w->stream, w->n_halo_recv,
                        w->halo_recv_idx.p, w->halo_recv.p, w->pose.p, w->vel.p);
@@ -1423,8 +1517,8 @@ int sfx_halo_download(sfx_world* w, float* send_host) {
     int rc = sfx_halo_pack(w);
     if (rc) return rc;
     if (w->n_halo_send)
-        HIPCHK(w, hipMemcpyAsync(send_host, w->halo_send.p, sizeof(float4) * 2 * w->n_halo_send, hipMemcpyDeviceToHost, w->stream));
-    HIPCHK(w, hipStreamSynchronize(w->stream));
+        HIPCHK(w, hipMemcpyAsync(send_host, w->halo_send.p, sizeof(float4) * 2 * w->n_halo_send, hipMemcpyDeviceToHost, xfer_stream(w)));
+    HIPCHK(w, hipStreamSynchronize(xfer_stream(w)));
     return SFX_OK;
 }
 
@@ -1432,8 +1526,8 @@ int sfx_halo_upload(sfx_world* w, const float* recv_host) {
     if (!w || (w->n_halo_recv && !recv_host)) return fail(w, SFX_ERR_INVALID, "null argument");
     if (!w->n_halo_recv) return SFX_OK;
     HIPCHK(w, hipSetDevice(w->device));
-    HIPCHK(w, hipMemcpyAsync(w->halo_recv.p, recv_host, sizeof(float4) * 2 * w->n_halo_recv, hipMemcpyHostToDevice, w->stream));
-    HIPCHK(w, hipStreamSynchronize(w->stream));  // recv_host is borrowed for this call only
+    HIPCHK(w, hipMemcpyAsync(w->halo_recv.p, recv_host, sizeof(float4) * 2 * w->n_halo_recv, hipMemcpyHostToDevice, xfer_stream(w)));
+    HIPCHK(w, hipStreamSynchronize(xfer_stream(w)));  // recv_host is borrowed for this call only
     return sfx_halo_unpack(w);
 }
 
@@ -1444,21 +1538,22 @@ int sfx_halo_copy(sfx_world* dst, uint32_t dst_first, sfx_world* src, uint32_t s
         return fail(dst, SFX_ERR_INVALID, "halo copy range out of bounds");
     if (!count) return SFX_OK;
     HIPCHK(dst, hipSetDevice(dst->device));
-    // ordered after the source's pack and before the destination's unpack
-    if (src->stream != dst->stream) {
+    // ordered after the source's pack and before the destination's unpack: on the streams the halos travel on
+    hipStream_t ss = xfer_stream(src), ds = xfer_stream(dst);
+    if (ss != ds) {
         hipEvent_t ev;
         HIPCHK(dst, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIPCHK(dst, hipEventRecord(ev, src->stream));
-        HIPCHK(dst, hipStreamWaitEvent(dst->stream, ev, 0));
+        HIPCHK(dst, hipEventRecord(ev, ss));
+        HIPCHK(dst, hipStreamWaitEvent(ds, ev, 0));
         HIPCHK(dst, hipEventDestroy(ev));
     }
     HIPCHK(dst, hipMemcpyAsync(dst->halo_recv.p + 2 * (size_t)dst_first, src->halo_send.p + 2 * (size_t)src_first,
-                               sizeof(float4) * 2 * count, hipMemcpyDeviceToDevice, dst->stream));
-    if (src->stream != dst->stream) {  // the source must not pack again before this copy has read its buffer
+                               sizeof(float4) * 2 * count, hipMemcpyDeviceToDevice, ds));
+    if (ss != ds) {  // the source must not pack again before this copy has read its buffer
         hipEvent_t ev;
         HIPCHK(dst, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        HIPCHK(dst, hipEventRecord(ev, dst->stream));
-        HIPCHK(dst, hipStreamWaitEvent(src->stream, ev, 0));
+        HIPCHK(dst, hipEventRecord(ev, ds));
+        HIPCHK(dst, hipStreamWaitEvent(ss, ev, 0));
         HIPCHK(dst, hipEventDestroy(ev));
     }
     return SFX_OK;
@@ -1934,6 +2029,19 @@ int sfx_debug_joint_order(sfx_world* w, uint32_t* perm, uint8_t* colors, size_t 
         if (perm) perm[k] = w->joint_perm[k];
         if (colors) colors[k] = w->joint_color_sorted[k];
     }
+    return SFX_OK;
+}
+
+int sfx_debug_near_batches(sfx_world* w, uint32_t* n_near, uint32_t* n_batches) {
+    if (!w || !n_near || !n_batches) return SFX_ERR_INVALID;
+    *n_near = 0; *n_batches = 0;
+    if (!w->ticked || !w->ctr) return SFX_OK;
+    HIPCHK(w, hipSetDevice(w->device));
+    HIPCHK(w, hipStreamSynchronize(w->stream));
+    Counters c;
+    HIPCHK(w, hipMemcpy(&c, w->ctr, sizeof(Counters), hipMemcpyDeviceToHost));
+    *n_near = c.n_near;
+    for (int ph = 0; ph < 4; ++ph) *n_batches += c.n_batches[ph];
     return SFX_OK;
 }
 

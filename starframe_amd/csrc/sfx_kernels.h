@@ -80,7 +80,8 @@ struct Counters {
     uint32_t item_ticket[2];  // next batch of a tile-solve launch, handed out in item order; launches alternate between
                               // the two counters and every launch clears the one its successor will use
     uint32_t n_medium;      // colliders sorted into the grid's second level (written by k_finalize_slots)
-    uint32_t pad3[2];
+    uint32_t n_near;        // batches on the near list (k_near_closure; slab worlds with the exchange overlapped)
+    uint32_t pad3[1];
 };
 static_assert(sizeof(Counters) % 16 == 0, "the per-tick block is cleared in 16-byte units");
 static_assert(offsetof(Counters, overflow) == 12, "k_zero / k_aabb_count fold word 3 of the block into the sticky overflow word");
@@ -943,9 +944,11 @@ __device__ __forceinline__ void tile_pair_range(uint32_t t, const uint32_t* __re
 // are disjoint, so they do not interact; each tile is still coloured on its own, the batch only
 // runs colour c of all its tiles in the same step).  Batching is scheduling only: results do
 // not depend on which tiles share a batch.
+constexpr uint32_t kBatchNear = 0x80000000u;   // bit 31 of BatchDesc.count: a NEAR batch (see k_near_closure)
+constexpr uint32_t kNoSplit = 0xFFFFFFFFu;     // Counters.n_near of a tick whose velocity sweep is not split
 struct BatchDesc {
     uint32_t first;    // index of the first tile on the phase's list
-    uint32_t count;    // tiles
+    uint32_t count;    // tiles | kBatchNear
     uint32_t bstart;   // first pair in tpair / first record slot
     uint32_t np;       // pairs within reach: the ones the solves take (the others follow them in tpair)
     uint32_t ncol;     // most colours of any of its tiles
@@ -1088,7 +1091,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
     __shared__ uint8_t s_mark[MB];        // block bodies that a kept pair of this class touches: the batch's LDS bodies
     __shared__ uint16_t s_remap[MB];      // block-local index -> index in the batch's (compact) body list
     __shared__ uint32_t s_scan[kColorThreads / 64 + 1];
-    __shared__ uint32_t s_np, s_nbc;
+    __shared__ uint32_t s_np, s_nbc, s_near;
     const uint32_t tid = threadIdx.x;
     const uint32_t cls = blockIdx.y;      // the class of pairs (= phase of the sweep) this workgroup forms batches of
     const uint32_t nlist = ctr->n_listed[0];
@@ -1129,7 +1132,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                 uint32_t run = 0;
                 for (uint32_t j = 0; j < c; ++j) { s_poff[j] = run; run += s_tnp[f + j]; }
                 s_poff[c] = run;
-                s_nleft = 0u; s_ovf = 0u; s_npruned = 0u; s_np = 0u;
+                s_nleft = 0u; s_ovf = 0u; s_npruned = 0u; s_np = 0u; s_near = 0u;
             }
             if (tid < kMaxExt) s_ext[tid] = 0xFFFFFFFFu;
             if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
@@ -1137,7 +1140,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
             __syncthreads();
             const uint32_t nb = min(S.off[4u * c], MB), np_all = min(s_poff[c], MP);
             for (uint32_t l = tid; l < nb; l += kBlock) {
-                s_dyn[l] = (uint8_t)(filt[batch_slot(S, 4u * c, l)].w & kFiltDynamic);   // (filt: the filter words in slot order)
+                s_dyn[l] = (uint8_t)(filt[batch_slot(S, 4u * c, l)].w & (kFiltDynamic | kFiltHalo));   // (filt: the filter words in slot order)
                 s_mark[l] = 0u;
                 s_used[l] = 0ull;
 #pragma unroll
@@ -1214,12 +1217,13 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                     const uint32_t id = sorted_id[batch_slot(S, 4u * c, l)];
                     bbody[s_boff + s_remap[l]] = id;
                     bmass[s_boff + s_remap[l]] = mass[id];   // the masses in list order: the tile solves fetch them beside the ids, not after them
+                    if (s_dyn[l] & kFiltHalo) s_near = 1u;   // the batch touches a halo body (sent or received): see k_near_closure
                 }
             SFX_TT(tc1);
 #if defined(SFX_PROBE_COLOR_STAGE) && SFX_PROBE_COLOR_STAGE == 1   // timing probe: a batch ends after its set-up (results are wrong)
             continue;
 #endif
-#define TDYN(l) ((l) != kExt && (l) < MB && s_dyn[(l)])
+#define TDYN(l) ((l) != kExt && (l) < MB && (s_dyn[(l)] & kFiltDynamic))
             // A thread owns the same (at most MP / threads) edges in every round: their ends, keys, dynamic flags, colour and
             // proposal stay in registers, so a round is one LDS read (the ends' used colours / the claims) and one LDS
             // atomic per edge and phase instead of a chain of dependent reads.
@@ -1355,7 +1359,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                 const uint32_t ph = cls;
                 BatchDesc d;
                 d.first = e0 + f;
-                d.count = c; d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nbc + s_next; d.boff = s_boff; d.roff = roff;
+                d.count = c | (s_near ? kBatchNear : 0u); d.bstart = bstart; d.np = kept; d.ncol = nc; d.nb = nbc + s_next; d.boff = s_boff; d.roff = roff;
                 const uint32_t bidx = r_bidx;
                 batches[ph * g.pstride + bidx] = d;
                 s_bidx = bidx;
@@ -1601,6 +1605,8 @@ struct TileArrays {
     const uint32_t* bruns;        // per batch (BatchDesc.roff): 64 colour runs, first | end << 16
     const uint32_t* tile_batch;   // [phase][tile]: 1 + index of the tile's batch on that phase's table (0: none this tick)
     uint32_t* done;               // per batch slot: epoch of the last fused launch that finished it
+    const uint32_t* near_list;    // (phase << 24 | batch) of the NEAR batches in phase order (k_near_closure), ctr->n_near of them
+    uint32_t near_cap;
     const uint2* fsorted;         // fallback list, colour-major
     uint32_t max_pairs;           // record slot of fallback pair k = max_pairs + k
     uint32_t fb_cap;
@@ -1918,7 +1924,9 @@ __device__ __forceinline__ uint32_t phase_total(const Counters* __restrict__ ctr
 // then the argument above needs every workgroup of the grid on the device, which the host can promise only while
 // no other world runs fused launches on the same device (sfx_host.hip: live worlds per device, SFX_SHARED_DEVICE).
 // kTileSlot: which of the two ticket counters this launch uses.
-constexpr int kTileFallback = 1, kTileStaticFirst = 2, kTileSlot = 4, kTileRaceSelfTest = 8;
+// kTileOnlyNear / kTileOnlyFar: the velocity sweep of a slab world in two launches (k_near_closure): the near batches from
+// their list, then every other batch.
+constexpr int kTileFallback = 1, kTileStaticFirst = 2, kTileSlot = 4, kTileRaceSelfTest = 8, kTileOnlyNear = 16, kTileOnlyFar = 32;
 
 __device__ __forceinline__ uint32_t* ticket_of(Counters* __restrict__ ctr, int flags) {
     return &ctr->item_ticket[(flags & kTileSlot) ? 1 : 0];
@@ -2009,6 +2017,59 @@ __device__ __forceinline__ void publish_batch(const TileArrays& T, const GridPar
     __syncthreads();
     if (threadIdx.x == 0)
         __hip_atomic_store(&T.done[ph * g.pstride + it], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Exchange / compute overlap of slab worlds (SURVEY.md section 5 "overlap it with interior-constraint solving"; DESIGN.md
+// "Multi-GPU / overlap").  The last kernel of a substep is the velocity sweep; what the neighbours need of it are the
+// bodies on the halo send list.  k_batch_color marks every batch whose pairs touch a halo body (kBatchNear); this
+// kernel -- one workgroup, once per frame -- closes the set under "waits for": a batch of phase p waits for the batches
+// that hold, in an earlier phase, a unit of one of the 3 x 3 tiles around each of its own (wait_for_earlier_phases), so
+// going through the phases from the last to the second, every near batch marks those.  Then it lists the near batches
+// in phase order.  The velocity sweep of such a world runs as two launches: the near list (its items only ever wait for
+// earlier items of the list: it is closed), after which the halo is packed and travels on a second stream, and all the
+// other batches meanwhile (they find the near batches' flags set, same epoch).  Which launch runs a batch does not
+// change what it computes: the states are bit-identical to the single launch (tests/test_gpu_host_api.py).
+__global__ __launch_bounds__(1024) void k_near_closure(GridParams g, uint32_t nph, BatchDesc* __restrict__ batches,
+                                                       const uint32_t* __restrict__ active, const uint32_t* __restrict__ tile_batch,
+                                                       uint32_t* __restrict__ near_list, uint32_t near_cap, Counters* __restrict__ ctr) {
+    __shared__ uint32_t s_n;
+    const uint32_t lx = g.gxl - g.tlx;
+    const bool one_row = g.tly == g.gyl;
+    // the fallback list is solved after every batch, by the last workgroup of the sweep, and may touch halo bodies: a tick
+    // that has one runs its whole sweep in the first launch (nothing is overlapped, everything is right)
+    if (ctr->n_fb != 0u) { if (threadIdx.x == 0) ctr->n_near = kNoSplit; return; }
+    if (threadIdx.x == 0) s_n = 0u;
+    for (uint32_t ph = nph; ph-- > 1u;) {
+        const uint32_t nb = min(ctr->n_batches[ph], g.pstride);
+        __syncthreads();   // the marks of the later phases are in place
+        for (uint32_t it = threadIdx.x; it < nb; it += blockDim.x) {
+            const BatchDesc d = batches[ph * g.pstride + it];
+            if (!(d.count & kBatchNear)) continue;
+            const uint32_t cnt = d.count & ~kBatchNear;
+            for (uint32_t j = 0; j < cnt * 9u; ++j) {
+                const uint32_t t = active[d.first + j / 9u], dir = j % 9u;
+                const int dx = (int)(dir % 3u) - 1, dy = (int)(dir / 3u) - 1;
+                if (one_row && dy != 0) continue;
+                const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
+                const uint32_t t2 = tile_of(tx + dx, ty + dy, g);
+                for (uint32_t ph2 = 0; ph2 < ph; ++ph2) {
+                    const uint32_t b2 = tile_batch[ph2 * g.ntiles + t2];
+                    if (b2) atomicOr(&batches[ph2 * g.pstride + (b2 - 1u)].count, kBatchNear);
+                }
+            }
+        }
+    }
+    for (uint32_t ph = 0; ph < nph; ++ph) {   // the list, phase by phase (inside a phase the order is free)
+        const uint32_t nb = min(ctr->n_batches[ph], g.pstride);
+        __syncthreads();
+        for (uint32_t it = threadIdx.x; it < nb; it += blockDim.x) {
+            if (!(batches[ph * g.pstride + it].count & kBatchNear)) continue;
+            const uint32_t k = atomicAdd(&s_n, 1u);
+            if (k < near_cap) near_list[k] = (ph << 24) | it;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ctr->n_near = min(s_n, near_cap);
 }
 
 // Device-side race detector ("a debug kernel that asserts no body index is touched twice per colour";
@@ -2116,7 +2177,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
             const uint32_t k = (st & 0xFFFFu) + half;
             fetch_side<false>(T, C, start + k, side, (uint32_t)u < ns && k < (st >> 16), q[u]);
         }
-        if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
+        if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count & ~kBatchNear, ph, ph0, epoch);
         SFX_TT(ttw);
         SFX_TT_ADD(6, tt0, ttw);
         if (ph != 0u)
@@ -2208,12 +2269,35 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
     if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[48 + 2 * (epoch & 15u)], ~wall_clock64());   // earliest kernel entry
 #endif
     const __amdgpu_buffer_rsrc_t pose_rs = record_rsrc(B.pose), vel_rs = record_rsrc(B.vel);
-    const uint32_t nitems = phase_total(ctr, ph0, nph);
+    // The near launch (kTileOnlyNear) runs BESIDE the far launch, on the halo stream: it takes no tickets (the far launch owns
+    // the counters) -- workgroup b takes the items b, b + grid, ... of the near list, and the host keeps its grid small enough
+    // for both launches to be on the device together, so the lowest unfinished item is always held by a running workgroup.
+    const bool strided = (flags & kTileOnlyNear) != 0;
+    bool only_near = strided;
+    const bool only_far = (flags & kTileOnlyFar) != 0;
+    if ((only_near || only_far) && ctr->n_near == kNoSplit) {   // this tick's sweep is not split: all of it in the near launch
+        if (only_far) {   // nothing left to do -- but the ticket counter of the NEXT launch is this launch's to clear (next_item)
+            if (blockIdx.x == 0 && threadIdx.x == 0) ctr->item_ticket[(flags & kTileSlot) ? 0 : 1] = 0u;
+            return;
+        }
+        only_near = false;
+    }
+    if (only_near) flags &= ~kTileFallback;   // (the fallback list follows the LAST batch: the far launch has it)
+    const uint32_t nitems = only_near ? min(ctr->n_near, T.near_cap) : phase_total(ctr, ph0, nph);
     __shared__ uint32_t s_next;
-    for (uint32_t item = next_item(ctr, flags); item < nitems; item = s_next) {
-        const PhaseItem pi = phase_item(ctr, ph0, nph, item);
+    for (uint32_t item = strided ? blockIdx.x : next_item(ctr, flags); item < nitems; item = s_next) {
+        PhaseItem pi;
+        if (only_near) { const uint32_t v = T.near_list[item]; pi.ph = v >> 24; pi.it = v & 0xFFFFFFu; pi.ok = true; }
+        else pi = phase_item(ctr, ph0, nph, item);
         const uint32_t ph = pi.ph, it = pi.it;
         const BatchDesc d = T.batches[ph * g.pstride + it];
+        if (only_far && (d.count & kBatchNear)) {   // the near launch has solved it (and published it under this epoch)
+            __syncthreads();   // every thread has read s_next
+            if (tid == 0)
+                s_next = __hip_atomic_fetch_add(ticket_of(ctr, flags), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + ((flags & kTileStaticFirst) ? gridDim.x : 0u);
+            __syncthreads();
+            continue;
+        }
         const uint32_t* tiles = T.active + d.first;   // one tile list for all phases
         SFX_TT(tv0);
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol;
@@ -2240,7 +2324,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
             const uint32_t k = (st & 0xFFFFu) + half;
             fetch_side<true>(T, C, start + k, side, (uint32_t)u < ns && k < (st >> 16), q[u]);
         }
-        if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count, ph, ph0, epoch);
+        if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count & ~kBatchNear, ph, ph0, epoch);
         SFX_TT(tvw);
         float4 rp[kRounds];
 #pragma unroll
@@ -2265,7 +2349,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
             }
         }
         __syncthreads();
-        const uint32_t ahead = take_ahead<NT>(ctr, flags);
+        const uint32_t ahead = strided ? item + gridDim.x : take_ahead<NT>(ctr, flags);
         SFX_TT(tv1);
         uint32_t colour = 0u;
         (void)colour;

@@ -116,7 +116,7 @@ int sfx_rccl_halo_exchange(sfx_rccl_comm* c, sfx_world* w, int left, int right, 
                     n_recv_left, n_recv_right, n_send, n_recv);
     void* stream = nullptr;
     float *send = nullptr, *recv = nullptr;
-    rc = sfx_get_stream(w, &stream);
+    rc = sfx_halo_stream(w, &stream);   // the world's stream, or the halo stream of a world with the exchange overlapped
     if (!rc) rc = sfx_halo_buffers(w, &send, &recv);
     if (!rc) rc = sfx_halo_pack(w);
     if (rc) return fail(rc, "%s", sfx_last_error(w));

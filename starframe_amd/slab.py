@@ -203,8 +203,10 @@ class LocalSlabs:
     """All slabs of a scene in one process: logical slabs on one GPU (device-to-device halo
     copies) or on any engine with halo_get / halo_put (host copies)."""
 
-    def __init__(self, scene, nslabs, engine, halo=None, rebalance_every=0, imbalance_tol=0.10, **cfg_kw):
+    def __init__(self, scene, nslabs, engine, halo=None, rebalance_every=0, imbalance_tol=0.10, overlap=False, **cfg_kw):
+        """overlap: the halo travels while the velocity sweep's far batches run (sfx_halo_overlap; engines that have it)."""
         self.engine, self.nslabs, self.cfg_kw = engine, nslabs, cfg_kw
+        self.overlap = bool(overlap)
         self.halo = default_halo(scene) if halo is None else float(halo)
         self.rebalance_every, self.imbalance_tol = int(rebalance_every), float(imbalance_tol)
         self.frames = self.replans = 0
@@ -219,6 +221,8 @@ class LocalSlabs:
         for w, p in zip(self.worlds, self.plans):
             w.halo_set(p.send_idx, p.recv_idx)
             self.device_guard = arm_guard(w, self.halo) and self.device_guard
+            if self.overlap and hasattr(w, "halo_overlap"):
+                w.halo_overlap(True)
         self.device_copies = all(hasattr(w, "halo_copy_from") for w in self.worlds)
 
     def rebalance(self, force=False):
@@ -309,7 +313,7 @@ class DistSlab:
     Any other backend ("gloo"): the halo goes through host memory (tests, CPU engines)."""
 
     def __init__(self, scene, engine, dist, halo=None, device_index=None, rebalance_every=0, imbalance_tol=0.10,
-                 transport="auto", check_every=16, **cfg_kw):
+                 transport="auto", check_every=16, overlap=False, **cfg_kw):
         """transport (device path only): "native" = libsfx_rccl.so, plain rccl.h ncclSend / ncclRecv on the world's own
         stream through a communicator of its own (the path a host without torch uses; include/sfx_rccl.h);
         "torch" = torch.distributed batch_isend_irecv on tensors that alias the library's buffers; "auto" = native when it comes up on every rank, else torch (all ranks together, with a warning).
@@ -330,6 +334,10 @@ class DistSlab:
             torch.cuda.set_device(device_index)
         self.engine, self.device_index = engine, device_index
         self.check_every = int(check_every)
+        # overlap: the exchange off the substep's critical path (sfx_halo_overlap): the velocity sweep in two launches, the
+        # halo's pack and transfer on the library's halo stream behind the first.  Device transports only.
+        self.overlap = bool(overlap)
+        self.halo_stream = None
         self._local_error = ""
         self.halo = default_halo(scene) if halo is None else float(halo)
         self.rebalance_every, self.imbalance_tol = int(rebalance_every), float(imbalance_tol)
@@ -352,6 +360,7 @@ class DistSlab:
         self.world.halo_set(self.plan.send_idx, self.plan.recv_idx)
         self.device_guard = arm_guard(self.world, self.halo)
         self.on_device = dist.get_backend() == "nccl" and hasattr(self.world, "halo_buffer_pointers")
+        self.halo_stream = None
         p = self.plan
         self.n_sl, self.n_sr, self.n_rl, self.n_rr = len(p.send_left), len(p.send_right), len(p.recv_left), len(p.recv_right)
         self.send = self.recv = None
@@ -359,6 +368,8 @@ class DistSlab:
         transport = os.environ.get("SFX_SLAB_TRANSPORT", self.transport)
         if self.on_device and transport in ("auto", "native"):
             self.native = self._native_comm(required=transport == "native")
+            if self.native and self.overlap and hasattr(self.world, "halo_overlap"):
+                self.world.halo_overlap(True)   # sfx_rccl_halo_exchange enqueues on the halo stream by itself
         if self.on_device and not self.native:
             try:
                 dev = torch.device("cuda", device_index)
@@ -370,6 +381,9 @@ class DistSlab:
                 ns, nr = 8 * (self.n_sl + self.n_sr), 8 * (self.n_rl + self.n_rr)
                 self.send = torch.as_tensor(_DeviceArray(sp, ns), device=dev) if ns else torch.empty(0, device=dev)
                 self.recv = torch.as_tensor(_DeviceArray(rp, nr), device=dev) if nr else torch.empty(0, device=dev)
+                if self.overlap and hasattr(self.world, "halo_overlap"):
+                    self.world.halo_overlap(True)   # torch's transfers then go on the library's halo stream
+                    self.halo_stream = torch.cuda.ExternalStream(self.world.halo_stream(), device=dev)
             except Exception as e:  # the transfer then goes through host memory: slower, same results
                 import warnings
 
@@ -509,7 +523,7 @@ class DistSlab:
             self.world.halo_pack()
             ops = self._ops(self.send, self.recv)
             if ops:
-                with self.torch.cuda.stream(self.stream):
+                with self.torch.cuda.stream(self.halo_stream or self.stream):
                     for w in self.dist.batch_isend_irecv(ops):
                         w.wait()       # orders the world's stream after the transfer; no host wait with NCCL
             self.world.halo_unpack()

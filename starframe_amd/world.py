@@ -153,6 +153,17 @@ class World(WorldBase):
         """Ticks flag (overflow bit 128 -> SFX_ERR_CAPACITY) a body that moved further than max_move on x since halo_set."""
         self._check(self.lib.sfx_halo_guard(self.handle, float(max_move)))
 
+    def halo_overlap(self, on=True):
+        """The velocity sweep as two launches with the halo's pack and transfer on a stream of their own behind the first
+        (include/sfx.h sfx_halo_overlap): same results, the exchange off the substep's critical path."""
+        self._check(self.lib.sfx_halo_overlap(self.handle, 1 if on else 0))
+
+    def halo_stream(self):
+        """The hipStream_t (as an integer) the halo's pack and transfer are enqueued on."""
+        s = C.c_void_p()
+        self._check(self.lib.sfx_halo_stream(self.handle, C.byref(s)))
+        return s.value or 0
+
     def halo_get(self):
         """Host copy of the send bodies' (pose, velocity): [n_send, 8]."""
         out = np.empty((self.n_halo_send, 8), np.float32)
@@ -273,6 +284,12 @@ class World(WorldBase):
         self._check(self.lib.sfx_readback_wait(self.handle, C.byref(ptr), C.byref(n)))
         a = np.ctypeslib.as_array(ptr, shape=(n.value, 4)) if n.value else np.zeros((0, 4), np.float32)
         return a.copy() if copy else a
+
+    def debug_near_batches(self):
+        """(batches on the near list of the last tick's velocity sweep, batches in all); halo_overlap worlds."""
+        a, b = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.sfx_debug_near_batches(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def joint_order(self):
         cap = max(self.m, 1)

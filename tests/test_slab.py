@@ -317,3 +317,92 @@ def test_gpu_torch_views_the_library_halo_buffers_and_single_rank_nccl():
                        capture_output=True, text=True, timeout=280)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "slab gpu worker ok" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tiles", ["strips", "square"])
+def test_gpu_overlapped_exchange_equals_the_serial_exchange(tiles):
+    """sfx_halo_overlap (SURVEY.md section 5 "overlap it with interior-constraint solving"): the velocity sweep as a near and a
+    far launch with the halo's pack and device-to-device copies on the halo streams behind the near launch.  Which launch
+    runs a batch does not change what it computes: four logical slabs of a mixed pile tick to the SAME BITS with overlap on
+    and off, on strips (two phases) and on square tiles (four phases, the closure over three earlier phases), and the near
+    list is a proper part of the batches (something is left to overlap with)."""
+    from starframe_amd.world import World
+
+    kw = dict(tile_cells_y=1 << 20) if tiles == "strips" else dict(tile_cells=4, tile_cells_y=4)
+    s = scenes.mixed_pile(n=6000, width=120)
+    W = World.from_scene(s, linear_damping=3.3, angular_damping=1.0)
+    for _ in range(250):
+        W.step(DT)
+    pos, rot = W.poses()
+    vel, ang = W.velocities()
+    W.close()
+    s2 = s.with_state(pos, rot, vel, ang)
+    A = LocalSlabs(s2, 4, World, halo=1.5, overlap=False, **kw)
+    B = LocalSlabs(s2, 4, World, halo=1.5, overlap=True, **kw)
+    assert sum(len(p.recv_idx) for p in B.plans) > 100
+    for f in range(12):
+        A.step(DT)
+        B.step(DT)
+    a, b = A.gather(), B.gather()
+    for x, y in zip(a, b):
+        assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+    assert sum(w.stats().n_manifolds for w in B.worlds) > 5000
+    assert all(w.stats().overflow == 0 for w in B.worlds)
+    near = [w.debug_near_batches() for w in B.worlds]
+    assert all(0 < n < total for n, total in near), near
+    A.close()
+    B.close()
+
+
+@pytest.mark.gpu
+def test_gpu_overlap_in_a_world_alone_on_its_device_and_with_a_fallback_list():
+    """The same with ONE world on the device (its fused launches start workgroup b on batch b instead of taking tickets): a
+    pile whose left edge is 'sent' onto ghosts that sit in a second pile further right (a halo copied to itself) -- not a
+    physical scene, a deterministic one.  Overlap on and off give the same bits; so does a world with pairs on the fallback
+    list (a large dynamic body), whose ticks are not split."""
+    from starframe_amd.world import World
+
+    for big in (False, True):
+        s = scenes.mixed_pile(n=4000, width=100)
+        W = World.from_scene(s, linear_damping=3.3, angular_damping=1.0)
+        for _ in range(200):
+            W.step(DT)
+        pos, rot = W.poses()
+        W.close()
+        s2 = s.with_state(pos, rot)
+        if big:   # one circle on top of the pile grows beyond a grid cell: its pairs go to the fallback list
+            import copy
+            s2 = copy.copy(s2)
+            col = s2.colliders.copy()
+            circ = np.flatnonzero((col["type"][: s2.n] == 1) & (s2.inv_mass > 0))
+            k = circ[np.argmax(s2.pos[circ, 1])]
+            col["p"][k, 0] = 2.5
+            s2.colliders = col
+        dyn = np.flatnonzero(s2.inv_mass > 0)
+        order = dyn[np.argsort(s2.pos[dyn, 0])]
+        send, recv = order[:150].astype(np.uint32), order[-150:].astype(np.uint32)
+        out = []
+        for overlap in (False, True):
+            w = World.from_scene(s2, tile_cells_y=1 << 20, **(dict(cell_size=0.3) if big else {}))
+            w.halo_set(send, recv)
+            if overlap:
+                w.halo_overlap(True)
+            for _ in range(6):
+                w.tick_begin(DT)
+                for _ in range(s2.substeps):
+                    w.tick_substep()
+                    w.halo_pack()
+                    w.halo_copy_from(w, 0, 0, 150)
+                    w.halo_unpack()
+            st = w.stats()
+            assert st.overflow == 0 and st.n_manifolds > 3000
+            if big:
+                assert st.n_fallback > 0
+            n, total = w.debug_near_batches()
+            out.append((w.poses(), w.velocities(), n, total))
+            w.close()
+        (p0, v0, _, _), (p1, v1, n, total) = out
+        for x, y in zip(p0 + v0, p1 + v1):
+            assert np.array_equal(x.view(np.uint32), y.view(np.uint32))
+        assert (n == 0xFFFFFFFF) if big else (0 < n < total), (big, n, total)
