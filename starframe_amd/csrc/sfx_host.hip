@@ -2100,7 +2100,7 @@ int sfx_kernel_times(sfx_world* w, sfx_kernel_time* out, int reset) {
     return SFX_OK;
 }
 
-#ifdef SFX_TILE_TIMING
+#if defined(SFX_TILE_TIMING) || defined(SFX_STEP_PROBE)
 // development hook: stage timing in 10 ns units, 16 slots.  k_tile_pos: [load, narrowphase, colour loop, whole batch,
 // batches, colours, wait, write-back]; k_tile_vel: [8 wait, 9 load, 10 colour loop, 11 write-back, 12 whole batch, 13 batches]
 int sfx_debug_tile_timing(sfx_world* w, unsigned long long* out, int reset) {

@@ -2072,6 +2072,34 @@ __global__ __launch_bounds__(1024) void k_near_closure(GridParams g, uint32_t np
     if (threadIdx.x == 0) ctr->n_near = min(s_n, near_cap);
 }
 
+// In-kernel stamps of the colour loops (diagnostic builds with -DSFX_STEP_PROBE only: scripts/dev/step_probe.py reads the
+// SHARES of a step's segments; the build's run time means nothing).  Scalar clock reads; workgroup 3 adds its sums to T.dbg.
+#ifdef SFX_STEP_PROBE
+#define SFX_STAMP(t)                                                                          \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");           \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#define SFX_STAMP_VM(t)                                                                       \
+    do {                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+    } while (0)
+#define SFX_PROBE_DECL unsigned long long pq0 = 0, pq1 = 0, pq2 = 0, pq3 = 0, pq4 = 0, pa0 = 0, pa1 = 0, pa2 = 0, pa3 = 0, pa4 = 0, pns = 0; (void)pq0; (void)pq1; (void)pq2; (void)pq3; (void)pq4;
+#define SFX_PROBE_OUT(base)                                                                   \
+    if (blockIdx.x == 3u && threadIdx.x == 0u && T.dbg) {                                     \
+        atomicAdd(&T.dbg[(base) + 0], pa0); atomicAdd(&T.dbg[(base) + 1], pa1); atomicAdd(&T.dbg[(base) + 2], pa2); \
+        atomicAdd(&T.dbg[(base) + 3], pa3); atomicAdd(&T.dbg[(base) + 4], pa4); atomicAdd(&T.dbg[(base) + 5], pns);  \
+    }
+#else
+#define SFX_STAMP(t)
+#define SFX_STAMP_VM(t)
+#define SFX_PROBE_DECL
+#define SFX_PROBE_OUT(base)
+#endif
+
 // Device-side race detector ("a debug kernel that asserts no body index is touched twice per colour";
 // builds with -DSFX_DEBUG_RACES: libsfx_races.so).  The colouring is what makes the solves race-free: within one colour no
 // two pairs write the same body.  Here every write of a body's LDS record inside a colour step first stamps the body's
@@ -2170,13 +2198,12 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
 #else
         const uint32_t ns = s_nsteps;
 #endif
-        RawSide q[kDepth];
-#pragma unroll
-        for (int u = 0; u < kDepth; ++u) {
-            const uint32_t st = s_step[min((uint32_t)u, kMaxSteps - 1u)];
-            const uint32_t k = (st & 0xFFFFu) + half;
-            fetch_side<false>(T, C, start + k, side, (uint32_t)u < ns && k < (st >> 16), q[u]);
-        }
+        static_assert(kDepth == 1, "the colour loop keeps the step entries of this step and the next in registers");
+        RawSide q;
+        SFX_PROBE_DECL
+        // the step table entries of the current and the next step ride in (scalar) registers: no LDS round trip for them in a step
+        uint32_t st_cur = __builtin_amdgcn_readfirstlane(s_step[0]), st_nxt = __builtin_amdgcn_readfirstlane(s_step[1]);
+        fetch_side<false>(T, C, start + (st_cur & 0xFFFFu) + half, side, 0u < ns && (st_cur & 0xFFFFu) + half < (st_cur >> 16), q);
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count & ~kBatchNear, ph, ph0, epoch);
         SFX_TT(ttw);
         SFX_TT_ADD(6, tt0, ttw);
@@ -2201,27 +2228,30 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
             }
             if (side == 0u) s_lam[k] = make_float2(p.r.l0, p.r.l1);
         };
-        for (uint32_t s0 = 0; s0 < ns; s0 += (uint32_t)kDepth) {
-#pragma unroll
-            for (int u = 0; u < kDepth; ++u) {
-                const uint32_t sidx = s0 + (uint32_t)u;
-                if (sidx < ns) {
-                    const uint32_t st = s_step[sidx];
-                    const uint32_t k = (st & 0xFFFFu) + half;
-                    SideSlot cur;
-                    decode_side<false>(q[u], side, cur, nb);
-                    {   // the record of the step kDepth ahead takes this one's registers
-                        const uint32_t nx = sidx + (uint32_t)kDepth;
-                        const uint32_t st2 = s_step[min(nx, kMaxSteps - 1u)];
-                        const uint32_t k2 = (st2 & 0xFFFFu) + half;
-                        fetch_side<false>(T, C, start + k2, side, nx < ns && k2 < (st2 >> 16), q[u]);
-                    }
-                    if (cur.valid) solve(k, cur);
-                    if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) { lds_barrier(); ++colour; }   // the colour's last chunk
-                }
+        for (uint32_t sidx = 0; sidx < ns; ++sidx) {
+            SFX_STAMP(pq0);
+            const uint32_t st = st_cur, st2 = st_nxt;
+            const uint32_t st3 = s_step[min(sidx + 2u, kMaxSteps - 1u)];   // (in flight during the step; first used by the next one)
+            const uint32_t k = (st & 0xFFFFu) + half;
+            SideSlot cur;
+            SFX_STAMP_VM(pq1);
+            decode_side<false>(q, side, cur, nb);
+            {   // the record of the next step takes this one's registers
+                const uint32_t k2 = (st2 & 0xFFFFu) + half;
+                fetch_side<false>(T, C, start + k2, side, sidx + 1u < ns && k2 < (st2 >> 16), q);
             }
+            SFX_STAMP(pq2);
+            if (cur.valid) solve(k, cur);
+            SFX_STAMP(pq3);
+            if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) { lds_barrier(); ++colour; }   // the colour's last chunk
+            SFX_STAMP(pq4);
+#ifdef SFX_STEP_PROBE
+            pa0 += pq1 - pq0; pa1 += pq2 - pq1; pa2 += pq3 - pq2; pa3 += pq4 - pq3; pns += 1;
+#endif
+            st_cur = st2; st_nxt = __builtin_amdgcn_readfirstlane(st3);
         }
         __syncthreads();
+        SFX_PROBE_OUT(64)
         if (tid == NT - 64) s_next = ahead;  // read after the barrier that ends the write-back
         for (uint32_t k = tid; k < npb; k += NT) C.lam[start + k] = s_lam[k];
         SFX_TT(tt3);
@@ -2317,13 +2347,11 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
 #else
         const uint32_t ns = s_nsteps;
 #endif
-        RawSide q[kDepth];
-#pragma unroll
-        for (int u = 0; u < kDepth; ++u) {
-            const uint32_t st = s_step[min((uint32_t)u, kMaxSteps - 1u)];
-            const uint32_t k = (st & 0xFFFFu) + half;
-            fetch_side<true>(T, C, start + k, side, (uint32_t)u < ns && k < (st >> 16), q[u]);
-        }
+        static_assert(kDepth == 1, "the colour loop keeps the step entries of this step and the next in registers");
+        RawSide q;
+        SFX_PROBE_DECL
+        uint32_t st_cur = __builtin_amdgcn_readfirstlane(s_step[0]), st_nxt = __builtin_amdgcn_readfirstlane(s_step[1]);   // as in k_tile_pos
+        fetch_side<true>(T, C, start + (st_cur & 0xFFFFu) + half, side, 0u < ns && (st_cur & 0xFFFFu) + half < (st_cur >> 16), q);
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count & ~kBatchNear, ph, ph0, epoch);
         SFX_TT(tvw);
         float4 rp[kRounds];
@@ -2364,26 +2392,29 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
             const int ch = solve_vel_side(p.r, vs, S, w, sp);
             if (w.x > 0.0f || w.y > 0.0f) { SFX_RACE_WRITE(p.li, colour); s_vel[p.li] = vs; if (ch & 2) s_sh[p.li] = S; }
         };
-        for (uint32_t s0 = 0; s0 < ns; s0 += (uint32_t)kDepth) {
-#pragma unroll
-            for (int u = 0; u < kDepth; ++u) {
-                const uint32_t sidx = s0 + (uint32_t)u;
-                if (sidx < ns) {
-                    const uint32_t st = s_step[sidx];
-                    SideSlot cur;
-                    decode_side<true>(q[u], side, cur, nb);
-                    {
-                        const uint32_t nx = sidx + (uint32_t)kDepth;
-                        const uint32_t st2 = s_step[min(nx, kMaxSteps - 1u)];
-                        const uint32_t k2 = (st2 & 0xFFFFu) + half;
-                        fetch_side<true>(T, C, start + k2, side, nx < ns && k2 < (st2 >> 16), q[u]);
-                    }
-                    if (cur.valid) solve(cur);
-                    if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) { lds_barrier(); ++colour; }
-                }
+        for (uint32_t sidx = 0; sidx < ns; ++sidx) {
+            SFX_STAMP(pq0);
+            const uint32_t st = st_cur, st2 = st_nxt;
+            const uint32_t st3 = s_step[min(sidx + 2u, kMaxSteps - 1u)];
+            SideSlot cur;
+            SFX_STAMP_VM(pq1);
+            decode_side<true>(q, side, cur, nb);
+            {
+                const uint32_t k2 = (st2 & 0xFFFFu) + half;
+                fetch_side<true>(T, C, start + k2, side, sidx + 1u < ns && k2 < (st2 >> 16), q);
             }
+            SFX_STAMP(pq2);
+            if (cur.valid) solve(cur);
+            SFX_STAMP(pq3);
+            if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) { lds_barrier(); ++colour; }
+            SFX_STAMP(pq4);
+#ifdef SFX_STEP_PROBE
+            pa0 += pq1 - pq0; pa1 += pq2 - pq1; pa2 += pq3 - pq2; pa3 += pq4 - pq3; pns += 1;
+#endif
+            st_cur = st2; st_nxt = __builtin_amdgcn_readfirstlane(st3);
         }
         __syncthreads();
+        SFX_PROBE_OUT(72)
         if (tid == NT - 64) s_next = ahead;
         SFX_TT(tv2);
         // write-back by the lanes that loaded: velocity, and the pose when it changed here (the displacement applied on load,
