@@ -39,3 +39,11 @@ w.timer_begin()
 for _ in range(50):
     w.step(bench.DT)
 print("device ms/tick (this build): %.4f" % (w.timer_end() / 50))
+nb = max(o[89], 1)
+print(f"k_batch_color, workgroup (5, 0, 0): {nb} batches stamped; cycles per batch (every stamp drains the loads in flight):")
+names = ["tile info + greedy cut", "batch ranges + tables", "filter gather + table init", "pair load loop", "body mark scan",
+         "body_cursor atomic + outside bodies", "body list + masses", "colouring rounds", "finish + output"]
+tot = sum(o[80:89])
+for nm, v in zip(names, o[80:89]):
+    print(f"   {nm:40s} {v / nb:9.0f}  {100.0 * v / max(tot, 1):5.1f} %")
+print(f"   {'sum':40s} {tot / nb:9.0f}")

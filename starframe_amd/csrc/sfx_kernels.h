@@ -50,6 +50,12 @@ constexpr uint32_t kOvfPairs = 1u, kOvfColors = 2u, kOvfLeftover = 4u, kOvfLarge
 #define SFX_TT_MAX(slot, a, b)
 #endif
 
+#ifdef SFX_STEP_PROBE   // stage stamps of k_batch_color (see SFX_STAMP below: diagnostic builds only)
+#define SFX_CSTAMP(t) unsigned long long t; do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SFX_CSTAMP(t)
+#endif
+
 // device-resident counters of one tick (one allocation, zeroed at the start of every tick)
 struct Counters {
     uint32_t n_small;       // written by k_finalize_slots
@@ -1101,6 +1107,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
     for (uint32_t gi = blockIdx.x; gi < ngroups; gi += gridDim.x) {
         const uint32_t e0 = gi * group, cnt = min(group, nlist - e0);
         __syncthreads();
+        SFX_CSTAMP(cq0);
         if (tid < cnt) {
             const uint32_t t = lst[e0 + tid];
             BlockRanges R;
@@ -1124,6 +1131,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
         }
         __syncthreads();
         const uint32_t nbat = s_nbat;
+        SFX_CSTAMP(cq1);
         for (uint32_t bi = blockIdx.z; bi < nbat; bi += gridDim.z) {  // the batches of a group are coloured side by side
             const uint32_t f = s_bfirst[bi], c = s_bfirst[bi + 1] - f;
             SFX_TT(tc0);
@@ -1138,6 +1146,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
             if (tid < SFX_MAX_COLORS) s_hist[tid] = 0u;
             if (tid < 4) s_cls[tid] = 0u;
             __syncthreads();
+            SFX_CSTAMP(cq2);
             const uint32_t nb = min(S.off[4u * c], MB), np_all = min(s_poff[c], MP);
             for (uint32_t l = tid; l < nb; l += kBlock) {
                 s_dyn[l] = (uint8_t)(filt[batch_slot(S, 4u * c, l)].w & (kFiltDynamic | kFiltHalo));   // (filt: the filter words in slot order)
@@ -1146,6 +1155,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
 #pragma unroll
                 for (int k = 0; k < kClaim; ++k) s_claim[l * kClaim + k] = ~0ull;
             }
+            SFX_CSTAMP(cq3);
             __syncthreads();  // the marks are cleared before the pairs set them
             int open_edges = 0;
             for (uint32_t e0 = tid; e0 < np_all; e0 += kBlock) {  // the tiles' pairs of this class, in no particular order
@@ -1178,6 +1188,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                 }
             }
             int any_open = __syncthreads_or(open_edges);
+            SFX_CSTAMP(cq4);
             const uint32_t np = s_np;
             if (np == 0u) continue;  // no pair of this class in these tiles: no batch (uniform: s_np is read after the barrier)
             {   // the batch's body list holds the touched block bodies only: the units of one class may share a tile's bodies
@@ -1201,6 +1212,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
             }
             __syncthreads();
             const uint32_t nbc = s_nbc;
+            SFX_CSTAMP(cq5);
             if (tid < 64u) {  // the batch's body list: touched block bodies, then the outside bodies (filled from slot 0 on)
                 static_assert(kMaxExt == 64, "one lane per slot");
                 const unsigned long long have = __ballot(s_ext[tid] != 0xFFFFFFFFu);
@@ -1212,6 +1224,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                 if (tid < next && boff + nbc + tid < bbody_cap) { bbody[boff + nbc + tid] = s_ext[tid]; bmass[boff + nbc + tid] = mass[s_ext[tid]]; }
             }
             __syncthreads();
+            SFX_CSTAMP(cq6);
             for (uint32_t l = tid; l < nb; l += kBlock)  // the tile solves load their bodies from this list
                 if (s_mark[l] && s_boff + s_remap[l] < bbody_cap) {
                     const uint32_t id = sorted_id[batch_slot(S, 4u * c, l)];
@@ -1220,6 +1233,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                     if (s_dyn[l] & kFiltHalo) s_near = 1u;   // the batch touches a halo body (sent or received): see k_near_closure
                 }
             SFX_TT(tc1);
+            SFX_CSTAMP(cq7);
 #if defined(SFX_PROBE_COLOR_STAGE) && SFX_PROBE_COLOR_STAGE == 1   // timing probe: a batch ends after its set-up (results are wrong)
             continue;
 #endif
@@ -1282,6 +1296,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                 any_open = __syncthreads_or(open_edges);
             }
             SFX_TT(tc2);
+            SFX_CSTAMP(cq8);
 #if defined(SFX_PROBE_COLOR_STAGE) && SFX_PROBE_COLOR_STAGE == 2   // ... after the colouring rounds
             continue;
 #endif
@@ -1410,6 +1425,14 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
             for (uint32_t e = s_ptail_first + tid; e < np; e += kBlock) torder[bstart + e] = make_uint4(0u, 0u, kNoPair, 0u);  // pruned pairs: no narrowphase
             __syncthreads();
             SFX_TT(tc4);
+            SFX_CSTAMP(cq9);
+#ifdef SFX_STEP_PROBE
+            if (blockIdx.x == 5u && blockIdx.y == 0u && blockIdx.z == 0u && tid == 0u && dbg) {
+                const unsigned long long st_[10] = {cq0, cq1, cq2, cq3, cq4, cq5, cq6, cq7, cq8, cq9};
+                for (int k_ = 0; k_ < 9; ++k_) atomicAdd(&dbg[80 + k_], st_[k_ + 1] - st_[k_]);
+                atomicAdd(&dbg[89], 1ull);
+            }
+#endif
             SFX_TT_ADD(96, tc0, tc1); SFX_TT_ADD(97, tc1, tc2); SFX_TT_ADD(99, tc2, tc3); SFX_TT_ADD(100, tc3, tc4);
             SFX_TT_ADD(101, 0ull, 1ull); SFX_TT_ADD(102, tc0, tc4); SFX_TT_MAX(103, tc0, tc4);
         }
