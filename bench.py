@@ -73,7 +73,7 @@ def penetration_mm(w):
             "p99": round(1e3 * float(p99), 2), "max": round(1e3 * float(d.max()), 2)}
 
 
-def kernel_bytes(st, derive_bodies=0):
+def kernel_bytes(st, derive_bodies=0, fused_narrow=False):
     """Algorithmic (compulsory) bytes of ONE launch of each contact-sweep kernel (one launch per substep),
     from the tick's measured counts.  DESIGN.md "Kernels": P = solver pairs, M = touching pairs (manifolds),
     M2 = of which with two points; record planes A..G are 16 bytes each (sfx_device.h ContactArrays).
@@ -85,15 +85,24 @@ def kernel_bytes(st, derive_bodies=0):
                    2 x 16 velocity written) + M2 x 48
                    + derive_bodies x 64: inside sfx_step the kernel also applies the position sweep's displacement and
                    derives the velocities (DESIGN.md "Velocities derived where they are first read"): pose, start-of-substep
-                   pose and displacement of every dynamic body read once, its pose written once"""
+                   pose and displacement of every dynamic body read once, its pose written once
+    fused_narrow: the narrowphase runs inside k_tile_pos (libsfx's default; DESIGN.md "Narrowphase inside the position sweep")."""
     P, M, M2 = float(st.n_solver_pairs), float(st.n_manifolds), float(st.n_manifolds2)
-    return {
+    kb = {
         "narrow": P * 96.0 + M * 96.0 + M2 * 48.0,
         "solve_pos": P * 20.0 + M * 104.0 + M2 * 48.0,
         "solve_vel": P * 28.0 + M * 128.0 + M2 * 48.0 + 64.0 * derive_bodies,
     }
+    if fused_narrow:
+        # k_tile_pos computes the records of its batches' pairs itself (no k_narrow launch): the narrowphase's bytes are
+        # its own now, and what a kernel that kept the records on chip between the two stages would not read again is NOT
+        # counted as compulsory -- the pair indices, plane A, B and E..G of the position solve and the masses (read once)
+        kb["solve_pos"] = kb.pop("narrow") + M * (2 * 16.0 + 8.0 + 2 * 16.0)   # + displacements read, lambda and displacements written
+    return kb
 
 
+FUSED_POS_NAME = ("k_tile_pos (narrowphase of the batch's own pairs, then the XPBD manifold block solves; all tile phases in one "
+                  "launch, bodies in LDS)")
 KERNEL_NAMES = {
     "narrow": "k_narrow (manifolds of all solver pairs, one pair per lane)",
     "solve_pos": "k_tile_pos (XPBD manifold block solves, all tile phases in one launch, bodies in LDS)",
@@ -101,9 +110,9 @@ KERNEL_NAMES = {
 }
 
 
-def tick_bytes_per_body_substep(st, n_dyn, substeps):
+def tick_bytes_per_body_substep(st, n_dyn, substeps, fused_narrow=False):
     """SURVEY.md 8d accounting for the whole tick, from measured pair / contact counts."""
-    kb = kernel_bytes(st, n_dyn)
+    kb = kernel_bytes(st, n_dyn, fused_narrow)
     integrate = 16 + 16 + 8 + 16 + 16 + 16 + 16     # pose, vel, mass read; prev, pose, vel, zero displacement written
     derive = 0                                      # applied and derived where the velocity solve loads a body: in kernel_bytes
     p = st.n_pairs / n_dyn
@@ -302,7 +311,7 @@ def main():
     ap.add_argument("--no-survey-scene", action="store_true",
                     help="N = 1: skip the second, untimed-for-value leg on SURVEY.md 8d's 400-wide lattice (config.survey_scene)")
     ap.add_argument("--settle-frames", type=int, default=600)
-    ap.add_argument("--live-events", default="solve_vel",
+    ap.add_argument("--live-events", default="solve_pos",
                     help="comma-separated kernel classes bracketed with HIP events INSIDE the timed region (the roofline's "
                          "launch time when the dominant kernel is among them); 'off' = none")
     ap.add_argument("--live-every", type=int, default=8,
@@ -484,7 +493,9 @@ def main():
         vv, _ = w.velocities()
         v_rms = round(float(np.sqrt((vv[np.asarray(scene.inv_mass) > 0] ** 2).sum(1).mean())), 4)
     derive_bodies = scene.n_dynamic() if slab is None else 0   # sfx_step derives on load; the slab driver steps substep by substep
-    kb = kernel_bytes(st2, derive_bodies)
+    fused_narrow = kt["narrow"]["launches"] == 0     # no k_narrow launch: the position sweep computed the records
+    names = dict(KERNEL_NAMES, solve_pos=FUSED_POS_NAME) if fused_narrow else KERNEL_NAMES
+    kb = kernel_bytes(st2, derive_bodies, fused_narrow)
     per_kernel = {}
     for cls, nbytes in kb.items():
         k = kt[cls]
@@ -499,7 +510,7 @@ def main():
     measured_over = f"{prof_frames} further ticks after the timed region (the dominant kernel was not among --live-events)"
     if dom in kt_live and kt_live[dom]["launches"]:
         k = kt_live[dom]
-        nbytes = kernel_bytes(st, derive_bodies)[dom]
+        nbytes = kernel_bytes(st, derive_bodies, fused_narrow)[dom]
         live_ticks = len(range(0, args.steps, every))
         per_launch = k["launches"] / (live_ticks * scene.substeps)
         dur = 1e-3 * k["total_ms"] / k["launches"]
@@ -511,7 +522,7 @@ def main():
     kernel_ms = {k: round(v["total_ms"] / prof_frames, 4) for k, v in kt.items() if v["launches"]}
     value = n_dyn * scene.substeps * args.steps / elapsed
     n_rank = slab.plan.n_owned if slab is not None else n_dyn
-    bpbs = tick_bytes_per_body_substep(st2, n_rank, scene.substeps)
+    bpbs = tick_bytes_per_body_substep(st2, n_rank, scene.substeps, fused_narrow)
 
     out = {
         "metric": "body-substeps/sec (100k-body pile, 4 substeps)" if slab is None else
@@ -548,7 +559,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": KERNEL_NAMES[dom],
+            "kernel": names[dom],
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
@@ -558,7 +569,7 @@ def main():
             "launch_us": sp["launch_us"],
             "launches_per_step": kt[dom]["launches"] / prof_frames,
             "launch_us_second_leg": per_kernel[dom]["launch_us"],
-            "other_kernels": {KERNEL_NAMES[c].split(" ")[0]: {"achieved": round(v["achieved"], 1), "frac": round(v["achieved"] / HBM_PEAK_GBS, 4),
+            "other_kernels": {names[c].split(" ")[0]: {"achieved": round(v["achieved"], 1), "frac": round(v["achieved"] / HBM_PEAK_GBS, 4),
                                                                 "launch_us": round(v["launch_us"], 2), "bytes_per_launch": v["bytes_per_launch"],
                                                                 "traffic": load_traffic(c) if slab is None else None}
                               for c, v in per_kernel.items() if c != dom},

@@ -55,7 +55,7 @@ for _ in range(k):
 kt = w.kernel_times()
 print("per tick, us:", {a: round(1e3 * v["total_ms"] / k, 1) for a, v in kt.items() if v["launches"]})
 st = w.stats()
-kb = bench.kernel_bytes(st)
+kb = bench.kernel_bytes(st, fused_narrow=kt["narrow"]["launches"] == 0)
 for cls, nbytes in kb.items():
     v = kt[cls]
     if v["launches"]:

@@ -1279,9 +1279,9 @@ int sfx_tick_substep(sfx_world* w) {
     auto launch_pos = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
         fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;
         const uint32_t nt = tvp == 0 ? 512u : tvp == 1 ? 256u : 128u;
-        if (tvp == 2) hipLaunchKernelGGL(k_tile_pos<128>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
-        else if (tvp == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
-        else hipLaunchKernelGGL(k_tile_pos<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr);
+        if (tvp == 2) hipLaunchKernelGGL(k_tile_pos<128>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin, sp.vthr);
+        else if (tvp == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin, sp.vthr);
+        else hipLaunchKernelGGL(k_tile_pos<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin, sp.vthr);
     };
     auto launch_vel = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb, hipStream_t st = nullptr) {
         if (!(fb & kTileOnlyNear)) fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;   // (the near launch takes no tickets)
@@ -1292,21 +1292,26 @@ int sfx_tick_substep(sfx_world* w) {
         else hipLaunchKernelGGL(k_tile_vel<256>, dim3(grid), dim3(nt), 0, st, ph0, np, ep, fb, g, T, w->ctr, B, C, sp, vstamp);
     };
     mirror_entries(w);   // the narrowphase reads colliders (entries), the solves write bodies
-    {   // manifolds of all solver pairs at the poses integration and joints left (one pair per lane)
+    // The narrowphase inside the position sweep (sfx_kernels.h narrow_batch): every batch computes its own pairs' records
+    // before it solves them -- one launch less per substep, and the batches of the later phases do that work while they
+    // wait for their neighbours.  Same bits.  SFX_FUSE_NARROW=0 keeps the k_narrow launch (2: later phases only).
+    static const int fuse_narrow_mode = [] { const char* e = getenv("SFX_FUSE_NARROW"); return e ? atoi(e) : 1; }();
+    const int fuse_narrow = !fuse_narrow_mode ? 0 : fuse_narrow_mode == 2 ? kTileNarrow : (kTileNarrow | kTileNarrowAll);
+    if (!(fuse_narrow & kTileNarrowAll)) {   // manifolds of all solver pairs at the poses integration and joints left (one pair per lane)
         const uint32_t est = w->ctr_valid ? w->stale.n_pairs : w->max_pairs;
         Prof p(w, SFX_K_NARROW, w->ctr_valid ? w->stale.n_kept : 0);
         static const uint32_t ndiv = [] { const char* e = getenv("SFX_NARROW_DIV"); return e ? (uint32_t)std::max(1, atoi(e)) : 1u; }();
         hipLaunchKernelGGL(k_narrow, dim3(std::min(std::max(cdiv(est, kBlock * ndiv), 1u), 16384u)), dim3(kBlock), 0, w->stream, T, w->ctr,
-                           B, C, w->cfg.speculative_margin, sp.vthr);
+                           B, C, w->cfg.speculative_margin, sp.vthr, fuse_narrow ? 1u : 0u);
     }
     if (w->fuse_phases) {
         // all phases in one launch, batches wait for the neighbouring batches of earlier phases
         Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_kept : 0);
-        launch_pos(std::min(total_grid, res_pos), 0u, nph, ++w->epoch, kTileFallback | first);
+        launch_pos(std::min(total_grid, res_pos), 0u, nph, ++w->epoch, kTileFallback | first | fuse_narrow);
     } else {
         for (uint32_t ph = 0; ph < nph; ++ph) {
             Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_kept / nph : 0);
-            launch_pos(w->tile_grid[ph], ph, 1u, 0u, (ph + 1 == nph ? kTileFallback : 0) | kTileStaticFirst);
+            launch_pos(w->tile_grid[ph], ph, 1u, 0u, (ph + 1 == nph ? kTileFallback : 0) | kTileStaticFirst | fuse_narrow);
         }
     }
     if (!fuse_derive) {

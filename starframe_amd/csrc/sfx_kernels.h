@@ -1420,7 +1420,7 @@ __global__ __launch_bounds__(kColorThreads, 4) void k_batch_color(GridParams g, 
                     if (a_out) la = lx; else lb = lx;
                 }
                 tpair[bstart + dst] = make_uint4(s_a[e], s_b[e], la | (lb << 16), cc | (((cls << 22) | s_tile[f + s_tj[e]]) << 8));
-                if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_scl[e]], 1u)] = make_uint4(s_a[e], s_b[e], bstart + dst, 0u);
+                if (cc != SFX_PRUNED_COLOR) torder[bstart + atomicAdd(&s_cls[s_scl[e]], 1u)] = make_uint4(s_a[e], s_b[e], bstart + dst, cls);
             }
             for (uint32_t e = s_ptail_first + tid; e < np; e += kBlock) torder[bstart + e] = make_uint4(0u, 0u, kNoPair, 0u);  // pruned pairs: no narrowphase
             __syncthreads();
@@ -1688,7 +1688,7 @@ __device__ __forceinline__ void load_record(const ContactArrays& C, uint32_t slo
 #define SFX_NARROW_WAVES 1   // waves per SIMD the register budget of k_narrow must allow (build knob)
 #endif
 __global__ __launch_bounds__(kBlock, SFX_NARROW_WAVES) void k_narrow(TileArrays T, const Counters* __restrict__ ctr, BodyArrays B,
-                                                    ContactArrays C, float sm, float vthr) {
+                                                    ContactArrays C, float sm, float vthr, uint32_t first_phase_only) {
     const uint32_t ntp = min(ctr->tp_cursor, T.max_pairs);
     const uint32_t nfb = min(ctr->n_fb, T.fb_cap) ? ctr->fb_start[SFX_MAX_COLORS] : 0u;
     for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < ntp + nfb; j += gridDim.x * kBlock) {
@@ -1697,6 +1697,7 @@ __global__ __launch_bounds__(kBlock, SFX_NARROW_WAVES) void k_narrow(TileArrays 
             const uint4 o = T.torder[j];
             slot = o.z;
             if (slot == kNoPair) continue;
+            if (first_phase_only && o.w != 0u) continue;   // the batches of the later phases compute their own (kTileNarrow)
             a = o.x; b = o.y;
         } else {
             const uint2 ab = T.fsorted[j - ntp];
@@ -1711,8 +1712,48 @@ __global__ __launch_bounds__(kBlock, SFX_NARROW_WAVES) void k_narrow(TileArrays 
     }
 }
 
+// The narrowphase inside the position sweep (kTileNarrow): the workgroup that will solve a batch first computes the
+// records of the batch's pairs, in the batch's class-grouped order, exactly as k_narrow's lanes would (same function, same
+// inputs: the position sweep moves displacements, not poses or velocities, so a batch of a later phase sees what k_narrow
+// would have seen -- and does this work while the batches it waits for are still solving).  The records go through the
+// contact arrays: the velocity sweep reads them too.  Every storing wave drains its stores; the caller's next barrier
+// makes them visible to the workgroup's other waves (same CU, write-through L1).
+__device__ __forceinline__ void narrow_batch(const TileArrays& T, const BodyArrays& B, const ContactArrays& C, uint32_t start,
+                                             uint32_t np, float sm, float vthr, uint32_t nt) {
+    // (measured, profiles/r03/ab_fused_narrow.log: order entries fetched a round ahead: +-0; the bodies' records too: +6 us
+    // per launch -- the registers they take cost the compute more than the round trip they hide)
+    for (uint32_t k = threadIdx.x; k < np; k += nt) {
+        const uint4 o = T.torder[start + k];
+        const bool skip = o.z == kNoPair;
+        const uint32_t a = skip ? 0u : o.x, b = skip ? 0u : o.y;   // (no branch between the order entry and the gathers)
+        const float4 pa = B.pose[a], pb = B.pose[b], sa = B.shape[a], sb = B.shape[b], va = B.vel[a], vb = B.vel[b];
+        const float2 wa = B.mass[body_of(B, a)], wb = B.mass[body_of(B, b)];   // the masses are the BODIES' (a further collider has none of its own)
+        if (skip) continue;
+        PairRec r;
+        prepare_pair(pa, sa, va, wa, pb, sb, vb, wb, shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, vthr, r);
+        store_record(C, o.z, r);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void narrow_fallback(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
+                                                const ContactArrays& C, float sm, float vthr) {
+    const uint32_t nfb = min(ctr->n_fb, T.fb_cap) ? ctr->fb_start[SFX_MAX_COLORS] : 0u;
+    for (uint32_t k = threadIdx.x; k < nfb; k += blockDim.x) {
+        const uint2 ab = T.fsorted[k];
+        const uint32_t a = ab.x, b = ab.y;
+        PairRec r;
+        const float4 pa = B.pose[a], pb = B.pose[b], sa = B.shape[a], sb = B.shape[b];
+        const float2 wa = B.mass[body_of(B, a)], wb = B.mass[body_of(B, b)];
+        prepare_pair(pa, sa, B.vel[a], wa, pb, sb, B.vel[b], wb, shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, vthr, r);
+        store_record(C, T.max_pairs + k, r);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // The fallback list, solved by one whole workgroup directly on global memory after the last
-// phase, colour by colour (its manifolds come from k_narrow like everybody else's).
+// phase, colour by colour (its manifolds come from k_narrow like everybody else's, or from narrow_fallback).
 __device__ __forceinline__ void fallback_pos(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
                                              const ContactArrays& C, float max_corr) {
     const uint32_t nfb = min(ctr->n_fb, T.fb_cap);
@@ -1949,7 +1990,11 @@ __device__ __forceinline__ uint32_t phase_total(const Counters* __restrict__ ctr
 // kTileSlot: which of the two ticket counters this launch uses.
 // kTileOnlyNear / kTileOnlyFar: the velocity sweep of a slab world in two launches (k_near_closure): the near batches from
 // their list, then every other batch.
-constexpr int kTileFallback = 1, kTileStaticFirst = 2, kTileSlot = 4, kTileRaceSelfTest = 8, kTileOnlyNear = 16, kTileOnlyFar = 32;
+// kTileNarrow (position sweep): every batch computes the manifolds and frozen rows of its own pairs before it solves
+// them -- no k_narrow launch in that substep (narrow_batch below).
+// kTileNarrowAll: the batches of the first phase too (and the fallback list): no k_narrow launch at all.
+constexpr int kTileFallback = 1, kTileStaticFirst = 2, kTileSlot = 4, kTileRaceSelfTest = 8, kTileOnlyNear = 16, kTileOnlyFar = 32,
+              kTileNarrow = 64, kTileNarrowAll = 128;
 
 __device__ __forceinline__ uint32_t* ticket_of(Counters* __restrict__ ctr, int flags) {
     return &ctr->item_ticket[(flags & kTileSlot) ? 1 : 0];
@@ -2181,9 +2226,9 @@ __device__ __forceinline__ void build_steps(const uint32_t* __restrict__ runs, u
 // dynamic bodies' displacements are written back.  Poses are not touched: the displacement is applied once per body
 // where its velocity is derived.  Batches of one phase have disjoint bodies.
 template <int NT>
-__global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int flags, GridParams g,
+__global__ __launch_bounds__(NT, (NT == 256 && SFX_TILE_MIN_WAVES < 3) ? 3 : SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int flags, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
-                                                  float max_corr) {
+                                                  float max_corr, float sm, float vthr) {
     __shared__ float4 s_d[kMaxBX];
     __shared__ float2 s_mass[kMaxBX];
     __shared__ uint32_t s_gid[kMaxBX];
@@ -2205,6 +2250,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         // everything that no earlier phase of this launch writes is fetched before waiting for them: the step list, the
         // records of the first kDepth steps, the body ids, the masses
         const uint32_t side = tid & 1u, half = tid >> 1;   // two lanes per pair: body a, body b
+        if ((flags & kTileNarrow) && (ph != 0u || (flags & kTileNarrowAll))) narrow_batch(T, B, C, start, npb, sm, vthr, NT);
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
         build_steps<NT>(T.bruns + 64u * d.roff, ncol, s_step, &s_nsteps);
         for (uint32_t l = tid; l < nb; l += NT) {  // block bodies, then the large colliders outside the block its pairs touch
@@ -2297,7 +2343,10 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph
         SFX_TT_ADD(0, ttw, tt1); SFX_TT_ADD(3, tt0, tt4); SFX_TT_ADD(4, 0ull, 1ull); SFX_TT_ADD(7, tt3, tt4); SFX_TT_MAX(15, ttw, tt4);
     }
     // the fallback list is usually empty: then no workgroup pays for the exit ticket (fence + atomic round trip)
-    if ((flags & kTileFallback) && ctr->n_fb != 0u && last_workgroup(ctr)) fallback_pos(T, ctr, B, C, max_corr);
+    if ((flags & kTileFallback) && ctr->n_fb != 0u && last_workgroup(ctr)) {
+        if (flags & kTileNarrowAll) narrow_fallback(T, ctr, B, C, sm, vthr);
+        fallback_pos(T, ctr, B, C, max_corr);
+    }
 }
 
 // Velocity pass, same batches.  The bodies' velocities go to LDS; inside sfx_step (vstamp != 0) the first batch of the sweep

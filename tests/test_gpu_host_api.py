@@ -161,13 +161,15 @@ def test_kernel_times_of_all_launches_and_of_chosen_classes():
     for _ in range(2):
         prof.step(1.0 / 60.0)
     kt = prof.kernel_times(reset=True)
-    assert kt["solve_vel"]["launches"] == 2 * s.substeps and kt["narrow"]["launches"] == 2 * s.substeps
+    # (the narrowphase runs inside the position sweep: no k_narrow launch unless SFX_FUSE_NARROW=0 asks for it)
+    assert kt["solve_vel"]["launches"] == 2 * s.substeps and kt["solve_pos"]["launches"] == 2 * s.substeps
+    assert kt["narrow"]["launches"] == (2 * s.substeps if os.environ.get("SFX_FUSE_NARROW") == "0" else 0)
     assert kt["pair_count"]["launches"] == 2 and kt["solve_vel"]["total_ms"] > 0.0
-    prof.set_profiling_classes(["solve_vel", "narrow"])
+    prof.set_profiling_classes(["solve_vel", "integrate"])
     for _ in range(3):
         prof.step(1.0 / 60.0)
     kt = prof.kernel_times(reset=True)
-    assert kt["solve_vel"]["launches"] == 3 * s.substeps and kt["narrow"]["launches"] == 3 * s.substeps
+    assert kt["solve_vel"]["launches"] == 3 * s.substeps and kt["integrate"]["launches"] == 3 * s.substeps
     assert kt["solve_pos"]["launches"] == 0 and kt["pair_count"]["launches"] == 0
     assert 0.0 < kt["solve_vel"]["total_ms"] < 50.0
     prof.set_profiling(False)
