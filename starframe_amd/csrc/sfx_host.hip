@@ -112,6 +112,7 @@ struct sfx_world {
     bool counted = false;          // this world is in g_live_worlds[device]
     int tile_slot = 0;             // ticket counter of the next tile-solve launch (alternates)
     uint32_t ctr_skipped = 0;      // ticks since the last asynchronous read-back of the counters
+    uint32_t ctr_age = 0;          // ticks begun since the pending read-back was enqueued
     int tile_variant_fixed = -1;   // SFX_TILE_NT=512|256|128 pins the variant (tuning); -1: the default (256)
     int tile_variant_pos = -1, tile_variant_vel = -1;  // SFX_TILE_NT_POS / SFX_TILE_NT_VEL: per kernel (tuning)
     bool fuse_phases = true;
@@ -1158,6 +1159,12 @@ int sfx_tick_begin(sfx_world* w, float frame_dt) {
     if (rc) return rc;
     if (!(frame_dt > 0.0f)) return fail(w, SFX_ERR_INVALID, "frame_dt must be positive");
     HIPCHK(w, hipSetDevice(w->device));
+    // The launch sizes follow the counters of an earlier tick.  A caller that enqueues ticks without ever synchronising
+    // could run arbitrarily far ahead of them -- a scene whose pair count grows a thousandfold meanwhile would run its tile
+    // sweeps on the few workgroups of the empty scene (measured on the chains config: 4.4 ms per tick instead of 0.5) --
+    // so the host waits for a read-back that is kMaxLag ticks old (the device still has that many ticks queued: no bubble).
+    static const uint32_t max_lag = [] { const char* e = getenv("SFX_CTR_MAX_LAG"); return e ? (uint32_t)std::max(0, atoi(e)) : 16u; }();
+    if (w->ctr_pending && max_lag && ++w->ctr_age > max_lag) HIPCHK(w, hipEventSynchronize(w->ev_ctr));
     poll_counters(w);
     if (w->ovf_host)
         return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u, listed by sfx_sync): its results are incomplete; sfx_sync reports "
@@ -1372,6 +1379,7 @@ static int substeps_done(sfx_world* w, uint32_t count, bool mirror) {
         // back every few ticks: the copy costs the stream about 6 us
         if (!w->ctr_pending && (!w->ctr_valid || ++w->ctr_skipped >= every)) {
             w->ctr_skipped = 0;
+            w->ctr_age = 0;
             HIPCHK(w, hipMemcpyAsync(w->h_ctr, w->ctr, sizeof(Counters), hipMemcpyDeviceToHost, w->stream));
             HIPCHK(w, hipEventRecord(w->ev_ctr, w->stream));
             w->ctr_pending = true;
