@@ -7,7 +7,7 @@
 #![allow(non_camel_case_types)]
 use std::os::raw::{c_char, c_int, c_void};
 
-pub const SFX_ABI_VERSION: u32 = 11;
+pub const SFX_ABI_VERSION: u32 = 12;
 
 // sfx_status
 pub const SFX_OK: c_int = 0;
@@ -60,7 +60,8 @@ pub const SFX_K_STATS: usize = 12;
 pub const SFX_K_HALO: usize = 13;
 pub const SFX_K_QUERY: usize = 14;
 pub const SFX_K_NARROW: usize = 15;
-pub const SFX_K_CLASSES: usize = 16;
+pub const SFX_K_TICK: usize = 16;
+pub const SFX_K_CLASSES: usize = 17;
 
 #[repr(C)]
 #[derive(Clone, Copy, Default)]

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SFX_ABI_VERSION 11u
+#define SFX_ABI_VERSION 12u
 
 typedef enum sfx_status {
     SFX_OK = 0,
@@ -226,7 +226,8 @@ typedef struct sfx_ray_hit {
 typedef enum sfx_kernel_class {
     SFX_K_AABB_COUNT = 0, SFX_K_SCAN, SFX_K_SCATTER, SFX_K_PAIR_COUNT, SFX_K_PAIR_FILL,
     SFX_K_TILE_LIST, SFX_K_COLOR, SFX_K_INTEGRATE, SFX_K_SOLVE_JOINTS, SFX_K_SOLVE_POS,
-    SFX_K_DERIVE_VEL, SFX_K_SOLVE_VEL, SFX_K_STATS, SFX_K_HALO, SFX_K_QUERY, SFX_K_NARROW, SFX_K_CLASSES
+    SFX_K_DERIVE_VEL, SFX_K_SOLVE_VEL, SFX_K_STATS, SFX_K_HALO, SFX_K_QUERY, SFX_K_NARROW,
+    SFX_K_TICK /* all substeps of a tick in one launch: narrowphase, position and velocity sweeps (sfx_step) */, SFX_K_CLASSES
 } sfx_kernel_class;
 
 typedef struct sfx_kernel_time {

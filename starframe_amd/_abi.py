@@ -86,7 +86,7 @@ class SfxKernelTime(C.Structure):
     _fields_ = [("total_ms", C.c_double), ("launches", C.c_uint64), ("items", C.c_uint64)]
 
 
-K_CLASSES = 16
+K_CLASSES = 17
 NO_BODY = 0xFFFFFFFF
 
 collider_dtype = np.dtype(

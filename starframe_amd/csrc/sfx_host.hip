@@ -90,6 +90,8 @@ struct sfx_world {
     DevBuf<float2> mass;
     uint32_t vel_epoch = 0;        // derive-on-load: stamp of the current substep's velocity solve (sfx_step only)
     uint32_t vel_prev_epoch = 0;   // stamp of the previous substep of this tick when it left bodies underived, else 0
+    bool dpos_clean = false;       // every displacement record is zero (the one-launch tick leaves them so and relies on it)
+    uint32_t resident_tick = 0;    // workgroups of k_tile_tick<256> the device holds at once
     bool in_step = false;          // sfx_step is driving the substeps (it sees the whole tick)
     DevBuf<uint4> filt, sorted_filt;   // filter words by entry id / in slot order (written by k_finalize_slots)
     DevBuf<uint32_t> slot_of;          // slot of every entry; only worlds in which a dynamic body has further colliders
@@ -757,6 +759,7 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
         occ(k_tile_pos<512>, 512, w->resident_pos_v[0]); occ(k_tile_vel<512>, 512, w->resident_vel_v[0]);
         occ(k_tile_pos<256>, 256, w->resident_pos_v[1]); occ(k_tile_vel<256>, 256, w->resident_vel_v[1]);
         occ(k_tile_pos<128>, 128, w->resident_pos_v[2]); occ(k_tile_vel<128>, 128, w->resident_vel_v[2]);
+        occ(k_tile_tick<256>, 256, w->resident_tick);
         auto variant = [](int v) { return v == 512 ? 0 : v == 256 ? 1 : v == 128 ? 2 : -1; };
         if (const char* nt = getenv("SFX_TILE_NT")) {
             const int v = atoi(nt);
@@ -1212,6 +1215,7 @@ static bool small_world(const sfx_world* w) {
 static int small_substeps(sfx_world* w, uint32_t nsub) {
     const StepParams sp = w->sp;
     w->q_valid = false;
+    w->dpos_clean = false;
     JointArrays J;
     J.bodies = w->j_bodies.p; J.anchors = w->j_anchors.p; J.params = w->j_params.p;
     SmallJoints SJ;
@@ -1238,6 +1242,7 @@ int sfx_tick_substep(sfx_world* w) {
 
     const StepParams sp = w->sp;
     w->q_valid = false;
+    w->dpos_clean = false;   // (k_integrate zeroes the displacements at the start of a substep, nobody after its sweep)
     const BodyArrays B = body_arrays(w);
     const ContactArrays C = contact_arrays(w);
     JointArrays J;
@@ -1389,9 +1394,67 @@ static int substeps_done(sfx_world* w, uint32_t count, bool mirror) {
     return SFX_OK;
 }
 
+// The substeps of a tick as ONE launch (sfx_kernels.h k_tile_tick; DESIGN.md "The substeps of a tick as one launch"): the
+// position and velocity sweeps of all substeps are the items of one ticketed launch, integration and the narrowphase happen
+// where bodies and pairs are loaded, and a batch waits for the batches around it instead of the device waiting for the end
+// of a launch.  Taken by sfx_step (which sees the whole tick) for worlds whose substeps are contact sweeps and nothing else:
+// no joints, no further colliders (their mirrors are refreshed between the stages), no halos (exchanged between
+// substeps), no per-stage profiling.  Same bits as the launch-per-stage path.  SFX_FUSE_TICK=0 keeps that path.
+static const bool g_fuse_tick_off = [] { const char* e = getenv("SFX_FUSE_TICK"); return e && e[0] == '0'; }();
+
+static bool tick_fused(const sfx_world* w) {
+    static const bool other_knobs = [] {   // the launch-per-stage variants these knobs ask for
+        const char* a = getenv("SFX_FUSE_DERIVE"); const char* b = getenv("SFX_FUSE_NARROW");
+        return (a && a[0] == '0') || (b && atoi(b) != 1);
+    }();
+    if (g_fuse_tick_off || other_knobs || !w->fuse_phases || w->profiling || w->resident_tick < 32u) return false;
+    if (w->joint_color_start.size() > 1 || w->joint_damped || w->n != w->nb || w->n_halo_send || w->n_halo_recv) return false;
+    if (w->tile_variant_fixed >= 0 && w->tile_variant_fixed != 1) return false;
+    if ((w->tile_variant_pos >= 0 && w->tile_variant_pos != 1) || (w->tile_variant_vel >= 0 && w->tile_variant_vel != 1)) return false;
+    if (((uint64_t)w->max_pairs + w->fb_cap) * kRecPlanes * 16ull >= 0xFFFFFFF0ull) return false;   // record planes addressed by 32-bit byte offsets
+    return true;
+}
+
+static int tick_substeps(sfx_world* w) {
+    const StepParams sp = w->sp;
+    const uint32_t nsub = w->cfg.substeps;
+    w->q_valid = false;
+    const BodyArrays B = body_arrays(w);
+    const ContactArrays C = contact_arrays(w);
+    const TileArrays T = tile_arrays(w);
+    const GridParams g = grid_params(w);
+    if (!w->dpos_clean) {   // the launch-per-stage path (or the upload) left displacements behind
+        HIPCHK(w, hipMemsetAsync(w->dpos.p, 0, sizeof(float4) * (size_t)w->n, w->stream));
+        w->dpos_clean = true;
+    }
+    const uint32_t nph = (w->tly == w->gyl) ? 2u : 4u;
+    uint32_t total_grid = 0;
+    for (uint32_t ph = 0; ph < nph; ++ph) total_grid += w->tile_grid[ph];
+    const uint32_t epoch0 = w->epoch;   // sweep u publishes epoch0 + u + 1
+    w->epoch += 2u * nsub;
+    if (w->vel_epoch > 0xFFFF0000u) w->vel_epoch = 0u;
+    const uint32_t vstamp0 = w->vel_epoch + 1u;   // substep s stamps vstamp0 + s (never 0)
+    w->vel_epoch += nsub;
+    static const int race_selftest = [] { const char* e = getenv("SFX_RACE_SELFTEST"); return (e && e[0] == '1') ? kTileRaceSelfTest : 0; }();
+    int fl = ((w->counted && g_live_worlds[w->device].load() == 1 && !g_shared_device) ? kTileStaticFirst : 0) | race_selftest;
+    fl |= (w->tile_slot ^= 1) ? kTileSlot : 0;
+    // two sweeps can be under way at once (a batch of the next sweep starts when the batches around it are done)
+    const uint32_t grid = std::max(std::min(2u * total_grid, w->resident_tick), 1u);
+    { Prof p(w, SFX_K_TICK, w->ctr_valid ? (uint64_t)w->stale.n_kept * nsub : 0);
+      hipLaunchKernelGGL(k_tile_tick<256>, dim3(grid), dim3(256), 0, w->stream, nsub, nph, epoch0, vstamp0, fl, g, T, w->ctr, B, C, sp,
+                         w->cfg.speculative_margin); }
+    { Prof p(w, SFX_K_INTEGRATE, w->nb);
+      hipLaunchKernelGGL(k_tick_free, dim3(cdiv(std::max(w->nb, 1u), kBlock)), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p,
+                         w->vel.p, w->mass.p, sp, nsub, vstamp0 + nsub - 1u); }
+    w->vel_prev_epoch = 0u;
+    HIPCHK(w, hipGetLastError());
+    return substeps_done(w, nsub, true);
+}
+
 int sfx_step(sfx_world* w, float frame_dt) {
     int rc = sfx_tick_begin(w, frame_dt);
     if (rc == SFX_OK && small_world(w)) return small_substeps(w, w->cfg.substeps);   // the whole tick in one launch
+    if (rc == SFX_OK && tick_fused(w)) return tick_substeps(w);                      // the substeps in one launch
     w->in_step = true;   // the substeps below are the whole tick: velocities may stay underived between them
     for (uint32_t s = 0; rc == SFX_OK && s < w->cfg.substeps; ++s) rc = sfx_tick_substep(w);
     w->in_step = false;
@@ -2129,7 +2192,7 @@ int sfx_debug_tile_timing(sfx_world* w, unsigned long long* out, int reset) {
 const char* sfx_kernel_class_name(int cls) {
     static const char* names[SFX_K_CLASSES] = {
         "aabb_count", "scan", "scatter", "pair_count", "pair_fill", "tile_list", "color", "integrate",
-        "solve_joints", "solve_pos", "derive_vel", "solve_vel", "stats", "halo", "query", "narrow"};
+        "solve_joints", "solve_pos", "derive_vel", "solve_vel", "stats", "halo", "query", "narrow", "tick"};
     return (cls >= 0 && cls < SFX_K_CLASSES) ? names[cls] : "?";
 }
 

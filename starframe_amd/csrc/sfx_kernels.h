@@ -87,7 +87,7 @@ struct Counters {
                               // the two counters and every launch clears the one its successor will use
     uint32_t n_medium;      // colliders sorted into the grid's second level (written by k_finalize_slots)
     uint32_t n_near;        // batches on the near list (k_near_closure; slab worlds with the exchange overlapped)
-    uint32_t pad3[1];
+    uint32_t fb_done;       // k_tile_tick: epoch0 + u + 1 once the fallback list of sweep u has been solved
 };
 static_assert(sizeof(Counters) % 16 == 0, "the per-tick block is cleared in 16-byte units");
 static_assert(offsetof(Counters, overflow) == 12, "k_zero / k_aabb_count fold word 3 of the block into the sticky overflow word");
@@ -2527,6 +2527,421 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
 #ifdef SFX_TILE_TIMING
     if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[49 + 2 * (epoch & 15u)], wall_clock64());    // latest kernel exit
 #endif
+}
+
+// ---------------------------------------------------------------- all substeps of a tick in ONE launch
+// DESIGN.md "The substeps of a tick as one launch".  On a world of 100 k bodies a sweep is a chain of dependent colour
+// steps that keeps a wave or two per CU busy, and every launch boundary is a device-wide barrier in front of which the
+// whole device waits for the slowest chain (and pays a launch's start and end).  Nothing in a substep needs that
+// barrier: a batch depends on the batches around it only.  Here the position and the velocity sweeps of ALL substeps
+// are the items of one launch -- item = (sweep u = 2 * substep + (0: position, 1: velocity), class, batch), in that
+// order, handed out by ticket as in the launches above -- and a batch waits for exactly the batches that can have
+// touched what it reads or writes: the batches of the 3 x 3 tiles around its own, of every class, in the sweep before
+// (flag >= epoch0 + u) and of the earlier classes in its own sweep (flag >= epoch0 + u + 1).  A batch publishes
+// epoch0 + u + 1 in its flag, the same flag in every sweep, so the flags only grow and "has finished sweep u" implies
+// every sweep before it.  What used to sit between the sweeps moved into them:
+//   - integration: a body's pose and velocity at the start of a substep are a function of its record at the end of the
+//     substep before (integrate_body); the narrowphase computes them where it loads a body (tick_integrate) and the
+//     velocity sweep where it derives one (the first batch to load a body: it integrates, applies the displacement,
+//     derives, stamps and writes the body back, and zeroes its displacement for the next substep).  No k_integrate, no
+//     start-of-substep poses in memory.  Bodies that are not dynamic are written by nobody inside the launch: substep s
+//     sees them integrated s + 1 times from their record (their velocity is constant);
+//   - the bodies no batch holds are not read by any pair: k_tick_free steps them through all substeps after the launch;
+//   - the fallback list (usually empty) follows all batches of a sweep: the workgroup that finishes a sweep's last batch
+//     solves it, and while there is one every batch of the next sweep waits for it.
+// Everything a later item reads is stored write-through (records, multipliers, displacements, poses, velocities) and
+// handed over as between the phases of the launches above.  Same functions, same order per body and pair: the states
+// are bit-identical to the launch-per-stage path (tests/test_gpu_fused_tick.py).  Host side: sfx_host.hip tick_fused().
+static_assert(kBatchP * sizeof(float2) <= kMaxBX * sizeof(float4), "the multipliers of a batch share the LDS of the friction shifts");
+
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void store_rec_wt(__amdgpu_buffer_rsrc_t rs, uint32_t idx, const float4& v) {
+    const v4u32 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, rs, (int)(idx * 16u), 0, 16 /* sc1: write-through */);
+}
+
+// store_record with write-through stores (rs: raw buffer over C.rec; the host checks that all planes lie within 4 GB)
+__device__ __forceinline__ void store_record_wt(const ContactArrays& C, __amdgpu_buffer_rsrc_t rs, uint32_t slot, const PairRec& r) {
+    const uint32_t n = C.nslots;
+    store_rec_wt(rs, kPlA * n + slot, make_float4(r.nx, r.ny, __uint_as_float((uint32_t)r.count | (r.block ? 256u : 0u)), r.iK[0]));
+    if (r.count == 0) return;
+    store_rec_wt(rs, kPlB * n + slot, make_float4(r.ca[0], r.cb[0], r.d0[0], r.tgt[0]));
+    store_rec_wt(rs, kPlC * n + slot, make_float4(r.cta, r.ctb, r.mu_s, r.mu_d));
+    store_rec_wt(rs, kPlD * n + slot, make_float4(r.At[0], r.invS, r.Att, 0.0f));
+    if (r.count == 2) {
+        store_rec_wt(rs, kPlE * n + slot, make_float4(r.ca[1], r.cb[1], r.d0[1], r.tgt[1]));
+        store_rec_wt(rs, kPlF * n + slot, make_float4(r.i00, r.i01, r.i11, r.K01));
+        store_rec_wt(rs, kPlG * n + slot, make_float4(r.iK[1], r.At[1], r.invS0, r.invS1));
+    }
+}
+
+// pose and velocity of a body at the start of substep `s` of the launch, from its record
+__device__ __forceinline__ void tick_integrate(float4& p, float4& v, const float2& w, const StepParams& sp, uint32_t s) {
+    float4 q;
+    if (w.x > 0.0f || w.y > 0.0f) { integrate_body(p, q, v, w, sp); return; }   // written back at the end of every substep
+    for (uint32_t i = 0; i <= s; ++i) {   // not dynamic: its record is the one of the start of the tick
+        const float4 p0 = p;
+        integrate_body(p, q, v, w, sp);
+        // (a body at rest is a fixed point after at most a rounding of its rotation: the later steps change nothing)
+        if (__float_as_uint(p.x) == __float_as_uint(p0.x) && __float_as_uint(p.y) == __float_as_uint(p0.y) &&
+            __float_as_uint(p.z) == __float_as_uint(p0.z) && __float_as_uint(p.w) == __float_as_uint(p0.w)) break;
+    }
+}
+
+__device__ __forceinline__ void narrow_batch_tick(const TileArrays& T, const BodyArrays& B, const ContactArrays& C,
+                                                  __amdgpu_buffer_rsrc_t rec_rs, uint32_t start, uint32_t np, float sm,
+                                                  const StepParams& sp, uint32_t s, uint32_t nt) {
+    for (uint32_t k = threadIdx.x; k < np; k += nt) {
+        const uint4 o = T.torder[start + k];
+        const bool skip = o.z == kNoPair;
+        const uint32_t a = skip ? 0u : o.x, b = skip ? 0u : o.y;   // (no branch between the order entry and the gathers)
+        float4 pa = B.pose[a], pb = B.pose[b], va = B.vel[a], vb = B.vel[b];
+        const float4 sa = B.shape[a], sb = B.shape[b];
+        const float2 wa = B.mass[a], wb = B.mass[b];   // (no further colliders in a world that takes this path: entries are bodies)
+        if (skip) continue;
+        tick_integrate(pa, va, wa, sp, s);
+        tick_integrate(pb, vb, wb, sp, s);
+        PairRec r;
+        prepare_pair(pa, sa, va, wa, pb, sb, vb, wb, shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, sp.vthr, r);
+        store_record_wt(C, rec_rs, o.z, r);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+__device__ __forceinline__ void narrow_fallback_tick(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
+                                                     const ContactArrays& C, float sm, const StepParams& sp, uint32_t s) {
+    const uint32_t nfb = min(ctr->n_fb, T.fb_cap) ? ctr->fb_start[SFX_MAX_COLORS] : 0u;
+    for (uint32_t k = threadIdx.x; k < nfb; k += blockDim.x) {
+        const uint2 ab = T.fsorted[k];
+        const uint32_t a = ab.x, b = ab.y;
+        PairRec r;
+        float4 pa = B.pose[a], pb = B.pose[b], va = B.vel[a], vb = B.vel[b];
+        const float4 sa = B.shape[a], sb = B.shape[b];
+        const float2 wa = B.mass[a], wb = B.mass[b];
+        tick_integrate(pa, va, wa, sp, s);
+        tick_integrate(pb, vb, wb, sp, s);
+        prepare_pair(pa, sa, va, wa, pb, sb, vb, wb, shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, sp.vthr, r);
+        store_record(C, T.max_pairs + k, r);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
+// fallback_vel of the one-launch tick: a dynamic body of the list that no batch has stepped yet in this substep is
+// integrated, moved and derived here, whether or not its pair touches (nobody else will)
+__device__ __forceinline__ void fallback_vel_tick(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
+                                                  const ContactArrays& C, const StepParams& sp, uint32_t vstamp) {
+    const uint32_t nfb = min(ctr->n_fb, T.fb_cap);
+    if (nfb == 0) return;
+    const uint32_t nc = ctr->n_fb_colors;
+    const float4 zero = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t c = 0; c < nc; ++c) {
+        const uint32_t s = ctr->fb_start[c], e = ctr->fb_start[c + 1];
+        for (uint32_t k = s + threadIdx.x; k < e; k += blockDim.x) {
+            const uint2 ab = T.fsorted[k];
+            PairRec r;
+            load_record(C, T.max_pairs + k, r);
+            float4 va = B.vel[ab.x], vb = B.vel[ab.y];
+            const float2 wa = B.mass[ab.x], wb = B.mass[ab.y];
+            const bool dyna = wa.x > 0.0f || wa.y > 0.0f, dynb = wb.x > 0.0f || wb.y > 0.0f;
+            bool da = false, db = false;
+            if (dyna && __float_as_uint(va.w) != vstamp) {
+                float4 pa = B.pose[ab.x], q;
+                integrate_body(pa, q, va, wa, sp);
+                apply_delta(pa, B.dpos[ab.x]);
+                derive_body(pa, q, va, sp); va.w = __uint_as_float(vstamp); da = true;
+                B.pose[ab.x] = pa; B.dpos[ab.x] = zero;
+            }
+            if (dynb && __float_as_uint(vb.w) != vstamp) {
+                float4 pb = B.pose[ab.y], q;
+                integrate_body(pb, q, vb, wb, sp);
+                apply_delta(pb, B.dpos[ab.y]);
+                derive_body(pb, q, vb, sp); vb.w = __uint_as_float(vstamp); db = true;
+                B.pose[ab.y] = pb; B.dpos[ab.y] = zero;
+            }
+            float4 Sa = zero, Sb = zero;
+            const int ch = r.count ? solve_vel_rec(r, va, wa, vb, wb, Sa, Sb, sp) : 0;
+            if (ch || da || db) {
+                if (dyna) B.vel[ab.x] = va;
+                if (dynb) B.vel[ab.y] = vb;
+            }
+            if (ch & 2) {
+                if (dyna) { float4 pa = B.pose[ab.x]; apply_delta(pa, Sa); B.pose[ab.x] = pa; }
+                if (dynb) { float4 pb = B.pose[ab.y]; apply_delta(pb, Sb); B.pose[ab.y] = pb; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// first wave: the batches of the 3 x 3 tiles around each of this batch's tiles have published at least tgt_lo (classes
+// below p_split, if `lo`) / tgt_hi (the other classes, if `hi`), and the fallback list of the sweep before is done (if
+// `fb`); then one agent-scope acquire.  Always ends in a workgroup barrier.
+template <int NT>
+__device__ __forceinline__ void tick_wait(const TileArrays& T, const GridParams& g, Counters* __restrict__ ctr,
+                                          const uint32_t* __restrict__ tiles, uint32_t count, uint32_t nph, uint32_t p_split,
+                                          bool lo, uint32_t tgt_lo, bool hi, uint32_t tgt_hi, bool fb, uint32_t tgt_fb) {
+    if ((lo && p_split > 0u) || hi || fb) {   // (uniform)
+        if (threadIdx.x < 64u) {
+            const uint32_t lx = g.gxl - g.tlx;
+            const bool one_row = g.tly == g.gyl;
+            for (uint32_t j = threadIdx.x; j < count * 9u; j += 64u) {
+                const uint32_t t = tiles[j / 9u], dir = j % 9u;
+                const int dx = (int)(dir % 3u) - 1, dy = (int)(dir / 3u) - 1;
+                if (one_row && dy != 0) continue;
+                const int32_t tx = (int32_t)(t & ((1u << lx) - 1u)), ty = (int32_t)(t >> lx);
+                const uint32_t t2 = tile_of(tx + dx, ty + dy, g);
+                for (uint32_t p2 = 0; p2 < nph; ++p2) {
+                    const bool is_lo = p2 < p_split;
+                    if (is_lo ? !lo : !hi) continue;
+                    const uint32_t tgt = is_lo ? tgt_lo : tgt_hi;
+                    const uint32_t b2 = T.tile_batch[p2 * g.ntiles + t2];
+                    if (!b2) continue;  // that tile has no pairs of that class this tick
+                    const uint32_t* flag = &T.done[p2 * g.pstride + (b2 - 1u)];
+                    uint32_t spins = 0;
+                    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tgt) < 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > 400000u) { atomicOr(&ctr->overflow, kOvfStall); break; }
+                    }
+                }
+            }
+            if (fb && threadIdx.x == 0u) {
+                uint32_t spins = 0;
+                while ((int32_t)(__hip_atomic_load(&ctr->fb_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tgt_fb) < 0) {
+                    __builtin_amdgcn_s_sleep(2);
+                    if (++spins > 400000u) { atomicOr(&ctr->overflow, kOvfStall); break; }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate has completed before the barrier opens
+        }
+    }
+    __syncthreads();
+}
+
+// the fallback list of one sweep, by the workgroup that finished the sweep's last batch (all threads).  (Measured as a
+// function that is not inlined: the call costs the sweeps 105 spilled VGPRs instead of 42.)
+__device__ __forceinline__ void tick_fallback(bool vel, const TileArrays& T, Counters* __restrict__ ctr, const BodyArrays& B,
+                                                        const ContactArrays& C, float sm, const StepParams& sp, uint32_t s,
+                                                        uint32_t vstamp, uint32_t e_cur) {
+    if (threadIdx.x < 64u) {   // every batch of the sweep has published: their stores are in memory
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (!vel) {
+        narrow_fallback_tick(T, ctr, B, C, sm, sp, s);
+        fallback_pos(T, ctr, B, C, sp.max_corr);
+    } else {
+        fallback_vel_tick(T, ctr, B, C, sp, vstamp);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0u) {   // plain stores above: one release for the workgroup, then the flag
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&ctr->fb_done, e_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+#ifndef SFX_TICK_WAVES
+#define SFX_TICK_WAVES 3
+#endif
+template <int NT>
+__global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub, uint32_t nph, uint32_t epoch0, uint32_t vstamp0, int flags,
+                                                     GridParams g, TileArrays T, Counters* __restrict__ ctr, BodyArrays B,
+                                                     ContactArrays C, StepParams sp, float sm) {
+    __shared__ float4 s_a[kMaxBX];     // position sweep: displacements; velocity sweep: velocities
+    __shared__ float4 s_b[kMaxBX];     // position sweep: the batch's multipliers (float2 per pair); velocity sweep: static-friction shifts
+    __shared__ float2 s_mass[kMaxBX];
+    __shared__ uint32_t s_gid[kMaxBX];
+    __shared__ uint32_t s_step[kMaxSteps], s_nsteps, s_next, s_fb;
+    SFX_RACE_DECL
+    float2* const s_lam = reinterpret_cast<float2*>(s_b);
+    constexpr int kRounds = (int)((kMaxBX + NT - 1) / NT);
+    const uint32_t tid = threadIdx.x;
+    const __amdgpu_buffer_rsrc_t dpos_rs = record_rsrc(B.dpos), pose_rs = record_rsrc(B.pose), vel_rs = record_rsrc(B.vel),
+                                 rec_rs = record_rsrc(C.rec);
+    const __amdgpu_buffer_rsrc_t lam_rs = __builtin_amdgcn_make_buffer_rsrc((void*)C.lam, 0, (int)0xFFFFFFF0u, 0x00020000);
+    const uint32_t S = phase_total(ctr, 0u, nph);
+    const uint32_t nitems = S * 2u * nsub;
+    const bool has_fb = ctr->n_fb != 0u;
+    const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t item = next_item(ctr, flags); item < nitems; item = s_next) {
+        const uint32_t u = item / S, ri = item - u * S, s = u >> 1;
+        const bool vel = (u & 1u) != 0u;
+        const PhaseItem pi = phase_item(ctr, 0u, nph, ri);
+        const uint32_t ph = pi.ph, it = pi.it;
+        const BatchDesc d = T.batches[ph * g.pstride + it];
+        const uint32_t* tiles = T.active + d.first;
+        const uint32_t ntl = d.count & ~kBatchNear;
+        const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol, npb = min(d.np, kBatchP);
+        const uint32_t side = tid & 1u, half = tid >> 1;   // two lanes per pair: body a, body b
+        const uint32_t e_prev = epoch0 + u, e_cur = e_prev + 1u;   // flags of the sweep before / of this sweep
+        __syncthreads();  // the previous item's write-back has read the LDS arrays
+        // what is the same all frame long -- the step list, the body ids, the masses -- before any waiting
+        build_steps<NT>(T.bruns + 64u * d.roff, ncol, s_step, &s_nsteps);
+        for (uint32_t l = tid; l < nb; l += NT) {
+            s_gid[l] = T.bbody[d.boff + l];
+            s_mass[l] = T.bmass[d.boff + l];
+            if (vel) s_b[l] = zero4;
+            else if (ph == 0u) s_a[l] = zero4;   // nothing has moved yet in this substep
+        }
+        if (!vel) for (uint32_t k = tid; k < npb; k += NT) s_lam[k] = make_float2(0.0f, 0.0f);
+        SFX_RACE_CLEAR(nb)
+        uint32_t colour = 0u;   // (counts the barriers of the loop: the race detector's stamp)
+        (void)colour;
+        RawSide q;
+        if (!vel) {
+            // ---- position sweep of substep s: narrowphase of the batch's pairs at the integrated poses, then the colours
+            tick_wait<NT>(T, g, ctr, tiles, ntl, nph, 0u, false, 0u, u > 0u, e_prev, has_fb && u > 0u, e_prev);
+            narrow_batch_tick(T, B, C, rec_rs, start, npb, sm, sp, s, NT);
+            __syncthreads();   // the records of the other waves' pairs (same CU)
+            const uint32_t ns = s_nsteps;
+            uint32_t st_cur = __builtin_amdgcn_readfirstlane(s_step[0]), st_nxt = __builtin_amdgcn_readfirstlane(s_step[1]);
+            fetch_side<false>(T, C, start + (st_cur & 0xFFFFu) + half, side, 0u < ns && (st_cur & 0xFFFFu) + half < (st_cur >> 16), q);
+            if (ph != 0u) {
+                tick_wait<NT>(T, g, ctr, tiles, ntl, nph, ph, true, e_cur, false, 0u, false, 0u);
+                for (uint32_t l = tid; l < nb; l += NT) s_a[l] = B.dpos[s_gid[l]];
+                __syncthreads();
+            }
+            const uint32_t ahead = take_ahead<NT>(ctr, flags);
+            for (uint32_t sidx = 0; sidx < ns; ++sidx) {
+                const uint32_t st = st_cur, st2 = st_nxt;
+                const uint32_t st3 = s_step[min(sidx + 2u, kMaxSteps - 1u)];
+                const uint32_t k = (st & 0xFFFFu) + half;
+                SideSlot cur;
+                decode_side<false>(q, side, cur, nb);
+                {
+                    const uint32_t k2 = (st2 & 0xFFFFu) + half;
+                    fetch_side<false>(T, C, start + k2, side, sidx + 1u < ns && k2 < (st2 >> 16), q);
+                }
+                if (cur.valid) {
+                    float4 D = s_a[cur.li];
+                    const float2 w = s_mass[cur.li];
+                    if (solve_pos_side(cur.r, D, w, sp.max_corr)) {
+                        if (w.x > 0.0f || w.y > 0.0f) { SFX_RACE_WRITE(cur.li, colour); s_a[cur.li] = D; }
+                    }
+                    if (side == 0u) s_lam[k] = make_float2(cur.r.l0, cur.r.l1);
+                }
+                if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) { lds_barrier(); ++colour; }
+                st_cur = st2; st_nxt = __builtin_amdgcn_readfirstlane(st3);
+            }
+            __syncthreads();
+            if (tid == NT - 64) s_next = ahead;
+            for (uint32_t k = tid; k < npb; k += NT) {
+                const float2 lm = s_lam[k];
+                const v2u32 uu = {__float_as_uint(lm.x), __float_as_uint(lm.y)};
+                __builtin_amdgcn_raw_buffer_store_b64(uu, lam_rs, (int)((start + k) * 8u), 0, 16 /* sc1 */);
+            }
+            for (uint32_t l = tid; l < nb; l += NT) {
+                const float2 w = s_mass[l];
+                if (w.x > 0.0f || w.y > 0.0f) store_record16<true>(B.dpos, dpos_rs, s_gid[l], s_a[l]);
+            }
+        } else {
+            // ---- velocity sweep of substep s: the first batch to load a body integrates it, applies its displacement and derives it
+            const uint32_t vstamp = vstamp0 + s;
+            tick_wait<NT>(T, g, ctr, tiles, ntl, nph, ph, true, e_cur, true, e_prev, has_fb, e_prev);
+            const uint32_t ns = s_nsteps;
+            uint32_t st_cur = __builtin_amdgcn_readfirstlane(s_step[0]), st_nxt = __builtin_amdgcn_readfirstlane(s_step[1]);
+            fetch_side<true>(T, C, start + (st_cur & 0xFFFFu) + half, side, 0u < ns && (st_cur & 0xFFFFu) + half < (st_cur >> 16), q);
+            float4 rp[kRounds];
+            uint32_t derived = 0u;
+#pragma unroll
+            for (int j = 0; j < kRounds; ++j) {
+                const uint32_t l = tid + (uint32_t)j * NT;
+                rp[j] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
+                if (l < nb) {
+                    const uint32_t gid = s_gid[l];
+                    float4 ps = B.pose[gid];
+                    float4 vs = B.vel[gid];
+                    const float4 dd = B.dpos[gid];   // (fetched beside the others: no load waits for the stamp)
+                    const float2 w = s_mass[l];
+                    if ((w.x > 0.0f || w.y > 0.0f) && __float_as_uint(vs.w) != vstamp) {
+                        float4 q0;
+                        integrate_body(ps, q0, vs, w, sp);
+                        apply_delta(ps, dd);
+                        derive_body(ps, q0, vs, sp);
+                        vs.w = __uint_as_float(vstamp);
+                        derived |= 1u << j;
+                    }
+                    rp[j] = ps;
+                    s_a[l] = vs;
+                }
+            }
+            __syncthreads();
+            const uint32_t ahead = take_ahead<NT>(ctr, flags);
+            for (uint32_t sidx = 0; sidx < ns; ++sidx) {
+                const uint32_t st = st_cur, st2 = st_nxt;
+                const uint32_t st3 = s_step[min(sidx + 2u, kMaxSteps - 1u)];
+                SideSlot cur;
+                decode_side<true>(q, side, cur, nb);
+                {
+                    const uint32_t k2 = (st2 & 0xFFFFu) + half;
+                    fetch_side<true>(T, C, start + k2, side, sidx + 1u < ns && k2 < (st2 >> 16), q);
+                }
+                if (cur.valid) {
+                    float4 vs = s_a[cur.li], Sh = s_b[cur.li];
+                    const float2 w = s_mass[cur.li];
+                    const int ch = solve_vel_side(cur.r, vs, Sh, w, sp);
+                    if (w.x > 0.0f || w.y > 0.0f) { SFX_RACE_WRITE(cur.li, colour); s_a[cur.li] = vs; if (ch & 2) s_b[cur.li] = Sh; }
+                }
+                if ((st & 0xFFFFu) + (uint32_t)(NT / 2) >= (st >> 16)) { lds_barrier(); ++colour; }
+                st_cur = st2; st_nxt = __builtin_amdgcn_readfirstlane(st3);
+            }
+            __syncthreads();
+            if (tid == NT - 64) s_next = ahead;
+#pragma unroll
+            for (int j = 0; j < kRounds; ++j) {
+                const uint32_t l = tid + (uint32_t)j * NT;
+                if (l < nb) {
+                    const float2 w = s_mass[l];
+                    if (w.x > 0.0f || w.y > 0.0f) {
+                        const float4 Sh = s_b[l];
+                        float4 ps = rp[j];
+                        if (Sh.x != 0.0f || Sh.y != 0.0f || Sh.z != 0.0f) apply_delta(ps, Sh);
+                        store_record16<true>(B.vel, vel_rs, s_gid[l], s_a[l]);
+                        store_record16<true>(B.pose, pose_rs, s_gid[l], ps);
+                        if (derived & (1u << j)) store_record16<true>(B.dpos, dpos_rs, s_gid[l], zero4);   // the next substep's sweep starts from nothing
+                    }
+                }
+            }
+        }
+        publish_batch(T, g, ph, it, e_cur);
+        if (has_fb) {   // the workgroup that finishes the last batch of a sweep solves the fallback list; the next sweep waits for it
+            if (tid == 0u) s_fb = (atomicAdd(&ctr->ticket, 1u) + 1u == (u + 1u) * S) ? 1u : 0u;
+            __syncthreads();
+            if (s_fb) tick_fallback(vel, T, ctr, B, C, sm, sp, s, vstamp0 + s, e_cur);
+        }
+    }
+}
+
+// The bodies no batch of the frame holds (and no fallback pair names) take part in nothing: after the launch above they
+// are stepped through the tick's substeps here, integrate and derive in turn as k_integrate / k_derive would.  `done`:
+// the stamp of the last substep's velocity sweep (a body that carries it has been stepped).  Bodies that are not dynamic
+// are integrated `nsub` times (the launch above only ever read them).
+__global__ __launch_bounds__(kBlock) void k_tick_free(uint32_t n, float4* __restrict__ pose, float4* __restrict__ prev,
+                                                      float4* __restrict__ vel, const float2* __restrict__ mass, StepParams sp,
+                                                      uint32_t nsub, uint32_t done) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float2 w = mass[i];
+    float4 v = vel[i];
+    const bool dyn = w.x > 0.0f || w.y > 0.0f;
+    if (dyn && __float_as_uint(v.w) == done) return;
+    float4 p = pose[i], q = p;
+    if (dyn) {
+        for (uint32_t s = 0; s < nsub; ++s) {
+            integrate_body(p, q, v, w, sp);
+            derive_body(p, q, v, sp);
+        }
+        vel[i] = v;
+    } else {
+        for (uint32_t s = 0; s < nsub; ++s) integrate_body(p, q, v, w, sp);
+    }
+    pose[i] = p;
+    prev[i] = q;
 }
 
 // ---------------------------------------------------------------- small worlds: whole substeps in ONE workgroup

@@ -28,7 +28,7 @@ def test_header_symbols_all_exported(libsfx):
     assert sorted(_abi.SFX_SYMBOLS) == syms, "starframe_amd/_abi.py symbol list out of date"
     for s in syms:
         assert hasattr(libsfx, s), f"libsfx.so does not export {s}"
-    assert libsfx.sfx_abi_version() == 11
+    assert libsfx.sfx_abi_version() == 12
 
 
 def test_rccl_library_exports_its_header():
