@@ -91,7 +91,7 @@ struct sfx_world {
     uint32_t vel_epoch = 0;        // derive-on-load: stamp of the current substep's velocity solve (sfx_step only)
     uint32_t vel_prev_epoch = 0;   // stamp of the previous substep of this tick when it left bodies underived, else 0
     bool dpos_clean = false;       // every displacement record is zero (the one-launch tick leaves them so and relies on it)
-    uint32_t resident_tick = 0;    // workgroups of k_tile_tick<256> the device holds at once
+    uint32_t resident_tick = 0, resident_tick_solve = 0;    // workgroups of k_tile_tick<256, with / without narrowphase> the device holds at once
     bool in_step = false;          // sfx_step is driving the substeps (it sees the whole tick)
     DevBuf<uint4> filt, sorted_filt;   // filter words by entry id / in slot order (written by k_finalize_slots)
     DevBuf<uint32_t> slot_of;          // slot of every entry; only worlds in which a dynamic body has further colliders
@@ -759,7 +759,7 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
         occ(k_tile_pos<512>, 512, w->resident_pos_v[0]); occ(k_tile_vel<512>, 512, w->resident_vel_v[0]);
         occ(k_tile_pos<256>, 256, w->resident_pos_v[1]); occ(k_tile_vel<256>, 256, w->resident_vel_v[1]);
         occ(k_tile_pos<128>, 128, w->resident_pos_v[2]); occ(k_tile_vel<128>, 128, w->resident_vel_v[2]);
-        occ(k_tile_tick<256>, 256, w->resident_tick);
+        occ(k_tile_tick<256, true>, 256, w->resident_tick); occ(k_tile_tick<256, false>, 256, w->resident_tick_solve);
         auto variant = [](int v) { return v == 512 ? 0 : v == 256 ? 1 : v == 128 ? 2 : -1; };
         if (const char* nt = getenv("SFX_TILE_NT")) {
             const int v = atoi(nt);
@@ -1400,7 +1400,8 @@ static int substeps_done(sfx_world* w, uint32_t count, bool mirror) {
 // of a launch.  Taken by sfx_step (which sees the whole tick) for worlds whose substeps are contact sweeps and nothing else:
 // no joints, no further colliders (their mirrors are refreshed between the stages), no halos (exchanged between
 // substeps), no per-stage profiling.  Same bits as the launch-per-stage path.  SFX_FUSE_TICK=0 keeps that path.
-static const bool g_fuse_tick_off = [] { const char* e = getenv("SFX_FUSE_TICK"); return e && e[0] == '0'; }();
+static const int g_fuse_tick_mode = [] { const char* e = getenv("SFX_FUSE_TICK"); return e ? atoi(e) : 1; }();   // 0: off, 1: one launch per tick, 2: per substep a narrowphase launch + one launch of both sweeps
+static const bool g_fuse_tick_off = g_fuse_tick_mode == 0;
 
 static bool tick_fused(const sfx_world* w) {
     static const bool other_knobs = [] {   // the launch-per-stage variants these knobs ask for
@@ -1430,19 +1431,36 @@ static int tick_substeps(sfx_world* w) {
     const uint32_t nph = (w->tly == w->gyl) ? 2u : 4u;
     uint32_t total_grid = 0;
     for (uint32_t ph = 0; ph < nph; ++ph) total_grid += w->tile_grid[ph];
-    const uint32_t epoch0 = w->epoch;   // sweep u publishes epoch0 + u + 1
-    w->epoch += 2u * nsub;
     if (w->vel_epoch > 0xFFFF0000u) w->vel_epoch = 0u;
     const uint32_t vstamp0 = w->vel_epoch + 1u;   // substep s stamps vstamp0 + s (never 0)
     w->vel_epoch += nsub;
     static const int race_selftest = [] { const char* e = getenv("SFX_RACE_SELFTEST"); return (e && e[0] == '1') ? kTileRaceSelfTest : 0; }();
-    int fl = ((w->counted && g_live_worlds[w->device].load() == 1 && !g_shared_device) ? kTileStaticFirst : 0) | race_selftest;
-    fl |= (w->tile_slot ^= 1) ? kTileSlot : 0;
-    // two sweeps can be under way at once (a batch of the next sweep starts when the batches around it are done)
-    const uint32_t grid = std::max(std::min(2u * total_grid, w->resident_tick), 1u);
-    { Prof p(w, SFX_K_TICK, w->ctr_valid ? (uint64_t)w->stale.n_kept * nsub : 0);
-      hipLaunchKernelGGL(k_tile_tick<256>, dim3(grid), dim3(256), 0, w->stream, nsub, nph, epoch0, vstamp0, fl, g, T, w->ctr, B, C, sp,
-                         w->cfg.speculative_margin); }
+    const int fl0 = ((w->counted && g_live_worlds[w->device].load() == 1 && !g_shared_device) ? kTileStaticFirst : 0) | race_selftest;
+    if (g_fuse_tick_mode == 2) {
+        // one launch per substep, the narrowphase (with the integration on load) in a launch of its own in front of it
+        const uint32_t grid = std::max(std::min(2u * total_grid, w->resident_tick_solve), 1u);
+        const uint32_t est = w->ctr_valid ? w->stale.n_pairs : w->max_pairs;
+        for (uint32_t s = 0; s < nsub; ++s) {
+            { Prof p(w, SFX_K_NARROW, w->ctr_valid ? w->stale.n_kept : 0);
+              hipLaunchKernelGGL(k_narrow_tick, dim3(std::min(std::max(cdiv(est, kBlock), 1u), 16384u)), dim3(kBlock), 0, w->stream, T, w->ctr, B, C,
+                                 w->cfg.speculative_margin, sp, s); }
+            const uint32_t epoch0 = w->epoch;
+            w->epoch += 2u;
+            const int fl = fl0 | ((w->tile_slot ^= 1) ? kTileSlot : 0);
+            Prof p(w, SFX_K_TICK, w->ctr_valid ? (uint64_t)w->stale.n_kept : 0);
+            hipLaunchKernelGGL((k_tile_tick<256, false>), dim3(grid), dim3(256), 0, w->stream, 1u, s, nph, epoch0, vstamp0 + s, fl, g, T, w->ctr, B, C, sp,
+                               w->cfg.speculative_margin);
+        }
+    } else {
+        const uint32_t epoch0 = w->epoch;   // sweep u publishes epoch0 + u + 1
+        w->epoch += 2u * nsub;
+        const int fl = fl0 | ((w->tile_slot ^= 1) ? kTileSlot : 0);
+        // two sweeps can be under way at once (a batch of the next sweep starts when the batches around it are done)
+        const uint32_t grid = std::max(std::min(2u * total_grid, w->resident_tick), 1u);
+        Prof p(w, SFX_K_TICK, w->ctr_valid ? (uint64_t)w->stale.n_kept * nsub : 0);
+        hipLaunchKernelGGL((k_tile_tick<256, true>), dim3(grid), dim3(256), 0, w->stream, nsub, 0u, nph, epoch0, vstamp0, fl, g, T, w->ctr, B, C, sp,
+                           w->cfg.speculative_margin);
+    }
     { Prof p(w, SFX_K_INTEGRATE, w->nb);
       hipLaunchKernelGGL(k_tick_free, dim3(cdiv(std::max(w->nb, 1u), kBlock)), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p,
                          w->vel.p, w->mass.p, sp, nsub, vstamp0 + nsub - 1u); }

@@ -2564,15 +2564,20 @@ __device__ __forceinline__ void store_rec_wt(__amdgpu_buffer_rsrc_t rs, uint32_t
 // store_record with write-through stores (rs: raw buffer over C.rec; the host checks that all planes lie within 4 GB)
 __device__ __forceinline__ void store_record_wt(const ContactArrays& C, __amdgpu_buffer_rsrc_t rs, uint32_t slot, const PairRec& r) {
     const uint32_t n = C.nslots;
-    store_rec_wt(rs, kPlA * n + slot, make_float4(r.nx, r.ny, __uint_as_float((uint32_t)r.count | (r.block ? 256u : 0u)), r.iK[0]));
-    if (r.count == 0) return;
-    store_rec_wt(rs, kPlB * n + slot, make_float4(r.ca[0], r.cb[0], r.d0[0], r.tgt[0]));
-    store_rec_wt(rs, kPlC * n + slot, make_float4(r.cta, r.ctb, r.mu_s, r.mu_d));
-    store_rec_wt(rs, kPlD * n + slot, make_float4(r.At[0], r.invS, r.Att, 0.0f));
-    if (r.count == 2) {
-        store_rec_wt(rs, kPlE * n + slot, make_float4(r.ca[1], r.cb[1], r.d0[1], r.tgt[1]));
-        store_rec_wt(rs, kPlF * n + slot, make_float4(r.i00, r.i01, r.i11, r.K01));
-        store_rec_wt(rs, kPlG * n + slot, make_float4(r.iK[1], r.At[1], r.invS0, r.invS1));
+    const int count = r.count;
+    const float4 pa = make_float4(r.nx, r.ny, __uint_as_float((uint32_t)count | (r.block ? 256u : 0u)), r.iK[0]);
+    const float4 pb = make_float4(r.ca[0], r.cb[0], r.d0[0], r.tgt[0]), pc = make_float4(r.cta, r.ctb, r.mu_s, r.mu_d);
+    const float4 pd = make_float4(r.At[0], r.invS, r.Att, 0.0f), pe = make_float4(r.ca[1], r.cb[1], r.d0[1], r.tgt[1]);
+    const float4 pf = make_float4(r.i00, r.i01, r.i11, r.K01), pg = make_float4(r.iK[1], r.At[1], r.invS0, r.invS1);
+    store_rec_wt(rs, kPlA * n + slot, pa);
+    if (count == 0) return;
+    store_rec_wt(rs, kPlB * n + slot, pb);
+    store_rec_wt(rs, kPlC * n + slot, pc);
+    store_rec_wt(rs, kPlD * n + slot, pd);
+    if (count == 2) {
+        store_rec_wt(rs, kPlE * n + slot, pe);
+        store_rec_wt(rs, kPlF * n + slot, pf);
+        store_rec_wt(rs, kPlG * n + slot, pg);
     }
 }
 
@@ -2591,8 +2596,8 @@ __device__ __forceinline__ void tick_integrate(float4& p, float4& v, const float
 
 __device__ __forceinline__ void narrow_batch_tick(const TileArrays& T, const BodyArrays& B, const ContactArrays& C,
                                                   __amdgpu_buffer_rsrc_t rec_rs, uint32_t start, uint32_t np, float sm,
-                                                  const StepParams& sp, uint32_t s, uint32_t nt) {
-    for (uint32_t k = threadIdx.x; k < np; k += nt) {
+                                                  const StepParams& sp, uint32_t s, uint32_t nt, uint32_t tid) {
+    for (uint32_t k = tid; k < np; k += nt) {
         const uint4 o = T.torder[start + k];
         const bool skip = o.z == kNoPair;
         const uint32_t a = skip ? 0u : o.x, b = skip ? 0u : o.y;   // (no branch between the order entry and the gathers)
@@ -2675,18 +2680,30 @@ __device__ __forceinline__ void fallback_vel_tick(const TileArrays& T, const Cou
     }
 }
 
+// a copy of uniform parameters that the compiler cannot see through (scalar registers): what a stage derives from them --
+// broadcast copies in vector registers, products -- is then derived inside that stage instead of once per kernel, where it
+// would be live across every other stage
+__device__ __forceinline__ float opaque_s(float x) { asm volatile("" : "+s"(x)); return x; }
+__device__ __forceinline__ StepParams opaque_params(const StepParams& sp) {
+    StepParams o;
+    o.h = opaque_s(sp.h); o.inv_h = opaque_s(sp.inv_h); o.inv_h2 = opaque_s(sp.inv_h2); o.gx = opaque_s(sp.gx); o.gy = opaque_s(sp.gy);
+    o.vthr = opaque_s(sp.vthr); o.max_corr = opaque_s(sp.max_corr); o.damp_lin = opaque_s(sp.damp_lin); o.damp_ang = opaque_s(sp.damp_ang);
+    o.flags = sp.flags;
+    return o;
+}
+
 // first wave: the batches of the 3 x 3 tiles around each of this batch's tiles have published at least tgt_lo (classes
 // below p_split, if `lo`) / tgt_hi (the other classes, if `hi`), and the fallback list of the sweep before is done (if
 // `fb`); then one agent-scope acquire.  Always ends in a workgroup barrier.
 template <int NT>
 __device__ __forceinline__ void tick_wait(const TileArrays& T, const GridParams& g, Counters* __restrict__ ctr,
                                           const uint32_t* __restrict__ tiles, uint32_t count, uint32_t nph, uint32_t p_split,
-                                          bool lo, uint32_t tgt_lo, bool hi, uint32_t tgt_hi, bool fb, uint32_t tgt_fb) {
+                                          bool lo, uint32_t tgt_lo, bool hi, uint32_t tgt_hi, bool fb, uint32_t tgt_fb, uint32_t tid) {
     if ((lo && p_split > 0u) || hi || fb) {   // (uniform)
-        if (threadIdx.x < 64u) {
+        if (tid < 64u) {
             const uint32_t lx = g.gxl - g.tlx;
             const bool one_row = g.tly == g.gyl;
-            for (uint32_t j = threadIdx.x; j < count * 9u; j += 64u) {
+            for (uint32_t j = tid; j < count * 9u; j += 64u) {
                 const uint32_t t = tiles[j / 9u], dir = j % 9u;
                 const int dx = (int)(dir % 3u) - 1, dy = (int)(dir / 3u) - 1;
                 if (one_row && dy != 0) continue;
@@ -2706,7 +2723,7 @@ __device__ __forceinline__ void tick_wait(const TileArrays& T, const GridParams&
                     }
                 }
             }
-            if (fb && threadIdx.x == 0u) {
+            if (fb && tid == 0u) {
                 uint32_t spins = 0;
                 while ((int32_t)(__hip_atomic_load(&ctr->fb_done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - tgt_fb) < 0) {
                     __builtin_amdgcn_s_sleep(2);
@@ -2722,16 +2739,17 @@ __device__ __forceinline__ void tick_wait(const TileArrays& T, const GridParams&
 
 // the fallback list of one sweep, by the workgroup that finished the sweep's last batch (all threads).  (Measured as a
 // function that is not inlined: the call costs the sweeps 105 spilled VGPRs instead of 42.)
+template <bool NARROW>
 __device__ __forceinline__ void tick_fallback(bool vel, const TileArrays& T, Counters* __restrict__ ctr, const BodyArrays& B,
                                                         const ContactArrays& C, float sm, const StepParams& sp, uint32_t s,
-                                                        uint32_t vstamp, uint32_t e_cur) {
+                                                        uint32_t vstamp, uint32_t e_cur, bool last) {
     if (threadIdx.x < 64u) {   // every batch of the sweep has published: their stores are in memory
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __syncthreads();
     if (!vel) {
-        narrow_fallback_tick(T, ctr, B, C, sm, sp, s);
+        if constexpr (NARROW) narrow_fallback_tick(T, ctr, B, C, sm, sp, s);
         fallback_pos(T, ctr, B, C, sp.max_corr);
     } else {
         fallback_vel_tick(T, ctr, B, C, sp, vstamp);
@@ -2741,6 +2759,7 @@ __device__ __forceinline__ void tick_fallback(bool vel, const TileArrays& T, Cou
     if (threadIdx.x == 0u) {   // plain stores above: one release for the workgroup, then the flag
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (last) ctr->ticket = 0u;   // (the next launch of this tick counts its own batches from zero)
         __hip_atomic_store(&ctr->fb_done, e_cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -2748,10 +2767,12 @@ __device__ __forceinline__ void tick_fallback(bool vel, const TileArrays& T, Cou
 #ifndef SFX_TICK_WAVES
 #define SFX_TICK_WAVES 3
 #endif
-template <int NT>
-__global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub, uint32_t nph, uint32_t epoch0, uint32_t vstamp0, int flags,
+// NARROW = false: the records come from a k_narrow_tick launch in front of this one (then one launch holds one substep, the
+// s0-th of its tick): no narrowphase in this kernel's register allocation.
+template <int NT, bool NARROW>
+__global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub, uint32_t s0, uint32_t nph, uint32_t epoch0, uint32_t vstamp0, int flags,
                                                      GridParams g, TileArrays T, Counters* __restrict__ ctr, BodyArrays B,
-                                                     ContactArrays C, StepParams sp, float sm) {
+                                                     ContactArrays C, StepParams sp_arg, float sm_arg) {
     __shared__ float4 s_a[kMaxBX];     // position sweep: displacements; velocity sweep: velocities
     __shared__ float4 s_b[kMaxBX];     // position sweep: the batch's multipliers (float2 per pair); velocity sweep: static-friction shifts
     __shared__ float2 s_mass[kMaxBX];
@@ -2760,7 +2781,6 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
     SFX_RACE_DECL
     float2* const s_lam = reinterpret_cast<float2*>(s_b);
     constexpr int kRounds = (int)((kMaxBX + NT - 1) / NT);
-    const uint32_t tid = threadIdx.x;
     const __amdgpu_buffer_rsrc_t dpos_rs = record_rsrc(B.dpos), pose_rs = record_rsrc(B.pose), vel_rs = record_rsrc(B.vel),
                                  rec_rs = record_rsrc(C.rec);
     const __amdgpu_buffer_rsrc_t lam_rs = __builtin_amdgcn_make_buffer_rsrc((void*)C.lam, 0, (int)0xFFFFFFF0u, 0x00020000);
@@ -2769,7 +2789,12 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
     const bool has_fb = ctr->n_fb != 0u;
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (uint32_t item = next_item(ctr, flags); item < nitems; item = s_next) {
-        const uint32_t u = item / S, ri = item - u * S, s = u >> 1;
+        // (the lane's index through a copy the compiler cannot see through, here and again behind the narrowphase and the
+        // waits: what is derived from it is then derived per item and per stage, not once per kernel and kept -- or spilled
+        // and reloaded inside the colour steps -- across the narrowphase, which wants every register)
+        uint32_t tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const uint32_t u = item / S, ri = item - u * S, s = s0 + (u >> 1);
         const bool vel = (u & 1u) != 0u;
         const PhaseItem pi = phase_item(ctr, 0u, nph, ri);
         const uint32_t ph = pi.ph, it = pi.it;
@@ -2777,7 +2802,6 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
         const uint32_t* tiles = T.active + d.first;
         const uint32_t ntl = d.count & ~kBatchNear;
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol, npb = min(d.np, kBatchP);
-        const uint32_t side = tid & 1u, half = tid >> 1;   // two lanes per pair: body a, body b
         const uint32_t e_prev = epoch0 + u, e_cur = e_prev + 1u;   // flags of the sweep before / of this sweep
         __syncthreads();  // the previous item's write-back has read the LDS arrays
         // what is the same all frame long -- the step list, the body ids, the masses -- before any waiting
@@ -2792,17 +2816,27 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
         SFX_RACE_CLEAR(nb)
         uint32_t colour = 0u;   // (counts the barriers of the loop: the race detector's stamp)
         (void)colour;
-        RawSide q;
         if (!vel) {
             // ---- position sweep of substep s: narrowphase of the batch's pairs at the integrated poses, then the colours
-            tick_wait<NT>(T, g, ctr, tiles, ntl, nph, 0u, false, 0u, u > 0u, e_prev, has_fb && u > 0u, e_prev);
-            narrow_batch_tick(T, B, C, rec_rs, start, npb, sm, sp, s, NT);
-            __syncthreads();   // the records of the other waves' pairs (same CU)
+            tick_wait<NT>(T, g, ctr, tiles, ntl, nph, 0u, false, 0u, u > 0u, e_prev, has_fb && u > 0u, e_prev, tid);
+            const StepParams sp = opaque_params(sp_arg);
+            const float sm = opaque_s(sm_arg);
+            if constexpr (NARROW) {
+                narrow_batch_tick(T, B, C, rec_rs, start, npb, sm, sp, s, NT, tid);
+                __syncthreads();   // the records of the other waves' pairs (same CU)
+            }
+            // Everything the colour loop derives from the lane's index is derived HERE, from a copy the compiler cannot see
+            // through: computed once per kernel they would be live across the narrowphase, which wants every register --
+            // they were spilled and reloaded (with a wait for ALL loads in flight, the record prefetch included) in every step
+            uint32_t tid = threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const uint32_t side = tid & 1u, half = tid >> 1;   // two lanes per pair: body a, body b
+            RawSide q;
             const uint32_t ns = s_nsteps;
             uint32_t st_cur = __builtin_amdgcn_readfirstlane(s_step[0]), st_nxt = __builtin_amdgcn_readfirstlane(s_step[1]);
             fetch_side<false>(T, C, start + (st_cur & 0xFFFFu) + half, side, 0u < ns && (st_cur & 0xFFFFu) + half < (st_cur >> 16), q);
             if (ph != 0u) {
-                tick_wait<NT>(T, g, ctr, tiles, ntl, nph, ph, true, e_cur, false, 0u, false, 0u);
+                tick_wait<NT>(T, g, ctr, tiles, ntl, nph, ph, true, e_cur, false, 0u, false, 0u, tid);
                 for (uint32_t l = tid; l < nb; l += NT) s_a[l] = B.dpos[s_gid[l]];
                 __syncthreads();
             }
@@ -2841,17 +2875,21 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
             }
         } else {
             // ---- velocity sweep of substep s: the first batch to load a body integrates it, applies its displacement and derives it
-            const uint32_t vstamp = vstamp0 + s;
-            tick_wait<NT>(T, g, ctr, tiles, ntl, nph, ph, true, e_cur, true, e_prev, has_fb, e_prev);
+            const uint32_t vstamp = vstamp0 + (u >> 1);
+            tick_wait<NT>(T, g, ctr, tiles, ntl, nph, ph, true, e_cur, true, e_prev, has_fb, e_prev, tid);
+            const StepParams sp = opaque_params(sp_arg);
+            uint32_t tid = threadIdx.x;   // (as in the position sweep)
+            asm volatile("" : "+v"(tid));
+            const uint32_t side = tid & 1u, half = tid >> 1;
+            RawSide q;
             const uint32_t ns = s_nsteps;
             uint32_t st_cur = __builtin_amdgcn_readfirstlane(s_step[0]), st_nxt = __builtin_amdgcn_readfirstlane(s_step[1]);
             fetch_side<true>(T, C, start + (st_cur & 0xFFFFu) + half, side, 0u < ns && (st_cur & 0xFFFFu) + half < (st_cur >> 16), q);
-            float4 rp[kRounds];
-            uint32_t derived = 0u;
+            // (no pose stays in a register across the colour loop: a body stepped here has its pose stored at once -- nobody
+            // reads it before this batch has published -- and a static-friction shift, which is rare, reads it back)
 #pragma unroll
             for (int j = 0; j < kRounds; ++j) {
                 const uint32_t l = tid + (uint32_t)j * NT;
-                rp[j] = make_float4(0.0f, 0.0f, 1.0f, 0.0f);
                 if (l < nb) {
                     const uint32_t gid = s_gid[l];
                     float4 ps = B.pose[gid];
@@ -2864,9 +2902,9 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
                         apply_delta(ps, dd);
                         derive_body(ps, q0, vs, sp);
                         vs.w = __uint_as_float(vstamp);
-                        derived |= 1u << j;
+                        store_record16<true>(B.pose, pose_rs, gid, ps);
+                        store_record16<true>(B.dpos, dpos_rs, gid, zero4);   // the next substep's sweep starts from nothing
                     }
-                    rp[j] = ps;
                     s_a[l] = vs;
                 }
             }
@@ -2899,11 +2937,15 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
                     const float2 w = s_mass[l];
                     if (w.x > 0.0f || w.y > 0.0f) {
                         const float4 Sh = s_b[l];
-                        float4 ps = rp[j];
-                        if (Sh.x != 0.0f || Sh.y != 0.0f || Sh.z != 0.0f) apply_delta(ps, Sh);
-                        store_record16<true>(B.vel, vel_rs, s_gid[l], s_a[l]);
-                        store_record16<true>(B.pose, pose_rs, s_gid[l], ps);
-                        if (derived & (1u << j)) store_record16<true>(B.dpos, dpos_rs, s_gid[l], zero4);   // the next substep's sweep starts from nothing
+                        const uint32_t gid = s_gid[l];
+                        store_record16<true>(B.vel, vel_rs, gid, s_a[l]);
+                        if (Sh.x != 0.0f || Sh.y != 0.0f || Sh.z != 0.0f) {
+                            // (this lane's own store from before the colour loop, or an earlier class's: read past the L1)
+                            const v4u32 pu = __builtin_amdgcn_raw_buffer_load_b128(pose_rs, (int)(gid * 16u), 0, 16 /* sc1 */);
+                            float4 ps = make_float4(__uint_as_float(pu.x), __uint_as_float(pu.y), __uint_as_float(pu.z), __uint_as_float(pu.w));
+                            apply_delta(ps, Sh);
+                            store_record16<true>(B.pose, pose_rs, gid, ps);
+                        }
                     }
                 }
             }
@@ -2912,7 +2954,7 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
         if (has_fb) {   // the workgroup that finishes the last batch of a sweep solves the fallback list; the next sweep waits for it
             if (tid == 0u) s_fb = (atomicAdd(&ctr->ticket, 1u) + 1u == (u + 1u) * S) ? 1u : 0u;
             __syncthreads();
-            if (s_fb) tick_fallback(vel, T, ctr, B, C, sm, sp, s, vstamp0 + s, e_cur);
+            if (s_fb) tick_fallback<NARROW>(vel, T, ctr, B, C, sm_arg, sp_arg, s, vstamp0 + (u >> 1), e_cur, u + 1u == 2u * nsub);
         }
     }
 }
@@ -2942,6 +2984,33 @@ __global__ __launch_bounds__(kBlock) void k_tick_free(uint32_t n, float4* __rest
     }
     pose[i] = p;
     prev[i] = q;
+}
+
+// k_narrow with the integration on load (the one-launch tick with its narrowphase in a launch of its own, substep s of the tick)
+__global__ __launch_bounds__(kBlock, SFX_NARROW_WAVES) void k_narrow_tick(TileArrays T, const Counters* __restrict__ ctr, BodyArrays B,
+                                                         ContactArrays C, float sm, StepParams sp, uint32_t s) {
+    const uint32_t ntp = min(ctr->tp_cursor, T.max_pairs);
+    const uint32_t nfb = min(ctr->n_fb, T.fb_cap) ? ctr->fb_start[SFX_MAX_COLORS] : 0u;
+    for (uint32_t j = blockIdx.x * kBlock + threadIdx.x; j < ntp + nfb; j += gridDim.x * kBlock) {
+        uint32_t a, b, slot;
+        if (j < ntp) {
+            const uint4 o = T.torder[j];
+            slot = o.z;
+            if (slot == kNoPair) continue;
+            a = o.x; b = o.y;
+        } else {
+            const uint2 ab = T.fsorted[j - ntp];
+            a = ab.x; b = ab.y; slot = T.max_pairs + (j - ntp);
+        }
+        PairRec r;
+        float4 pa = B.pose[a], pb = B.pose[b], va = B.vel[a], vb = B.vel[b];
+        const float4 sa = B.shape[a], sb = B.shape[b];
+        const float2 wa = B.mass[a], wb = B.mass[b];
+        tick_integrate(pa, va, wa, sp, s);
+        tick_integrate(pb, vb, wb, sp, s);
+        prepare_pair(pa, sa, va, wa, pb, sb, vb, wb, shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, sp.vthr, r);
+        store_record(C, slot, r);
+    }
 }
 
 // ---------------------------------------------------------------- small worlds: whole substeps in ONE workgroup
