@@ -91,6 +91,7 @@ struct sfx_world {
     uint32_t vel_epoch = 0;        // derive-on-load: stamp of the current substep's velocity solve (sfx_step only)
     uint32_t vel_prev_epoch = 0;   // stamp of the previous substep of this tick when it left bodies underived, else 0
     bool dpos_clean = false;       // every displacement record is zero (the one-launch tick leaves them so and relies on it)
+    uint32_t resident_pos_i = 0, resident_vel_i = 0;   // ... of k_tile_pos / k_tile_vel<256, integration on load>
     uint32_t resident_tick = 0, resident_tick_solve = 0;    // workgroups of k_tile_tick<256, with / without narrowphase> the device holds at once
     bool in_step = false;          // sfx_step is driving the substeps (it sees the whole tick)
     DevBuf<uint4> filt, sorted_filt;   // filter words by entry id / in slot order (written by k_finalize_slots)
@@ -760,6 +761,7 @@ int sfx_create(const sfx_config* cfg, sfx_world** out) {
         occ(k_tile_pos<256>, 256, w->resident_pos_v[1]); occ(k_tile_vel<256>, 256, w->resident_vel_v[1]);
         occ(k_tile_pos<128>, 128, w->resident_pos_v[2]); occ(k_tile_vel<128>, 128, w->resident_vel_v[2]);
         occ(k_tile_tick<256, true>, 256, w->resident_tick); occ(k_tile_tick<256, false>, 256, w->resident_tick_solve);
+        occ((k_tile_pos<256, true>), 256, w->resident_pos_i); occ((k_tile_vel<256, true>), 256, w->resident_vel_i);
         auto variant = [](int v) { return v == 512 ? 0 : v == 256 ? 1 : v == 128 ? 2 : -1; };
         if (const char* nt = getenv("SFX_TILE_NT")) {
             const int v = atoi(nt);
@@ -1291,9 +1293,9 @@ int sfx_tick_substep(sfx_world* w) {
     auto launch_pos = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb) {
         fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;
         const uint32_t nt = tvp == 0 ? 512u : tvp == 1 ? 256u : 128u;
-        if (tvp == 2) hipLaunchKernelGGL(k_tile_pos<128>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin, sp.vthr);
-        else if (tvp == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin, sp.vthr);
-        else hipLaunchKernelGGL(k_tile_pos<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin, sp.vthr);
+        if (tvp == 2) hipLaunchKernelGGL(k_tile_pos<128>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin, sp.vthr, sp, 0u);
+        else if (tvp == 0) hipLaunchKernelGGL(k_tile_pos<512>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin, sp.vthr, sp, 0u);
+        else hipLaunchKernelGGL(k_tile_pos<256>, dim3(grid), dim3(nt), 0, w->stream, ph0, np, ep, fb, g, T, w->ctr, B, C, sp.max_corr, w->cfg.speculative_margin, sp.vthr, sp, 0u);
     };
     auto launch_vel = [&](uint32_t grid, uint32_t ph0, uint32_t np, uint32_t ep, int fb, hipStream_t st = nullptr) {
         if (!(fb & kTileOnlyNear)) fb |= (w->tile_slot ^= 1) ? kTileSlot : 0;   // (the near launch takes no tickets)
@@ -1394,13 +1396,17 @@ static int substeps_done(sfx_world* w, uint32_t count, bool mirror) {
     return SFX_OK;
 }
 
-// The substeps of a tick as ONE launch (sfx_kernels.h k_tile_tick; DESIGN.md "The substeps of a tick as one launch"): the
-// position and velocity sweeps of all substeps are the items of one ticketed launch, integration and the narrowphase happen
-// where bodies and pairs are loaded, and a batch waits for the batches around it instead of the device waiting for the end
-// of a launch.  Taken by sfx_step (which sees the whole tick) for worlds whose substeps are contact sweeps and nothing else:
-// no joints, no further colliders (their mirrors are refreshed between the stages), no halos (exchanged between
-// substeps), no per-stage profiling.  Same bits as the launch-per-stage path.  SFX_FUSE_TICK=0 keeps that path.
-static const int g_fuse_tick_mode = [] { const char* e = getenv("SFX_FUSE_TICK"); return e ? atoi(e) : 1; }();   // 0: off, 1: one launch per tick, 2: per substep a narrowphase launch + one launch of both sweeps
+// Integration on load (DESIGN.md "Integration on load"; sfx_kernels.h k_tile_pos / k_tile_vel<256, true>, k_tick_free): sfx_step,
+// which sees the whole tick, runs the substeps of worlds whose substeps are contact sweeps and nothing else -- no joints, no
+// further colliders (their mirrors are refreshed between the stages), no halos (exchanged between substeps) -- WITHOUT
+// k_integrate: a body's pose and velocity at the start of a substep are a function of its record at the end of the substep
+// before, computed by the narrowphase where it loads a body and by the velocity sweep where it derives one; the bodies no
+// batch holds are stepped through all substeps by one k_tick_free at the end of the tick.  Same bits as the path with
+// k_integrate (tests/test_gpu_fused_tick.py).  SFX_FUSE_TICK=0 keeps that path; 1 and 2 are the two forms of "the substeps of
+// a tick as one launch" (k_tile_tick: sweeps as ticketed items that wait for the batches around them instead of launch
+// boundaries), bit-identical too, measured slower and kept as knobs (DESIGN.md "The substeps of a tick as one launch").
+static const int g_fuse_tick_mode = [] { const char* e = getenv("SFX_FUSE_TICK"); return e ? atoi(e) : 3; }();   // 0: off; 3 (default): the staged launches with the integration on load;
+                                                                                    // measured and not kept as defaults: 1: one launch per tick, 2: per substep a narrowphase launch + one launch of both sweeps
 static const bool g_fuse_tick_off = g_fuse_tick_mode == 0;
 
 static bool tick_fused(const sfx_world* w) {
@@ -1408,7 +1414,7 @@ static bool tick_fused(const sfx_world* w) {
         const char* a = getenv("SFX_FUSE_DERIVE"); const char* b = getenv("SFX_FUSE_NARROW");
         return (a && a[0] == '0') || (b && atoi(b) != 1);
     }();
-    if (g_fuse_tick_off || other_knobs || !w->fuse_phases || w->profiling || w->resident_tick < 32u) return false;
+    if (g_fuse_tick_off || other_knobs || !w->fuse_phases || w->resident_tick < 32u || w->resident_pos_i < 32u || w->resident_vel_i < 32u) return false;
     if (w->joint_color_start.size() > 1 || w->joint_damped || w->n != w->nb || w->n_halo_send || w->n_halo_recv) return false;
     if (w->tile_variant_fixed >= 0 && w->tile_variant_fixed != 1) return false;
     if ((w->tile_variant_pos >= 0 && w->tile_variant_pos != 1) || (w->tile_variant_vel >= 0 && w->tile_variant_vel != 1)) return false;
@@ -1436,7 +1442,20 @@ static int tick_substeps(sfx_world* w) {
     w->vel_epoch += nsub;
     static const int race_selftest = [] { const char* e = getenv("SFX_RACE_SELFTEST"); return (e && e[0] == '1') ? kTileRaceSelfTest : 0; }();
     const int fl0 = ((w->counted && g_live_worlds[w->device].load() == 1 && !g_shared_device) ? kTileStaticFirst : 0) | race_selftest;
-    if (g_fuse_tick_mode == 2) {
+    if (g_fuse_tick_mode == 3) {
+        // Integration on load, a launch per sweep (DESIGN.md "Integration on load"): the staged launches without k_integrate --
+        // the narrowphase at the head of the position sweep integrates the bodies it loads, the velocity sweep the ones it derives
+        const uint32_t grid_p = std::max(std::min(total_grid, w->resident_pos_i), 1u), grid_v = std::max(std::min(total_grid, w->resident_vel_i), 1u);
+        for (uint32_t s = 0; s < nsub; ++s) {
+            { Prof p(w, SFX_K_SOLVE_POS, w->ctr_valid ? w->stale.n_kept : 0);
+              const int fl = fl0 | kTileFallback | kTileNarrow | kTileNarrowAll | ((w->tile_slot ^= 1) ? kTileSlot : 0);
+              hipLaunchKernelGGL((k_tile_pos<256, true>), dim3(grid_p), dim3(256), 0, w->stream, 0u, nph, ++w->epoch, fl, g, T, w->ctr, B, C, sp.max_corr,
+                                 w->cfg.speculative_margin, sp.vthr, sp, s); }
+            { Prof p(w, SFX_K_SOLVE_VEL, w->ctr_valid ? w->stale.n_kept : 0);
+              const int fl = fl0 | kTileFallback | ((w->tile_slot ^= 1) ? kTileSlot : 0);
+              hipLaunchKernelGGL((k_tile_vel<256, true>), dim3(grid_v), dim3(256), 0, w->stream, 0u, nph, ++w->epoch, fl, g, T, w->ctr, B, C, sp, vstamp0 + s); }
+        }
+    } else if (g_fuse_tick_mode == 2) {
         // one launch per substep, the narrowphase (with the integration on load) in a launch of its own in front of it
         const uint32_t grid = std::max(std::min(2u * total_grid, w->resident_tick_solve), 1u);
         const uint32_t est = w->ctr_valid ? w->stale.n_pairs : w->max_pairs;

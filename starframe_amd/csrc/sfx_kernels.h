@@ -2218,6 +2218,16 @@ __device__ __forceinline__ void build_steps(const uint32_t* __restrict__ runs, u
     if (c == 63u) *s_nsteps = min(incl, kMaxSteps);
 }
 
+// (the integration-on-load forms of the narrowphase and of the fallback list: defined with the one-launch tick below)
+template <bool WT>
+__device__ __forceinline__ void narrow_batch_tick(const TileArrays& T, const BodyArrays& B, const ContactArrays& C,
+                                                  uint32_t start, uint32_t np, float sm,
+                                                  const StepParams& sp, uint32_t s, uint32_t nt, uint32_t tid);
+__device__ __forceinline__ void narrow_fallback_tick(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
+                                                     const ContactArrays& C, float sm, const StepParams& sp, uint32_t s);
+__device__ __forceinline__ void fallback_vel_tick(const TileArrays& T, const Counters* __restrict__ ctr, const BodyArrays& B,
+                                                  const ContactArrays& C, const StepParams& sp, uint32_t vstamp);
+
 // Position solve (DESIGN.md "Contract / frozen rows").  A workgroup takes one batch of tiles at a time: the displacements
 // (dx, dy, dtheta) of the batch's bodies -- zero for the first phase of a substep, what earlier phases accumulated
 // otherwise -- and their masses go to LDS; the colours are solved one after the other with an LDS-only barrier in
@@ -2225,10 +2235,12 @@ __device__ __forceinline__ void build_steps(const uint32_t* __restrict__ runs, u
 // lanes per pair; every lane fetches the record of its next colour's pair while it solves the current one.  Finally the
 // dynamic bodies' displacements are written back.  Poses are not touched: the displacement is applied once per body
 // where its velocity is derived.  Batches of one phase have disjoint bodies.
-template <int NT>
+// INTEG (DESIGN.md "Integration on load"): no k_integrate ran -- the narrowphase integrates the bodies it loads (substep `sub`
+// of the tick, parameters `spi`)
+template <int NT, bool INTEG = false>
 __global__ __launch_bounds__(NT, (NT == 256 && SFX_TILE_MIN_WAVES < 3) ? 3 : SFX_TILE_MIN_WAVES) void k_tile_pos(uint32_t ph0, uint32_t nph, uint32_t epoch, int flags, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
-                                                  float max_corr, float sm, float vthr) {
+                                                  float max_corr, float sm, float vthr, StepParams spi, uint32_t sub) {
     __shared__ float4 s_d[kMaxBX];
     __shared__ float2 s_mass[kMaxBX];
     __shared__ uint32_t s_gid[kMaxBX];
@@ -2249,8 +2261,15 @@ __global__ __launch_bounds__(NT, (NT == 256 && SFX_TILE_MIN_WAVES < 3) ? 3 : SFX
         const uint32_t nb = min(d.nb, kMaxBX), start = d.bstart, ncol = d.ncol, npb = min(d.np, kBatchP);
         // everything that no earlier phase of this launch writes is fetched before waiting for them: the step list, the
         // records of the first kDepth steps, the body ids, the masses
-        const uint32_t side = tid & 1u, half = tid >> 1;   // two lanes per pair: body a, body b
-        if ((flags & kTileNarrow) && (ph != 0u || (flags & kTileNarrowAll))) narrow_batch(T, B, C, start, npb, sm, vthr, NT);
+        if ((flags & kTileNarrow) && (ph != 0u || (flags & kTileNarrowAll))) {
+            if constexpr (INTEG) narrow_batch_tick<false>(T, B, C, start, npb, sm, spi, sub, NT, tid);
+            else narrow_batch(T, B, C, start, npb, sm, vthr, NT);
+        }
+        // (INTEG: the lane's index through a copy the compiler cannot see through -- what the colour loop derives from it is
+        // then derived here, behind the narrowphase, which wants every register, instead of being spilled across it)
+        uint32_t tl = tid;
+        if constexpr (INTEG) asm volatile("" : "+v"(tl));
+        const uint32_t side = tl & 1u, half = tl >> 1;   // two lanes per pair: body a, body b
         __syncthreads();  // the previous batch's write-back has read the LDS arrays
         build_steps<NT>(T.bruns + 64u * d.roff, ncol, s_step, &s_nsteps);
         for (uint32_t l = tid; l < nb; l += NT) {  // block bodies, then the large colliders outside the block its pairs touch
@@ -2344,7 +2363,10 @@ __global__ __launch_bounds__(NT, (NT == 256 && SFX_TILE_MIN_WAVES < 3) ? 3 : SFX
     }
     // the fallback list is usually empty: then no workgroup pays for the exit ticket (fence + atomic round trip)
     if ((flags & kTileFallback) && ctr->n_fb != 0u && last_workgroup(ctr)) {
-        if (flags & kTileNarrowAll) narrow_fallback(T, ctr, B, C, sm, vthr);
+        if (flags & kTileNarrowAll) {
+            if constexpr (INTEG) narrow_fallback_tick(T, ctr, B, C, sm, spi, sub);
+            else narrow_fallback(T, ctr, B, C, sm, vthr);
+        }
         fallback_pos(T, ctr, B, C, max_corr);
     }
 }
@@ -2354,7 +2376,9 @@ __global__ __launch_bounds__(NT, (NT == 256 && SFX_TILE_MIN_WAVES < 3) ? 3 : SFX
 // "Velocities derived where they are first read").  The poses stay in the registers of the lanes that loaded them: the
 // colour steps work on velocities and frozen rows only; static friction accumulates a pose shift per body in LDS, which
 // is applied when the batch writes back.
-template <int NT>
+// INTEG: no k_integrate ran -- the first batch to load a body integrates it, applies its displacement, derives it, and
+// leaves its displacement record zero for the next substep (no start-of-substep poses in memory)
+template <int NT, bool INTEG = false>
 __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph0, uint32_t nph, uint32_t epoch, int flags, GridParams g,
                                                   TileArrays T, Counters* __restrict__ ctr, BodyArrays B, ContactArrays C,
                                                   StepParams sp, uint32_t vstamp) {
@@ -2427,6 +2451,8 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         if (nph > 1u && ph > ph0) wait_for_earlier_phases<NT>(T, g, ctr, tiles, d.count & ~kBatchNear, ph, ph0, epoch);
         SFX_TT(tvw);
         float4 rp[kRounds];
+        uint32_t derived = 0u;
+        (void)derived;
 #pragma unroll
         for (int j = 0; j < kRounds; ++j) {
             const uint32_t l = tid + (uint32_t)j * NT;
@@ -2435,7 +2461,18 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
                 const uint32_t gid = s_gid[l];
                 float4 ps = B.pose[gid];
                 float4 vs = B.vel[gid];
-                if (vstamp) {   // derive-on-load: the first batch of the sweep to read a body applies its displacement, derives its velocity and stamps it
+                if constexpr (INTEG) {
+                    const float4 dd = B.dpos[gid];   // (fetched beside the others: no load waits for the stamp)
+                    const float2 w = s_mass[l];
+                    if ((w.x > 0.0f || w.y > 0.0f) && __float_as_uint(vs.w) != vstamp) {
+                        float4 q0;
+                        integrate_body(ps, q0, vs, w, sp);
+                        apply_delta(ps, dd);
+                        derive_body(ps, q0, vs, sp);
+                        vs.w = __uint_as_float(vstamp);
+                        derived |= 1u << j;
+                    }
+                } else if (vstamp) {   // derive-on-load: the first batch of the sweep to read a body applies its displacement, derives its velocity and stamps it
                     const float4 q = B.prev[gid], dd = B.dpos[gid];   // (fetched beside the others: no load waits for the stamp)
                     const float2 w = s_mass[l];
                     if ((w.x > 0.0f || w.y > 0.0f) && __float_as_uint(vs.w) != vstamp) {
@@ -2508,6 +2545,9 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
                         B.vel[s_gid[l]] = s_vel[l];
                         if (shifted || vstamp) B.pose[s_gid[l]] = ps;
                     }
+                    if constexpr (INTEG) {   // the next substep's sweep starts from nothing (nobody reads the record before the next launch)
+                        if (derived & (1u << j)) B.dpos[s_gid[l]] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    }
                 }
             }
         }
@@ -2523,7 +2563,10 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
         }
 #endif
     }
-    if ((flags & kTileFallback) && ctr->n_fb != 0u && last_workgroup(ctr)) fallback_vel(T, ctr, B, C, sp, vstamp);
+    if ((flags & kTileFallback) && ctr->n_fb != 0u && last_workgroup(ctr)) {
+        if constexpr (INTEG) fallback_vel_tick(T, ctr, B, C, sp, vstamp);
+        else fallback_vel(T, ctr, B, C, sp, vstamp);
+    }
 #ifdef SFX_TILE_TIMING
     if (threadIdx.x == 0 && T.dbg) atomicMax(&T.dbg[49 + 2 * (epoch & 15u)], wall_clock64());    // latest kernel exit
 #endif
@@ -2594,9 +2637,13 @@ __device__ __forceinline__ void tick_integrate(float4& p, float4& v, const float
     }
 }
 
+// WT: the records are stored write-through (a later item of the same launch reads them)
+template <bool WT>
 __device__ __forceinline__ void narrow_batch_tick(const TileArrays& T, const BodyArrays& B, const ContactArrays& C,
-                                                  __amdgpu_buffer_rsrc_t rec_rs, uint32_t start, uint32_t np, float sm,
+                                                  uint32_t start, uint32_t np, float sm,
                                                   const StepParams& sp, uint32_t s, uint32_t nt, uint32_t tid) {
+    const __amdgpu_buffer_rsrc_t rec_rs = record_rsrc(C.rec);
+    (void)rec_rs;
     for (uint32_t k = tid; k < np; k += nt) {
         const uint4 o = T.torder[start + k];
         const bool skip = o.z == kNoPair;
@@ -2609,7 +2656,8 @@ __device__ __forceinline__ void narrow_batch_tick(const TileArrays& T, const Bod
         tick_integrate(pb, vb, wb, sp, s);
         PairRec r;
         prepare_pair(pa, sa, va, wa, pb, sb, vb, wb, shape_pose(pa, sa, B.lpose, a), shape_pose(pb, sb, B.lpose, b), B.poly, B.mats, sm, sp.vthr, r);
-        store_record_wt(C, rec_rs, o.z, r);
+        if constexpr (WT) store_record_wt(C, rec_rs, o.z, r);
+        else store_record(C, o.z, r);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -2781,8 +2829,7 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
     SFX_RACE_DECL
     float2* const s_lam = reinterpret_cast<float2*>(s_b);
     constexpr int kRounds = (int)((kMaxBX + NT - 1) / NT);
-    const __amdgpu_buffer_rsrc_t dpos_rs = record_rsrc(B.dpos), pose_rs = record_rsrc(B.pose), vel_rs = record_rsrc(B.vel),
-                                 rec_rs = record_rsrc(C.rec);
+    const __amdgpu_buffer_rsrc_t dpos_rs = record_rsrc(B.dpos), pose_rs = record_rsrc(B.pose), vel_rs = record_rsrc(B.vel);
     const __amdgpu_buffer_rsrc_t lam_rs = __builtin_amdgcn_make_buffer_rsrc((void*)C.lam, 0, (int)0xFFFFFFF0u, 0x00020000);
     const uint32_t S = phase_total(ctr, 0u, nph);
     const uint32_t nitems = S * 2u * nsub;
@@ -2822,7 +2869,7 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
             const StepParams sp = opaque_params(sp_arg);
             const float sm = opaque_s(sm_arg);
             if constexpr (NARROW) {
-                narrow_batch_tick(T, B, C, rec_rs, start, npb, sm, sp, s, NT, tid);
+                narrow_batch_tick<true>(T, B, C, start, npb, sm, sp, s, NT, tid);
                 __syncthreads();   // the records of the other waves' pairs (same CU)
             }
             // Everything the colour loop derives from the lane's index is derived HERE, from a copy the compiler cannot see

@@ -1,9 +1,11 @@
-"""The substeps of a tick as one launch (sfx_kernels.h k_tile_tick, DESIGN.md "The substeps of a tick as one launch"): sfx_step
-runs the position and velocity sweeps of all substeps as the items of ONE launch, integrates bodies where they are loaded and
-lets a batch wait for the batches around it instead of the device for the end of a launch; SFX_FUSE_TICK=0 keeps a launch per
-stage.  Same functions in the same order per body and pair: the two must end in the same bits -- on soups (with moving
-non-dynamic bodies), square tiles and strips, with a fallback list, and when a world changes between the two paths from tick
-to tick.  (The parity tests against the oracle run on the default.)"""
+"""Integration on load and the substeps of a tick as one launch (DESIGN.md sections of those names; sfx_host.hip tick_fused).
+sfx_step runs the substeps of a world without joints, further colliders or halos WITHOUT k_integrate (SFX_FUSE_TICK=3, the
+default): the narrowphase integrates the bodies it loads, the velocity sweep the ones it derives, one k_tick_free steps the
+bodies no batch holds.  SFX_FUSE_TICK=1 runs the sweeps of all substeps as the items of ONE launch (a batch waits for the
+batches around it, not the device for the end of a launch), 2 the same per substep behind a narrowphase launch; 0 keeps
+k_integrate and a launch per stage.  Same functions in the same order per body and pair: all four must end in the same
+bits -- on soups (with moving non-dynamic bodies), square tiles and strips, with a fallback list, and when a world changes
+between the paths from tick to tick.  (The parity tests against the oracle run on the default.)"""
 import json
 import os
 import subprocess
@@ -22,10 +24,13 @@ def worker(mode):
 
 
 @pytest.mark.gpu
-def test_one_launch_tick_equals_a_launch_per_stage():
-    staged, fused = worker(0), worker(1)
-    assert staged["tick_launches"] == 0 and fused["tick_launches"] > 0
-    assert fused["solver_pairs"] > 50_000, fused
-    for a, b in zip(staged["per_world"], fused["per_world"]):
-        assert a == b, (a, b)
-    assert fused["fallback"] > 0, fused   # the fallback list inside the launch was exercised
+def test_integration_on_load_and_one_launch_ticks_equal_a_launch_per_stage():
+    staged, one, per_substep, on_load = worker(0), worker(1), worker(2), worker(3)
+    assert staged["tick_launches"] == 0 and on_load["tick_launches"] == 0
+    assert one["tick_launches"] == one["ticks"] and per_substep["tick_launches"] == 4 * per_substep["ticks"]
+    assert staged["integrate_launches"] == 4 * staged["ticks"] and on_load["integrate_launches"] == on_load["ticks"]   # k_integrate per substep / one k_tick_free
+    assert on_load["solver_pairs"] > 50_000, on_load
+    for w in (one, per_substep, on_load):
+        for a, b in zip(staged["per_world"], w["per_world"]):
+            assert a == b, (a, b)
+    assert on_load["fallback"] > 0, on_load   # the fallback list's integration on load was exercised

@@ -19,15 +19,18 @@ def main():
     from starframe_amd.world import World
 
     h = hashlib.sha256()
-    out = {"tick_launches": 0, "fallback": 0, "solver_pairs": 0, "per_world": []}
+    out = {"tick_launches": 0, "integrate_launches": 0, "ticks": 0, "fallback": 0, "solver_pairs": 0, "per_world": []}
 
     def run(scene, n_ticks, **kw):
         w = World.from_scene(scene, flags=MULTI_LAUNCH, **kw)   # the tile kernels, never the one-workgroup path
-        w.set_profiling_classes(["tick"])
+        w.set_profiling_classes(["tick", "integrate"])
         w.kernel_times(reset=True)
         for _ in range(n_ticks):
             w.step(DT)
-        out["tick_launches"] += w.kernel_times()["tick"]["launches"]
+        kt = w.kernel_times()
+        out["tick_launches"] += kt["tick"]["launches"]
+        out["integrate_launches"] += kt["integrate"]["launches"]
+        out["ticks"] += n_ticks
         w.set_profiling(False)
         w.tick_begin(DT)                 # one tick substep by substep (the launch-per-stage path in both settings) ...
         for _ in range(scene.substeps):
