@@ -2008,7 +2008,7 @@ __device__ __forceinline__ uint32_t next_item(Counters* __restrict__ ctr, int fl
     __shared__ uint32_t s_item;
     if (threadIdx.x == 0) s_item = __hip_atomic_fetch_add(ticket_of(ctr, flags), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
-    return s_item;
+    return __builtin_amdgcn_readfirstlane(s_item);   // (uniform, and the compiler is told so: the batch's descriptor and what follows from it stay in scalar registers)
 }
 
 // The ticket of the workgroup's NEXT batch is taken while the current one is solved, by the first lane of the last
@@ -2252,7 +2252,7 @@ __global__ __launch_bounds__(NT, (NT == 256 && SFX_TILE_MIN_WAVES < 3) ? 3 : SFX
     const __amdgpu_buffer_rsrc_t dpos_rs = record_rsrc(B.dpos);
     const uint32_t nitems = phase_total(ctr, ph0, nph);
     __shared__ uint32_t s_next;
-    for (uint32_t item = next_item(ctr, flags); item < nitems; item = s_next) {
+    for (uint32_t item = next_item(ctr, flags); item < nitems; item = __builtin_amdgcn_readfirstlane(s_next)) {
         SFX_TT(tt0);
         const PhaseItem pi = phase_item(ctr, ph0, nph, item);
         const uint32_t ph = pi.ph, it = pi.it;
@@ -2411,7 +2411,7 @@ __global__ __launch_bounds__(NT, SFX_TILE_MIN_WAVES) void k_tile_vel(uint32_t ph
     if (only_near) flags &= ~kTileFallback;   // (the fallback list follows the LAST batch: the far launch has it)
     const uint32_t nitems = only_near ? min(ctr->n_near, T.near_cap) : phase_total(ctr, ph0, nph);
     __shared__ uint32_t s_next;
-    for (uint32_t item = strided ? blockIdx.x : next_item(ctr, flags); item < nitems; item = s_next) {
+    for (uint32_t item = strided ? blockIdx.x : next_item(ctr, flags); item < nitems; item = __builtin_amdgcn_readfirstlane(s_next)) {
         PhaseItem pi;
         if (only_near) { const uint32_t v = T.near_list[item]; pi.ph = v >> 24; pi.it = v & 0xFFFFFFu; pi.ok = true; }
         else pi = phase_item(ctr, ph0, nph, item);
@@ -2835,7 +2835,7 @@ __global__ __launch_bounds__(NT, SFX_TICK_WAVES) void k_tile_tick(uint32_t nsub,
     const uint32_t nitems = S * 2u * nsub;
     const bool has_fb = ctr->n_fb != 0u;
     const float4 zero4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (uint32_t item = next_item(ctr, flags); item < nitems; item = s_next) {
+    for (uint32_t item = next_item(ctr, flags); item < nitems; item = __builtin_amdgcn_readfirstlane(s_next)) {
         // (the lane's index through a copy the compiler cannot see through, here and again behind the narrowphase and the
         // waits: what is derived from it is then derived per item and per stage, not once per kernel and kept -- or spilled
         // and reloaded inside the colour steps -- across the narrowphase, which wants every register)
