@@ -2624,16 +2624,19 @@ __device__ __forceinline__ void store_record_wt(const ContactArrays& C, __amdgpu
     }
 }
 
-// pose and velocity of a body at the start of substep `s` of the launch, from its record
+// pose and velocity of a body at the start of substep `s` of the tick, from its record
 __device__ __forceinline__ void tick_integrate(float4& p, float4& v, const float2& w, const StepParams& sp, uint32_t s) {
     float4 q;
-    if (w.x > 0.0f || w.y > 0.0f) { integrate_body(p, q, v, w, sp); return; }   // written back at the end of every substep
-    for (uint32_t i = 0; i <= s; ++i) {   // not dynamic: its record is the one of the start of the tick
-        const float4 p0 = p;
-        integrate_body(p, q, v, w, sp);
-        // (a body at rest is a fixed point after at most a rounding of its rotation: the later steps change nothing)
-        if (__float_as_uint(p.x) == __float_as_uint(p0.x) && __float_as_uint(p.y) == __float_as_uint(p0.y) &&
-            __float_as_uint(p.z) == __float_as_uint(p0.z) && __float_as_uint(p.w) == __float_as_uint(p0.w)) break;
+    integrate_body(p, q, v, w, sp);   // a dynamic body: its record is the one of the end of the substep before
+    // A body that is not dynamic is written by nobody inside the tick: its record is the one of the start of the tick,
+    // and substep s sees it integrated s + 1 times (its velocity is constant).  A body at rest is a fixed point after at
+    // most a rounding of its rotation -- the usual case ends here, with the one step above that changed nothing.
+    if (!(w.x > 0.0f || w.y > 0.0f) && s != 0u) {
+        for (uint32_t i = 0; i < s; ++i) {
+            if (__float_as_uint(p.x) == __float_as_uint(q.x) && __float_as_uint(p.y) == __float_as_uint(q.y) &&
+                __float_as_uint(p.z) == __float_as_uint(q.z) && __float_as_uint(p.w) == __float_as_uint(q.w)) break;
+            integrate_body(p, q, v, w, sp);
+        }
     }
 }
 
