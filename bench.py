@@ -561,6 +561,7 @@ def main():
             "tiles": st.n_tiles,
             "fallback_pairs": st.n_fallback,
             "launches_per_step": st.launches,
+            "integration_on_load": bool(integrate_on_load),   # no k_integrate: DESIGN.md "Integration on load" (SFX_FUSE_TICK=0 keeps it)
         },
         "roofline": {
             "bound": "hbm",
