@@ -116,6 +116,8 @@ struct sfx_world {
     int tile_slot = 0;             // ticket counter of the next tile-solve launch (alternates)
     uint32_t ctr_skipped = 0;      // ticks since the last asynchronous read-back of the counters
     uint32_t ctr_age = 0;          // ticks begun since the pending read-back was enqueued
+    bool ctr_fast = false;         // the scene is growing (adopt_counters): counters read back every tick, host at most kFastLag ticks ahead
+    uint32_t prev_pairs = 0, prev_batches = 0;   // of the counters adopted before
     int tile_variant_fixed = -1;   // SFX_TILE_NT=512|256|128 pins the variant (tuning); -1: the default (256)
     int tile_variant_pos = -1, tile_variant_vel = -1;  // SFX_TILE_NT_POS / SFX_TILE_NT_VEL: per kernel (tuning)
     bool fuse_phases = true;
@@ -584,7 +586,7 @@ int broadphase(sfx_world* w, float dt) {
     RP.pose = w->pose.p; RP.vel = w->vel.p; RP.lpose = w->lpose.p; RP.poly = w->poly.p;
     RP.margin = w->cfg.aabb_margin; RP.vel_pad_max = w->cfg.vel_pad_max; RP.dt = dt; RP.sm = w->cfg.speculative_margin;
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
-      const uint32_t est = w->ctr_valid ? w->stale.n_tile_pairs + w->stale.n_tile_pairs / 4u + 4096u : w->max_pairs;
+      const uint32_t est = w->ctr_valid ? w->stale.n_tile_pairs + w->stale.n_tile_pairs / 4u + 16384u : w->max_pairs;
       hipLaunchKernelGGL(k_reach, dim3(cdiv(std::min(est, w->max_pairs), kBlock)), dim3(kBlock), 0, w->stream, w->tile_cnt,
                          w->ntiles, w->max_pairs, w->rawp.p, w->shape.p, RP); }
     { Prof p(w, SFX_K_COLOR, w->max_pairs);
@@ -629,13 +631,22 @@ void adopt_counters(sfx_world* w) {
         // batch of tiles): that tick dropped those pairs and says so; from now on batches hold half as many tiles
         if ((w->stale.overflow & kOvfExt) && w->group_cap > 1u) w->group_cap = std::max(1u, std::min(w->group, w->group_cap) / 2u);
         if (!w->group_fixed) w->group = std::min(w->group, w->group_cap);
-        uint32_t groups = 0;
+        // The grids follow these counters with an eighth of headroom -- and never fall below a floor that costs nothing
+        // (workgroups without a batch or a group leave at once): a scene that grows between two read-backs then runs on
+        // a small grid, not on the handful of workgroups of the scene it was (the chains config: 100 k links fall onto
+        // an empty floor and pile up within sixty ticks).
+        uint32_t groups = 0, batches = 0;
         for (int ph = 0; ph < 4; ++ph) {
             const uint32_t b = w->stale.n_batches[ph];
-            w->tile_grid[ph] = std::min(std::max(b + b / 8u + 4u, 1u), w->tile_grid_max);
+            batches += b;
+            w->tile_grid[ph] = std::min(std::max(b + b / 8u + 4u, 64u), w->tile_grid_max);
         }
         groups = cdiv(w->stale.n_listed[0], w->group);
-        w->color_grid = std::min(std::max(groups + groups / 8u + 4u, 1u), 8192u);
+        w->color_grid = std::min(std::max(groups + groups / 8u + 4u, 128u), 8192u);
+        // growing: more than an eighth more pairs or batches than the counters before said -- until it stops, the counters
+        // are read back after every tick and the host stays close behind them (sfx_tick_begin, substeps_done)
+        w->ctr_fast = w->stale.n_pairs > w->prev_pairs + w->prev_pairs / 8u + 1024u || batches > w->prev_batches + w->prev_batches / 8u + 16u;
+        w->prev_pairs = w->stale.n_pairs; w->prev_batches = batches;
     }
 }
 
@@ -1023,6 +1034,7 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
     HIPCHK(w, hipMemset(w->sticky.p, 0, sizeof(uint32_t)));   // every table is new: earlier overflows no longer apply
     w->ovf_host = 0;
     w->ctr_valid = false; w->ctr_pending = false;
+    w->ctr_fast = false; w->prev_pairs = w->prev_batches = 0;
     w->ticked = false;
     w->q_valid = false;
     return rebuild_filt(w);
@@ -1169,7 +1181,9 @@ int sfx_tick_begin(sfx_world* w, float frame_dt) {
     // sweeps on the few workgroups of the empty scene (measured on the chains config: 4.4 ms per tick instead of 0.5) --
     // so the host waits for a read-back that is kMaxLag ticks old (the device still has that many ticks queued: no bubble).
     static const uint32_t max_lag = [] { const char* e = getenv("SFX_CTR_MAX_LAG"); return e ? (uint32_t)std::max(0, atoi(e)) : 16u; }();
-    if (w->ctr_pending && max_lag && ++w->ctr_age > max_lag) HIPCHK(w, hipEventSynchronize(w->ev_ctr));
+    constexpr uint32_t kFastLag = 3;   // while the scene grows (three ticks are still queued on the device: no bubble)
+    const uint32_t lag = w->ctr_fast ? std::min(max_lag, kFastLag) : max_lag;
+    if (w->ctr_pending && max_lag && ++w->ctr_age > lag) HIPCHK(w, hipEventSynchronize(w->ev_ctr));
     poll_counters(w);
     if (w->ovf_host)
         return fail(w, SFX_ERR_CAPACITY, "capacity exceeded in an earlier tick (bits %u, listed by sfx_sync): its results are incomplete; sfx_sync reports "
@@ -1384,7 +1398,7 @@ static int substeps_done(sfx_world* w, uint32_t count, bool mirror) {
         static const uint32_t every = [] { const char* e = getenv("SFX_CTR_EVERY"); return e ? (uint32_t)std::max(1, atoi(e)) : 8u; }();
         // the counters only size the next ticks' grids (every kernel loops over what it is given), so they are read
         // back every few ticks: the copy costs the stream about 6 us
-        if (!w->ctr_pending && (!w->ctr_valid || ++w->ctr_skipped >= every)) {
+        if (!w->ctr_pending && (!w->ctr_valid || ++w->ctr_skipped >= (w->ctr_fast ? 1u : every))) {
             w->ctr_skipped = 0;
             w->ctr_age = 0;
             HIPCHK(w, hipMemcpyAsync(w->h_ctr, w->ctr, sizeof(Counters), hipMemcpyDeviceToHost, w->stream));
