@@ -174,6 +174,9 @@ struct sfx_world {
     std::vector<uint32_t> joint_perm;
     std::vector<uint8_t> joint_color_sorted;
     std::vector<uint32_t> joint_color_start;  // n_joint_colors + 1
+    // joints by component (k_joint_groups): groups of whole components, their joints colour by colour; 0 groups = a launch per colour
+    uint32_t joint_groups = 0;
+    DevBuf<uint32_t> jg_cstart, jg_index;
     // asynchronous pose read-back (sfx_readback_begin / _wait): two slots, each a device snapshot + a pinned host copy
     hipStream_t rb_stream = nullptr;
     DevBuf<float4> rb_dev[2];
@@ -843,7 +846,7 @@ void sfx_destroy(sfx_world* w) {
     w->q_large_tmp.release(); w->q_bounds.release(); w->q_nhits.release(); w->q_aabb.release(); w->q_sorted_aabb.release();
     w->q_cellxy.release(); w->q_sorted_cell.release(); w->q_in.release(); w->q_out.release();
     w->c_rec.release(); w->c_lam.release();
-    w->j_bodies.release(); w->j_anchors.release(); w->j_params.release(); w->j_count_dev.release();
+    w->j_bodies.release(); w->j_anchors.release(); w->j_params.release(); w->j_count_dev.release(); w->jg_cstart.release(); w->jg_index.release();
     if (w->rb_stream) (void)hipStreamSynchronize(w->rb_stream);
     for (int k = 0; k < 2; ++k) {
         w->rb_dev[k].release();
@@ -1042,6 +1045,59 @@ int sfx_upload_colliders(sfx_world* w, uint32_t n, const sfx_collider* col, cons
 
 namespace {
 
+// Joints by component (sfx_kernels.h k_joint_groups): the connected components of the joint graph, packed whole into groups
+// of at most kJointGroupCap joints; per group its joints colour by colour.  hb: the colour-sorted joints' bodies.  A world
+// with a larger component (a net, a long rope) keeps a launch per colour (joint_groups = 0).  SFX_JOINT_GROUPS=0: never.
+int group_joints(sfx_world* w, const std::vector<uint2>& hb, uint32_t nc) {
+    static const bool off = [] { const char* e = getenv("SFX_JOINT_GROUPS"); return e && e[0] == '0'; }();
+    const uint32_t m = (uint32_t)hb.size();
+    w->joint_groups = 0;
+    if (off || m == 0 || nc == 0) return SFX_OK;
+    std::vector<uint32_t> parent(w->nb);
+    for (uint32_t i = 0; i < w->nb; ++i) parent[i] = i;
+    auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    for (uint32_t d = 0; d < m; ++d) {
+        const uint32_t a = hb[d].x, b = hb[d].y;
+        if (a == SFX_WORLD_BODY || b == SFX_WORLD_BODY) continue;
+        const uint32_t ra = find(a), rb = find(b);
+        if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb);
+    }
+    // component of a joint = the root of one of its bodies; components in the order of their first joint
+    std::vector<uint32_t> comp_of(m), comp_id(w->nb, 0xFFFFFFFFu), comp_size;
+    for (uint32_t d = 0; d < m; ++d) {
+        const uint32_t body = hb[d].x != SFX_WORLD_BODY ? hb[d].x : hb[d].y;
+        if (body == SFX_WORLD_BODY) return SFX_OK;   // (a joint between the world and the world: nothing to group by)
+        const uint32_t r = find(body);
+        if (comp_id[r] == 0xFFFFFFFFu) { comp_id[r] = (uint32_t)comp_size.size(); comp_size.push_back(0); }
+        comp_of[d] = comp_id[r];
+        if (++comp_size[comp_of[d]] > kJointGroupCap) return SFX_OK;
+    }
+    std::vector<uint32_t> group_of_comp(comp_size.size());
+    uint32_t ng = 0, fill = 0;
+    for (size_t c = 0; c < comp_size.size(); ++c) {
+        if (c == 0 || fill + comp_size[c] > kJointGroupCap) { ++ng; fill = 0; }
+        fill += comp_size[c];
+        group_of_comp[c] = ng - 1;
+    }
+    // per group and colour: counts, then offsets, then the joints (d ascending inside a colour)
+    std::vector<uint32_t> cstart((size_t)ng * (nc + 1), 0), index(m);
+    for (uint32_t d = 0; d < m; ++d) cstart[(size_t)group_of_comp[comp_of[d]] * (nc + 1) + w->joint_color_sorted[d] + 1]++;
+    uint32_t run = 0;
+    for (uint32_t gq = 0; gq < ng; ++gq) {
+        uint32_t* cs = &cstart[(size_t)gq * (nc + 1)];
+        cs[0] = run;
+        for (uint32_t c = 0; c < nc; ++c) { const uint32_t cnt = cs[c + 1]; cs[c + 1] = cs[c] + cnt; }
+        run = cs[nc];
+    }
+    std::vector<uint32_t> cur(cstart);
+    for (uint32_t d = 0; d < m; ++d) index[cur[(size_t)group_of_comp[comp_of[d]] * (nc + 1) + w->joint_color_sorted[d]]++] = d;
+    ALLOC(w, w->jg_cstart, cstart.size()); ALLOC(w, w->jg_index, m);
+    HIPCHK(w, hipMemcpy(w->jg_cstart.p, cstart.data(), sizeof(uint32_t) * cstart.size(), hipMemcpyHostToDevice));
+    HIPCHK(w, hipMemcpy(w->jg_index.p, index.data(), sizeof(uint32_t) * m, hipMemcpyHostToDevice));
+    w->joint_groups = ng;
+    return SFX_OK;
+}
+
 // colours the joint list (distance constraints, then angle constraints) and uploads it colour-sorted
 int rebuild_joints(sfx_world* w) {
     const uint32_t md = (uint32_t)w->h_dist.size(), m = md + (uint32_t)w->h_angle.size();
@@ -1050,6 +1106,7 @@ int rebuild_joints(sfx_world* w) {
     w->joint_color_sorted.assign(m, 0);
     w->joint_color_start.assign(1, 0);
     w->joint_damped = false;
+    w->joint_groups = 0;
     if (m == 0) return SFX_OK;
     // colour the joint graph once, on the device, with the same kernels as the contact graph
     std::vector<uint2> ab(m);
@@ -1114,7 +1171,7 @@ int rebuild_joints(sfx_world* w) {
     HIPCHK(w, hipMemcpy(w->j_bodies.p, hb.data(), sizeof(uint2) * m, hipMemcpyHostToDevice));
     HIPCHK(w, hipMemcpy(w->j_anchors.p, ha.data(), sizeof(float4) * m, hipMemcpyHostToDevice));
     HIPCHK(w, hipMemcpy(w->j_params.p, hp.data(), sizeof(float4) * m, hipMemcpyHostToDevice));
-    return SFX_OK;
+    return group_joints(w, hb, nc);
 }
 
 int constraints_ready(sfx_world* w, uint32_t m, const void* c) {
@@ -1280,7 +1337,11 @@ int sfx_tick_substep(sfx_world* w) {
     const bool last_substep = w->substeps_done + 1u >= w->cfg.substeps;
     if (fuse_derive && ++w->vel_epoch == 0u) w->vel_epoch = 1u;   // (0 means "off")
     const uint32_t vstamp = fuse_derive ? w->vel_epoch : 0u;
-    for (uint32_t jc = 0; jc < njc; ++jc) {
+    if (w->joint_groups) {   // every colour in one launch, component by component (k_joint_groups)
+        Prof p(w, SFX_K_SOLVE_JOINTS, w->m);
+        hipLaunchKernelGGL(k_joint_groups<false>, dim3(w->joint_groups), dim3(kJointGroupThreads), 0, w->stream, njc, w->jg_cstart.p, w->jg_index.p, B, J, sp.inv_h2);
+    }
+    for (uint32_t jc = 0; !w->joint_groups && jc < njc; ++jc) {
         const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
         if (!cnt) continue;
         Prof p(w, SFX_K_SOLVE_JOINTS, cnt);
@@ -1346,7 +1407,11 @@ int sfx_tick_substep(sfx_world* w) {
       Prof p(w, SFX_K_DERIVE_VEL, w->nb);
       hipLaunchKernelGGL(k_derive, dim3(gb), dim3(kBlock), 0, w->stream, w->nb, w->pose.p, w->prev.p, w->vel.p, w->dpos.p, w->mass.p, sp, 0u);
     }
-    for (uint32_t jc = 0; w->joint_damped && jc < njc; ++jc) {
+    if (w->joint_damped && w->joint_groups) {
+        Prof p(w, SFX_K_SOLVE_JOINTS, w->m);
+        hipLaunchKernelGGL(k_joint_groups<true>, dim3(w->joint_groups), dim3(kJointGroupThreads), 0, w->stream, njc, w->jg_cstart.p, w->jg_index.p, B, J, sp.h);
+    }
+    for (uint32_t jc = 0; w->joint_damped && !w->joint_groups && jc < njc; ++jc) {
         const uint32_t start = w->joint_color_start[jc], cnt = w->joint_color_start[jc + 1] - start;
         if (!cnt) continue;
         Prof p(w, SFX_K_SOLVE_JOINTS, cnt);

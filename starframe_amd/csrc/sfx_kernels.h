@@ -3386,6 +3386,32 @@ __global__ __launch_bounds__(kBlock) void k_damp_joints(uint32_t start, uint32_t
     if (k < cnt) damp_joint(B, J, start + k, h);
 }
 
+// All joint colours of a substep in ONE launch (DESIGN.md "Joints by component").  The joint graph falls into connected
+// components (a chain, a ragdoll) that share no body, so the order of the solves only matters inside a component; the host
+// packs whole components into groups of at most kJointGroupCap joints, and one workgroup takes a group through the colours
+// in order, a workgroup barrier between two colours (the writes of one wave are the reads of another: same workgroup, so
+// __syncthreads() orders them) where the launch-per-colour path has a launch boundary.  Per body the same solves in the same
+// order: bit-identical.  cstart[g * (ncolors + 1) + c] .. [c + 1]: the group's joints of colour c in `index` (positions in
+// the colour-sorted joint arrays).  A world with a larger component keeps the launch per colour.
+constexpr uint32_t kJointGroupCap = 256;
+constexpr int kJointGroupThreads = 128;
+
+template <bool DAMP>
+__global__ __launch_bounds__(kJointGroupThreads) void k_joint_groups(uint32_t ncolors, const uint32_t* __restrict__ cstart,
+                                                                     const uint32_t* __restrict__ index, BodyArrays B, JointArrays J,
+                                                                     float param /* inv_h2 | h */) {
+    const uint32_t* cs = cstart + (size_t)blockIdx.x * (ncolors + 1u);
+    for (uint32_t c = 0; c < ncolors; ++c) {
+        const uint32_t s = cs[c], e = cs[c + 1u];
+        for (uint32_t i = s + threadIdx.x; i < e; i += kJointGroupThreads) {
+            const uint32_t k = index[i];
+            if (DAMP) damp_joint(B, J, k, param);
+            else solve_joint(B, J, k, param);
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------- slab halos
 // (pose, velocity) of the listed bodies <-> a dense [n][2] float4 buffer
 __global__ __launch_bounds__(kBlock) void k_halo_pack(uint32_t n, const uint32_t* __restrict__ idx,
