@@ -64,6 +64,7 @@ def main():
     run(scenes.mixed_pile(n=30_000, width=300), 120)                                 # strips
     run(scenes.mixed_pile(n=12_000, width=40, pitch=0.16), 60, tile_cells=8, tile_cells_y=8)   # over-full tiles: a fallback list
     run(scenes.circles_container(n=10_000), 60)
+    run(scenes.random_soup(300, seed=77, extent=80.0, with_statics=False), 12)   # sparse: hardly a pair -- nearly every body is stepped by k_tick_free
     print(json.dumps(out))
 
 
