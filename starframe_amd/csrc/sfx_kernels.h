@@ -1881,6 +1881,11 @@ struct RawSide {
     bool in_range;
 };
 
+template <typename V>
+__device__ __forceinline__ V load_at(const void* base, uint32_t byte_off) {
+    return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 template <bool VEL>
 __device__ __forceinline__ void fetch_side(const TileArrays& T, const ContactArrays& C, uint32_t slot, uint32_t side, bool in_range,
                                            RawSide& q) {
@@ -1891,16 +1896,21 @@ __device__ __forceinline__ void fetch_side(const TileArrays& T, const ContactArr
     q.lam = make_float2(0.0f, 0.0f);
     q.hc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     q.hd = make_float2(0.0f, 0.0f);
-    q.pr = T.tpair[slot];
-    q.ha = rec_plane(C, kPlA)[slot];
-    q.hb = rec_plane(C, kPlB)[slot];
-    q.he = rec_plane(C, kPlE)[slot];
-    q.hf = rec_plane(C, kPlF)[slot];
-    q.hg = rec_plane(C, kPlG)[slot];
+    // every array at (uniform base) + (one 32-bit byte offset per lane): global loads with a scalar base, no 64-bit address
+    // arithmetic per plane in the colour step's instruction chain (slots < 2^28: sfx_upload_bodies caps a world at 16 M entries,
+    // twelve pairs each).  Measured: two VGPRs fewer, the tick within +-0.1 % (profiles/r03/ab_scalar_base_fetch.log) -- the
+    // address arithmetic was not what a step waits for.
+    const uint32_t o16 = slot * 16u;
+    q.pr = load_at<uint4>(T.tpair, o16);
+    q.ha = load_at<float4>(rec_plane(C, kPlA), o16);
+    q.hb = load_at<float4>(rec_plane(C, kPlB), o16);
+    q.he = load_at<float4>(rec_plane(C, kPlE), o16);
+    q.hf = load_at<float4>(rec_plane(C, kPlF), o16);
+    q.hg = load_at<float4>(rec_plane(C, kPlG), o16);
     if (VEL) {
-        q.hc = rec_plane(C, kPlC)[slot];
-        q.hd = *reinterpret_cast<const float2*>(rec_plane(C, kPlD) + slot);
-        q.lam = C.lam[slot];
+        q.hc = load_at<float4>(rec_plane(C, kPlC), o16);
+        q.hd = load_at<float2>(rec_plane(C, kPlD), o16);
+        q.lam = load_at<float2>(C.lam, slot * 8u);
     }
 }
 
