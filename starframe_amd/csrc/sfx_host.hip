@@ -1307,11 +1307,15 @@ static int small_substeps(sfx_world* w, uint32_t nsub) {
     return substeps_done(w, nsub, false);
 }
 
+static bool tick_fused(const sfx_world* w, bool one_substep);
+static int tick_substeps(sfx_world* w, bool one_substep);
+
 int sfx_tick_substep(sfx_world* w) {
     if (!w) return SFX_ERR_INVALID;
     if (!w->tick_open) return fail(w, SFX_ERR_INVALID, "sfx_tick_substep without sfx_tick_begin");
     HIPCHK(w, hipSetDevice(w->device));
     if (small_world(w)) return small_substeps(w, 1u);
+    if (!w->in_step && tick_fused(w, true)) return tick_substeps(w, true);   // integration on load, substep by substep (slab drivers)
 
     const StepParams sp = w->sp;
     w->q_valid = false;
@@ -1488,22 +1492,26 @@ static const int g_fuse_tick_mode = [] { const char* e = getenv("SFX_FUSE_TICK")
                                                                                     // measured and not kept as defaults: 1: one launch per tick, 2: per substep a narrowphase launch + one launch of both sweeps
 static const bool g_fuse_tick_off = g_fuse_tick_mode == 0;
 
-static bool tick_fused(const sfx_world* w) {
+// one_substep: asked by sfx_tick_substep, which runs ONE substep and must leave every body final for its caller (a slab driver
+// packs its halo next): the default form only, halos allowed (a ghost is a dynamic body whose record the unpack refreshes),
+// k_tick_free after every substep; not with the exchange overlapped (the near launch's pack would overtake k_tick_free).
+static bool tick_fused(const sfx_world* w, bool one_substep) {
     static const bool other_knobs = [] {   // the launch-per-stage variants these knobs ask for
         const char* a = getenv("SFX_FUSE_DERIVE"); const char* b = getenv("SFX_FUSE_NARROW");
         return (a && a[0] == '0') || (b && atoi(b) != 1);
     }();
     if (g_fuse_tick_off || other_knobs || !w->fuse_phases || w->resident_tick < 32u || w->resident_pos_i < 32u || w->resident_vel_i < 32u) return false;
-    if (w->joint_color_start.size() > 1 || w->joint_damped || w->n != w->nb || w->n_halo_send || w->n_halo_recv) return false;
+    if (w->joint_color_start.size() > 1 || w->joint_damped || w->n != w->nb) return false;
+    if (one_substep ? (g_fuse_tick_mode != 3 || split_sweep(w)) : (w->n_halo_send || w->n_halo_recv)) return false;
     if (w->tile_variant_fixed >= 0 && w->tile_variant_fixed != 1) return false;
     if ((w->tile_variant_pos >= 0 && w->tile_variant_pos != 1) || (w->tile_variant_vel >= 0 && w->tile_variant_vel != 1)) return false;
     if (((uint64_t)w->max_pairs + w->fb_cap) * kRecPlanes * 16ull >= 0xFFFFFFF0ull) return false;   // record planes addressed by 32-bit byte offsets
     return true;
 }
 
-static int tick_substeps(sfx_world* w) {
+static int tick_substeps(sfx_world* w, bool one_substep) {
     const StepParams sp = w->sp;
-    const uint32_t nsub = w->cfg.substeps;
+    const uint32_t nsub = one_substep ? 1u : w->cfg.substeps;   // substeps of this call (one_substep: k_tick_free writes every body after it, so it is "substep 0" again)
     w->q_valid = false;
     const BodyArrays B = body_arrays(w);
     const ContactArrays C = contact_arrays(w);
@@ -1570,7 +1578,7 @@ static int tick_substeps(sfx_world* w) {
 int sfx_step(sfx_world* w, float frame_dt) {
     int rc = sfx_tick_begin(w, frame_dt);
     if (rc == SFX_OK && small_world(w)) return small_substeps(w, w->cfg.substeps);   // the whole tick in one launch
-    if (rc == SFX_OK && tick_fused(w)) return tick_substeps(w);                      // the substeps in one launch
+    if (rc == SFX_OK && tick_fused(w, false)) return tick_substeps(w, false);        // integration on load (or the substeps in one launch)
     w->in_step = true;   // the substeps below are the whole tick: velocities may stay underived between them
     for (uint32_t s = 0; rc == SFX_OK && s < w->cfg.substeps; ++s) rc = sfx_tick_substep(w);
     w->in_step = false;
