@@ -116,8 +116,9 @@ def tick_bytes_per_body_substep(st, n_dyn, substeps, fused_narrow=False, integra
     integrate = 16 + 16 + 8 + 16 + 16 + 16 + 16     # pose, vel, mass read; prev, pose, vel, zero displacement written
     if integrate_on_load:
         # no k_integrate (DESIGN.md "Integration on load"): the sweeps integrate the records they read anyway; what is left
-        # is the zero displacement written where a body is derived and one k_tick_free per tick (mass and velocity read)
-        integrate = 16 + (8 + 16) / substeps
+        # is the zero displacement written where a body is derived and one k_tick_free per tick (mass and velocity read) --
+        # per substep where the tick is driven substep by substep (integrate_on_load == "substep": the slab drivers)
+        integrate = 16 + (8 + 16) / (1 if integrate_on_load == "substep" else substeps)
     derive = 0                                      # applied and derived where the velocity solve loads a body: in kernel_bytes
     p = st.n_pairs / n_dyn
     broad = (16 + 16 + 16 + 16 + 4 + 8 + 4 + 4 + 28 + 16 * 5 + p * (8 + 8 + 2 + 16 + 16)) / substeps
@@ -526,7 +527,10 @@ def main():
     kernel_ms = {k: round(v["total_ms"] / prof_frames, 4) for k, v in kt.items() if v["launches"]}
     value = n_dyn * scene.substeps * args.steps / elapsed
     n_rank = slab.plan.n_owned if slab is not None else n_dyn
-    integrate_on_load = kt["integrate"]["launches"] == prof_frames   # one k_tick_free per tick instead of k_integrate per substep
+    # one k_tick_free per tick instead of k_integrate per substep -- or, substep by substep (the slab drivers), one per substep
+    # and no k_derive
+    integrate_on_load = (True if kt["integrate"]["launches"] == prof_frames else
+                         "substep" if kt["integrate"]["launches"] == prof_frames * scene.substeps and kt["derive_vel"]["launches"] == 0 else False)
     bpbs = tick_bytes_per_body_substep(st2, n_rank, scene.substeps, fused_narrow, integrate_on_load)
 
     out = {
