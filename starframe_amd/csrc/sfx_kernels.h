@@ -3441,7 +3441,9 @@ __global__ __launch_bounds__(kBlock) void k_halo_unpack(uint32_t n, const uint32
     if (k >= n) return;
     const uint32_t i = idx[k];
     pose[i] = in[2 * k];
-    vel[i] = in[2 * k + 1];
+    float4 v = in[2 * k + 1];
+    v.w = 0.0f;   // the sender's derive stamp means nothing here (and must never look like one of this world's: "stepped already")
+    vel[i] = v;
 }
 
 // x of every body at the moment the halo lists were cut (the reference of the halo guard)
