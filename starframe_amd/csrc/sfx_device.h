@@ -995,10 +995,12 @@ __device__ __forceinline__ float gen_inv_mass(const float2& w, float rx, float r
     return w.x + w.y * (rn * rn);
 }
 
+// one joint from its three records (k_joint_groups fetches them a colour ahead), and from its index
+__device__ __forceinline__ void solve_joint_rec(const BodyArrays& B, const uint2& ab, const float4& an, const float4& pr, float inv_h2);
 __device__ __forceinline__ void solve_joint(const BodyArrays& B, const JointArrays& J, uint32_t k, float inv_h2) {
-    const uint2 ab = J.bodies[k];
-    const float4 an = J.anchors[k];
-    const float4 pr = J.params[k];
+    solve_joint_rec(B, J.bodies[k], J.anchors[k], J.params[k], inv_h2);
+}
+__device__ __forceinline__ void solve_joint_rec(const BodyArrays& B, const uint2& ab, const float4& an, const float4& pr, float inv_h2) {
     const uint32_t a = ab.x, b = ab.y;
     float rax = 0.0f, ray = 0.0f, rbx = 0.0f, rby = 0.0f, pax, pay, pbx, pby;
     float4 pa = make_float4(0, 0, 1, 0), pb = make_float4(0, 0, 1, 0);
